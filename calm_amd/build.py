@@ -1,0 +1,71 @@
+"""Build recipes (explicit hipcc / gcc invocations, in-tree outputs).
+
+    python -m calm_amd.build            # libcalm_hip.so (+ calm_hip_run CLI)
+    python -m calm_amd.build --all      # + the oracle checker and, when /root/reference exists, oracle/_ref
+
+The product is calm_amd/libcalm_hip.so: hand-written HIP for gfx950 behind the C ABI of
+include/calm_hip.h.  hipcc cross-compiles without a GPU.  The built .so is git-ignored but travels to
+the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "calm_amd", "csrc")
+LIB_HIP = os.path.join(ROOT, "calm_amd", "libcalm_hip.so")
+RUN_HIP = os.path.join(ROOT, "calm_amd", "calm_hip_run")
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REFERENCE = os.environ.get("CALM_REFERENCE", "/root/reference")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _run(cmd, **kw):
+    print("+", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True, **kw)
+
+
+def hip_sources():
+    inc = os.path.join(ROOT, "include")
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
+
+
+def build_hip(force: bool = False) -> str:
+    """compile every HIP translation unit for gfx950 into libcalm_hip.so"""
+    srcs = hip_sources()
+    if force or not _newer(LIB_HIP, srcs):
+        _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP, os.path.join(CSRC, "infer_hip.hip")])
+    host_src = os.path.join(CSRC, "run_hip.cpp")
+    if os.path.exists(host_src) and (force or not _newer(RUN_HIP, srcs + [LIB_HIP])):
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", RUN_HIP, host_src, LIB_HIP, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
+    return LIB_HIP
+
+
+def build_oracle(force: bool = False) -> str:
+    """the CPU checker (test infrastructure): our C restatement, and the real reference when present"""
+    args = ["make", "-C", ORACLE_DIR]
+    if force:
+        args.append("-B")
+    _run(args + ["liboracle.so"])
+    if os.path.isdir(os.path.join(REFERENCE, "src")):
+        _run(args + [f"REF={REFERENCE}", "ref"])
+        if os.path.exists(LIB_HIP):
+            _run(args + [f"REF={REFERENCE}", "_ref/run_hip"])
+    return os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+if __name__ == "__main__":
+    build_hip(force="--force" in sys.argv)
+    if "--all" in sys.argv:
+        build_oracle(force="--force" in sys.argv)

@@ -1,0 +1,987 @@
+// infer_hip.hip -- host side of the MI355X infer backend: the C ABI of include/calm_hip.h.
+//
+// Mirrors the role of the reference's src/infer.cu host code (upload_cuda :69-71, prepare_cuda
+// :73-131, forward<T,KVT,AT> :651-741, perf_cuda :761-801) but not its structure: instead of one
+// cooperative megakernel with 6-7 software grid barriers per layer (4-26 us each on this chip),
+// a decode step is ~5 dependent weight-streaming kernels per layer, replayed from a hipGraph
+// (kernel boundary ~1.2-1.9 us).  All per-token scalars travel through a device-resident
+// TokState written by the graph's first kernel, whose arguments are patched before each replay.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <tuple>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/calm_hip.h"
+#include "../../include/calm_hip_test.h"
+#include "kernels.hip.h"
+
+using namespace calm;
+
+#define HIP_CHECK(x)                                                                                                                              \
+	do {                                                                                                                                          \
+		hipError_t err_ = (x);                                                                                                                    \
+		if (err_ != hipSuccess) {                                                                                                                 \
+			fprintf(stderr, "HIP error in %s at %s:%d: %s (%s=%d)\n", __FUNCTION__, __FILE__, __LINE__, hipGetErrorString(err_), hipGetErrorName(err_), \
+			        (int)err_);                                                                                                                   \
+			abort();                                                                                                                              \
+		}                                                                                                                                         \
+	} while (0)
+
+#define CALM_REQUIRE(cond, msg)                                                         \
+	do {                                                                                \
+		if (!(cond)) {                                                                  \
+			fprintf(stderr, "calm_hip: %s (%s) at %s:%d\n", msg, #cond, __FILE__, __LINE__); \
+			abort();                                                                    \
+		}                                                                               \
+	} while (0)
+
+namespace {
+
+constexpr int LDS_EXTRA = 1024; // reduction scratch + MoE routing scratch behind the activation image
+constexpr int MAX_SPLIT = 64;
+
+hipStream_t g_stream;
+int g_device = -1;
+int g_ncu = 256;
+int g_bpc = 4;       // cap on resident 256-thread workgroups per CU when sizing grids
+int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
+int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
+int g_split_t = 1024; // kv positions per attention split
+char g_devname[256] = "none";
+
+int env_int(const char* name, int dflt) {
+	const char* v = getenv(name);
+	return v && *v ? atoi(v) : dflt;
+}
+
+void* dev_alloc(size_t size) {
+	void* p = nullptr;
+	HIP_CHECK(hipMalloc(&p, size ? size : 16));
+	return p;
+}
+
+struct StageProf {
+	double us = 0;
+	uint64_t bytes = 0;
+	uint64_t runs = 0;
+};
+
+struct GraphEntry {
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+	hipGraphNode_t begin_node = nullptr;
+};
+
+struct Ctx {
+	struct Transformer* t = nullptr;
+	// shapes
+	int dim = 0, hidden = 0, head_dim = 0, n_layers = 0, n_heads = 0, n_kv_heads = 0, vocab = 0, seq_len = 0;
+	int q_dim = 0, kv_dim = 0, kv_mul = 0, n_experts = 0, n_active = 0, dbits = 0, kvbits = 0, lpr = 0;
+	// device state
+	float *x = nullptr, *xb = nullptr, *q = nullptr, *att = nullptr, *he = nullptr, *partial = nullptr, *logits_d = nullptr;
+	float *moe_w = nullptr, *rope_freq = nullptr;
+	int *moe_e = nullptr, *next_tok = nullptr, *trace = nullptr, *trace_count = nullptr;
+	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
+	TokState* ts = nullptr;
+	void *kc = nullptr, *vc = nullptr;
+	size_t kv_layer_bytes = 0;
+	float* logits_h = nullptr; // pinned host
+	int trace_cap = 0;
+	// graph cache: (n_split, kv_only, sink, chained, argmax)
+	std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
+	// argument block of the begin-token kernel (patched per replay)
+	struct BeginArgs {
+		TokState* ts;
+		int token;
+		const int* tok_src;
+		int pos, kv_sink, kv_pos, kv_len;
+		float* x;
+		const void* embed;
+		int dim;
+		const float* rope_freq;
+		float2* rope_cs;
+		int half_hd;
+	} ba;
+	void* ba_ptrs[13];
+	// profiling
+	StageProf prof[CALM_STAGE_COUNT];
+	std::vector<hipEvent_t> events;
+};
+
+std::map<struct Transformer*, Ctx*> g_ctx;
+Ctx* g_prof_ctx = nullptr;
+
+Ctx* ctx_of(struct Transformer* t) {
+	auto it = g_ctx.find(t);
+	CALM_REQUIRE(it != g_ctx.end(), "forward_hip called on a transformer that was not prepared with prepare_hip");
+	return it->second;
+}
+
+// choose a grid for `ntasks` wave-tasks at `wpb` waves per workgroup: everything resident if it fits,
+// else a whole number of workgroups per CU that wastes the fewest wave-slots (ties: more waves)
+int pick_blocks(int ntasks, int wpb) {
+	int need = (ntasks + wpb - 1) / wpb;
+	if (need <= g_ncu * g_bpc) {
+		return need > 0 ? need : 1;
+	}
+	int best_b = 1;
+	double best_waste = 1e30;
+	for (int b = 1; b <= g_bpc; ++b) {
+		long waves = (long)g_ncu * b * wpb;
+		long rounds = (ntasks + waves - 1) / waves;
+		double waste = (double)(rounds * waves) / ntasks;
+		if (waste <= best_waste + 1e-9) {
+			best_waste = waste;
+			best_b = b;
+		}
+	}
+	return g_ncu * best_b;
+}
+
+template <int DB>
+size_t lds_bytes(int n) {
+	return (size_t)xs_slots<DB>(n) * 16 + LDS_EXTRA;
+}
+
+template <class K>
+void allow_lds(K kernel, size_t bytes) {
+	if (bytes > 48 * 1024) {
+		CALM_REQUIRE(bytes <= 160 * 1024, "activation vector does not fit the 160 KiB LDS");
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	}
+}
+
+// ---------------------------------------------------------------- stage launchers ---------------
+
+template <int DB>
+void launch_begin(Ctx* c) {
+	int n = c->dim > c->head_dim / 2 ? c->dim : c->head_dim / 2;
+	hipLaunchKernelGGL((k_begin_token<DB>), dim3((n + 255) / 256), dim3(256), 0, g_stream, c->ba.ts, c->ba.token, c->ba.tok_src, c->ba.pos, c->ba.kv_sink,
+	                   c->ba.kv_pos, c->ba.kv_len, c->ba.x, c->ba.embed, c->ba.dim, c->ba.rope_freq, c->ba.rope_cs, c->ba.half_hd);
+}
+
+template <int KVB>
+void launch_rotate_sink(Ctx* c) {
+	int total = c->n_kv_heads * CALM_KV_SINKS * (c->head_dim / 2);
+	hipLaunchKernelGGL((k_rotate_sink<KVB>), dim3((total + 255) / 256, c->n_layers), dim3(256), 0, g_stream, c->kc, c->rope_cs1, c->n_kv_heads, c->head_dim,
+	                   c->seq_len, CALM_KV_SINKS);
+}
+
+template <int DB, int KVB>
+void launch_qkv(Ctx* c, int l) {
+	struct Config* p = &c->t->config;
+	struct Weights* w = &c->t->weights;
+	QkvArgs a;
+	a.x = c->x;
+	a.norm_w = w->rms_att_weight[l];
+	a.wq = w->wq[l], a.wk = w->wk[l], a.wv = w->wv[l];
+	a.bqkv = w->bqkv[l];
+	a.q = c->q;
+	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
+	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+	a.xb_dump = p->norm_par ? c->xb : nullptr;
+	a.ts = c->ts;
+	a.rope_cs = c->rope_cs;
+	a.dim = c->dim, a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len;
+	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
+	int ntasks = (c->q_dim + 2 * c->kv_dim) / Shape<DB>::NR;
+	hipLaunchKernelGGL((k_qkv<DB, KVB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+}
+
+template <int KVB, int LPR>
+void launch_attn_lpr(Ctx* c, int l, int n_split) {
+	AttnArgs a;
+	a.q = c->q;
+	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
+	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+	a.out = c->att;
+	a.partial = c->partial;
+	a.ts = c->ts;
+	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
+	hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads * n_split), dim3(256), 0, g_stream, a);
+	if (n_split > 1) {
+		hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	}
+}
+
+template <int KVB>
+void launch_attn(Ctx* c, int l, int n_split) {
+	switch (c->lpr) {
+	case 4:
+		return launch_attn_lpr<KVB, 4>(c, l, n_split);
+	case 8:
+		return launch_attn_lpr<KVB, 8>(c, l, n_split);
+	case 16:
+		return launch_attn_lpr<KVB, 16>(c, l, n_split);
+	case 32:
+		return launch_attn_lpr<KVB, 32>(c, l, n_split);
+	case 64:
+		return launch_attn_lpr<KVB, 64>(c, l, n_split);
+	default:
+		CALM_REQUIRE(false, "unsupported head_dim");
+	}
+}
+
+template <int DB>
+void launch_attn_out(Ctx* c, int l) {
+	int ntasks = c->dim / Shape<DB>::NR;
+	hipLaunchKernelGGL((k_attn_out<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->q_dim), g_stream, c->x, c->att, c->t->weights.wo[l], c->dim,
+	                   c->q_dim);
+}
+
+template <int DB>
+void launch_ffn_up(Ctx* c, int l) {
+	struct Config* p = &c->t->config;
+	struct Weights* w = &c->t->weights;
+	FfnUpArgs a;
+	a.x = p->norm_par ? c->xb : c->x;
+	a.norm_w = p->norm_par ? nullptr : w->rms_ffn_weight[l];
+	a.w1 = w->w1[l], a.w3 = w->w3[l], a.moegate = w->moegate[l];
+	a.he = c->he, a.moe_w = c->moe_w, a.moe_e = c->moe_e;
+	a.dim = c->dim, a.hidden = c->hidden, a.n_experts = c->n_experts, a.n_active = c->n_active;
+	a.eps = p->norm_eps, a.ln = p->norm_ln, a.gelu = p->act_gelu;
+	int nact = c->n_active > 0 ? c->n_active : 1;
+	int ntasks = nact * (c->hidden / (Shape<DB>::NR / 2));
+	hipLaunchKernelGGL((k_ffn_up<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+}
+
+template <int DB>
+void launch_ffn_down(Ctx* c, int l) {
+	constexpr int BLOCK = 512;
+	int ntasks = c->dim / Shape<DB>::NR;
+	hipLaunchKernelGGL((k_ffn_down<DB, BLOCK>), dim3(pick_blocks(ntasks, BLOCK / 64)), dim3(BLOCK), lds_bytes<DB>(c->hidden), g_stream, c->x, c->he,
+	                   c->t->weights.w2[l], c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+}
+
+template <int DB>
+void launch_output(Ctx* c) {
+	struct Config* p = &c->t->config;
+	int ntasks = (c->vocab + Shape<DB>::NR - 1) / Shape<DB>::NR;
+	hipLaunchKernelGGL((k_output<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
+	                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
+}
+
+void launch_argmax(Ctx* c) {
+	hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, g_stream, c->logits_d, c->vocab, c->next_tok, c->trace, c->trace_count);
+}
+
+// algorithmic bytes per launch, the reference's accounting (src/infer.cu:685-699)
+uint64_t stage_bytes(Ctx* c, int stage, int kv_len) {
+	uint64_t db = c->dbits;
+	uint64_t kvbw = (uint64_t)c->kv_dim * kv_len * (c->kvbits / 8);
+	int nact = c->n_active > 0 ? c->n_active : 1;
+	switch (stage) {
+	case CALM_STAGE_QKV:
+		return (uint64_t)(c->q_dim + 2 * c->kv_dim) * c->dim * db / 8;
+	case CALM_STAGE_ATTN:
+		return 2 * kvbw;
+	case CALM_STAGE_ATTN_OUT:
+		return (uint64_t)c->q_dim * c->dim * db / 8;
+	case CALM_STAGE_FFN_UP:
+		return 2 * ((uint64_t)c->hidden * c->dim * db / 8) * nact;
+	case CALM_STAGE_FFN_DOWN:
+		return ((uint64_t)c->hidden * c->dim * db / 8) * nact;
+	case CALM_STAGE_OUTPUT:
+		return (uint64_t)c->vocab * c->dim * db / 8;
+	}
+	return 0;
+}
+
+// ---------------------------------------------------------------- one decode step ---------------
+
+struct StepPlan {
+	int n_split;
+	bool kv_only, sink, chained, argmax, copy_logits;
+};
+
+template <int DB, int KVB>
+void enqueue_step(Ctx* c, const StepPlan& sp, bool timed) {
+	size_t ev = 0;
+	auto mark = [&]() {
+		if (timed) {
+			if (ev >= c->events.size()) {
+				hipEvent_t e;
+				HIP_CHECK(hipEventCreate(&e));
+				c->events.push_back(e);
+			}
+			HIP_CHECK(hipEventRecord(c->events[ev++], g_stream));
+		}
+	};
+	launch_begin<DB>(c);
+	if (sp.sink) {
+		launch_rotate_sink<KVB>(c);
+	}
+	for (int l = 0; l < c->n_layers; ++l) {
+		mark();
+		launch_qkv<DB, KVB>(c, l);
+		mark();
+		launch_attn<KVB>(c, l, sp.n_split);
+		mark();
+		launch_attn_out<DB>(c, l);
+		mark();
+		launch_ffn_up<DB>(c, l);
+		mark();
+		launch_ffn_down<DB>(c, l);
+	}
+	mark();
+	if (!sp.kv_only) {
+		launch_output<DB>(c);
+		mark();
+		if (sp.argmax) {
+			launch_argmax(c);
+		}
+		if (sp.copy_logits) {
+			HIP_CHECK(hipMemcpyAsync(c->logits_h, c->logits_d, (size_t)c->vocab * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+		}
+	}
+	HIP_CHECK(hipGetLastError());
+}
+
+void dispatch_step(Ctx* c, const StepPlan& sp, bool timed) {
+#define CASE(db, kvb)                       \
+	if (c->dbits == db && c->kvbits == kvb) \
+	return enqueue_step<db, kvb>(c, sp, timed)
+	CASE(16, 16);
+	CASE(8, 16);
+	CASE(4, 16);
+	CASE(16, 8);
+	CASE(8, 8);
+	CASE(4, 8);
+#undef CASE
+	CALM_REQUIRE(false, "unsupported dbits/kvbits combination: dbits must be 4, 8 or 16, kvbits must be 8 or 16");
+}
+
+void* begin_func(Ctx* c) {
+	switch (c->dbits) {
+	case 16:
+		return (void*)k_begin_token<16>;
+	case 8:
+		return (void*)k_begin_token<8>;
+	default:
+		return (void*)k_begin_token<4>;
+	}
+}
+
+void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp) {
+	struct Config* p = &c->t->config;
+	// rolling KV buffer with attention sinks (src/infer.c:329-332)
+	int kv_sink = pos >= p->seq_len ? CALM_KV_SINKS : 0;
+	int kv_pos = kv_sink + (pos - kv_sink) % (p->seq_len - kv_sink);
+	int kv_len = pos >= p->seq_len ? p->seq_len : pos + 1;
+	CALM_REQUIRE(tok_src || (token >= 0 && token < c->vocab), "token out of range");
+	CALM_REQUIRE(pos >= 0, "negative position");
+
+	sp.sink = kv_sink > 0;
+	sp.n_split = kv_len <= g_split_t ? 1 : (kv_len + g_split_t - 1) / g_split_t;
+	if (sp.n_split > MAX_SPLIT) {
+		sp.n_split = MAX_SPLIT;
+	}
+	sp.chained = tok_src != nullptr;
+
+	c->ba.token = token;
+	c->ba.tok_src = tok_src;
+	c->ba.pos = pos;
+	c->ba.kv_sink = kv_sink;
+	c->ba.kv_pos = kv_pos;
+	c->ba.kv_len = kv_len;
+
+	if (g_prof) {
+		dispatch_step(c, sp, true);
+		HIP_CHECK(hipStreamSynchronize(g_stream));
+		// events: per layer [qkv, attn, attn_out, ffn_up, ffn_down], then [end-of-layers, after output]
+		size_t ev = 0;
+		auto span = [&](int stage) {
+			float ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&ms, c->events[ev], c->events[ev + 1]));
+			ev++;
+			c->prof[stage].us += ms * 1e3;
+			c->prof[stage].bytes += stage_bytes(c, stage, kv_len);
+			c->prof[stage].runs++;
+		};
+		for (int l = 0; l < c->n_layers; ++l) {
+			span(CALM_STAGE_QKV), span(CALM_STAGE_ATTN), span(CALM_STAGE_ATTN_OUT), span(CALM_STAGE_FFN_UP), span(CALM_STAGE_FFN_DOWN);
+		}
+		if (!sp.kv_only) {
+			span(CALM_STAGE_OUTPUT);
+		}
+		g_prof_ctx = c;
+		return;
+	}
+	if (!g_use_graph) {
+		dispatch_step(c, sp, false);
+		return;
+	}
+
+	auto key = std::make_tuple(sp.n_split, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.argmax * 2 + (int)sp.copy_logits);
+	GraphEntry& ge = c->graphs[key];
+	if (!ge.exec) {
+		HIP_CHECK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+		dispatch_step(c, sp, false);
+		HIP_CHECK(hipStreamEndCapture(g_stream, &ge.graph));
+		HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+		// the begin-token kernel is the only root of the (linear) graph
+		size_t nroots = 0;
+		HIP_CHECK(hipGraphGetRootNodes(ge.graph, nullptr, &nroots));
+		CALM_REQUIRE(nroots == 1, "captured decode graph must have exactly one root");
+		HIP_CHECK(hipGraphGetRootNodes(ge.graph, &ge.begin_node, &nroots));
+		hipGraphNodeType ty;
+		HIP_CHECK(hipGraphNodeGetType(ge.begin_node, &ty));
+		CALM_REQUIRE(ty == hipGraphNodeTypeKernel, "root of the decode graph must be the begin-token kernel");
+	}
+	hipKernelNodeParams kp;
+	memset(&kp, 0, sizeof(kp));
+	int n = c->dim > c->head_dim / 2 ? c->dim : c->head_dim / 2;
+	kp.func = begin_func(c);
+	kp.gridDim = dim3((n + 255) / 256);
+	kp.blockDim = dim3(256);
+	kp.sharedMemBytes = 0;
+	kp.kernelParams = c->ba_ptrs;
+	kp.extra = nullptr;
+	HIP_CHECK(hipGraphExecKernelNodeSetParams(ge.exec, ge.begin_node, &kp));
+	HIP_CHECK(hipGraphLaunch(ge.exec, g_stream));
+}
+
+template <int DB>
+void set_lds_attrs(Ctx* c) {
+	allow_lds(k_qkv<DB, 16>, lds_bytes<DB>(c->dim));
+	allow_lds(k_qkv<DB, 8>, lds_bytes<DB>(c->dim));
+	allow_lds(k_attn_out<DB>, lds_bytes<DB>(c->q_dim));
+	allow_lds(k_ffn_up<DB>, lds_bytes<DB>(c->dim));
+	allow_lds(k_ffn_down<DB, 512>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_output<DB>, lds_bytes<DB>(c->dim));
+}
+
+} // namespace
+
+// ================================================================ C ABI =======================
+
+extern "C" int calm_hip_device_count(void) {
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		return 0;
+	}
+	return n;
+}
+
+extern "C" const char* calm_hip_device_name(void) {
+	return g_devname;
+}
+
+extern "C" int calm_hip_configure(const char* key, int value) {
+	init_hip();
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	int* slot = nullptr;
+	if (!strcmp(key, "graph")) {
+		slot = &g_use_graph;
+	} else if (!strcmp(key, "prof")) {
+		slot = &g_prof;
+	} else if (!strcmp(key, "bpc")) {
+		slot = &g_bpc;
+	} else if (!strcmp(key, "split_t")) {
+		slot = &g_split_t;
+	} else {
+		return -1;
+	}
+	int old = *slot;
+	if (value >= 0) {
+		*slot = value;
+	}
+	return old;
+}
+
+extern "C" void init_hip(void) {
+	if (g_device >= 0) {
+		return;
+	}
+	int n = calm_hip_device_count();
+	if (n <= 0) {
+		fprintf(stderr, "calm_hip: no HIP device visible -- this backend has no CPU fallback\n");
+		abort();
+	}
+	const char* dv = getenv("CALM_HIP_DEVICE");
+	if (!dv) {
+		dv = getenv("LOCAL_RANK");
+	}
+	int dev = dv ? atoi(dv) % n : 0;
+	HIP_CHECK(hipSetDevice(dev));
+	hipDeviceProp_t prop;
+	HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+	g_ncu = prop.multiProcessorCount;
+	snprintf(g_devname, sizeof(g_devname), "%s", prop.name);
+	HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+	g_device = dev;
+	g_bpc = env_int("CALM_HIP_BPC", g_bpc);
+	g_use_graph = env_int("CALM_HIP_GRAPH", 1);
+	g_prof = env_int("CALM_HIP_PROF", 0);
+	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
+	if (env_int("CALM_HIP_VERBOSE", 0)) {
+		printf("# HIP: %s (%s), %d CUs, %.1f GiB, device %d\n", prop.name, prop.gcnArchName, g_ncu, (double)prop.totalGlobalMem / (1024.0 * 1024 * 1024), dev);
+	}
+}
+
+extern "C" void* upload_hip(void* host, size_t size) {
+	init_hip();
+	void* device = dev_alloc(size);
+	HIP_CHECK(hipMemcpy(device, host, size, hipMemcpyHostToDevice));
+	return device;
+}
+
+extern "C" void free_hip(void* device) {
+	if (device) {
+		HIP_CHECK(hipFree(device));
+	}
+}
+
+extern "C" void download_hip(void* host, const void* device, size_t size) {
+	init_hip();
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	HIP_CHECK(hipMemcpy(host, device, size, hipMemcpyDeviceToHost));
+}
+
+extern "C" void prepare_hip(struct Transformer* t) {
+	init_hip();
+	struct Config* p = &t->config;
+	struct Weights* w = &t->weights;
+	struct RunState* s = &t->state;
+
+	Ctx* c = new Ctx();
+	c->t = t;
+	c->dim = p->dim, c->hidden = p->hidden_dim, c->head_dim = p->head_dim, c->n_layers = p->n_layers;
+	c->n_heads = p->n_heads, c->n_kv_heads = p->n_kv_heads, c->vocab = p->vocab_size, c->seq_len = p->seq_len;
+	c->q_dim = p->head_dim * p->n_heads, c->kv_dim = p->head_dim * p->n_kv_heads, c->kv_mul = p->n_heads / p->n_kv_heads;
+	c->n_experts = p->n_experts, c->n_active = p->n_experts_ac, c->dbits = w->dbits, c->kvbits = s->kvbits;
+
+	CALM_REQUIRE(c->dbits == 4 || c->dbits == 8 || c->dbits == 16, "dbits must be 4, 8 or 16");
+	CALM_REQUIRE(c->kvbits == 8 || c->kvbits == 16, "kvbits must be 8 or 16 and set before prepare_hip");
+	int G = 128 / c->dbits;
+	// every weight row must be a whole number of 16-byte lane-loads (the reference's CPU path asserts
+	// n % 16 / n % 32, src/infer.c:47,75,103; its CUDA path dims % 32, src/infer.cu:670)
+	CALM_REQUIRE(c->dim % G == 0 && c->hidden % G == 0 && c->q_dim % G == 0, "dim, hidden_dim and n_heads*head_dim must be multiples of 128/dbits");
+	CALM_REQUIRE(c->dim % 4 == 0 && c->hidden % 4 == 0 && c->q_dim % 4 == 0 && c->kv_dim % 4 == 0, "dims must be multiples of 4");
+	CALM_REQUIRE(c->head_dim % 8 == 0 && c->head_dim <= 512, "head_dim must be a multiple of 8, at most 512");
+	CALM_REQUIRE(p->n_layers <= CALM_MAX_LAYERS && p->n_experts <= CALM_MAX_EXPERTS, "too many layers / experts");
+	CALM_REQUIRE(p->n_heads % p->n_kv_heads == 0, "n_heads must be a multiple of n_kv_heads");
+	CALM_REQUIRE(p->seq_len > CALM_KV_SINKS, "seq_len too small");
+	CALM_REQUIRE(!p->n_experts || (p->n_experts_ac > 0 && p->n_experts_ac <= p->n_experts), "bad MoE configuration");
+	c->lpr = 4;
+	while (c->lpr * 8 < c->head_dim) {
+		c->lpr *= 2;
+	}
+
+	int nact = c->n_active > 0 ? c->n_active : 1;
+	c->x = (float*)dev_alloc(c->dim * sizeof(float));
+	c->xb = (float*)dev_alloc(c->dim * sizeof(float));
+	c->q = (float*)dev_alloc(c->q_dim * sizeof(float));
+	c->att = (float*)dev_alloc(c->q_dim * sizeof(float));
+	c->he = (float*)dev_alloc((size_t)nact * c->hidden * sizeof(float));
+	c->partial = (float*)dev_alloc((size_t)c->n_heads * MAX_SPLIT * (c->head_dim + 2) * sizeof(float));
+	c->logits_d = (float*)dev_alloc((size_t)c->vocab * sizeof(float));
+	c->moe_w = (float*)dev_alloc(CALM_MAX_EXPERTS * sizeof(float));
+	c->moe_e = (int*)dev_alloc(CALM_MAX_EXPERTS * sizeof(int));
+	c->next_tok = (int*)dev_alloc(sizeof(int));
+	c->trace_count = (int*)dev_alloc(sizeof(int));
+	c->trace_cap = 1 << 16;
+	c->trace = (int*)dev_alloc((size_t)c->trace_cap * sizeof(int));
+	c->ts = (TokState*)dev_alloc(sizeof(TokState));
+	HIP_CHECK(hipMemset(c->ts, 0, sizeof(TokState)));
+	HIP_CHECK(hipMemset(c->trace_count, 0, sizeof(int)));
+	HIP_CHECK(hipMemset(c->xb, 0, c->dim * sizeof(float)));
+
+	// KV cache, private layout [layer][kv_head][seq_len][head_dim]; zero like calloc (src/infer.c:162-163)
+	c->kv_layer_bytes = (size_t)c->kv_dim * c->seq_len * (c->kvbits / 8);
+	c->kc = dev_alloc(c->kv_layer_bytes * c->n_layers);
+	c->vc = dev_alloc(c->kv_layer_bytes * c->n_layers);
+	HIP_CHECK(hipMemset(c->kc, 0, c->kv_layer_bytes * c->n_layers));
+	HIP_CHECK(hipMemset(c->vc, 0, c->kv_layer_bytes * c->n_layers));
+
+	// RoPE frequencies with the host libm -- the very expression of src/infer.c:226 -- so that
+	// pos * freq is bit-identical to the CPU path's; cos/sin of one position step for the sink keys
+	int half_hd = c->head_dim / 2;
+	std::vector<float> freq(half_hd);
+	std::vector<float2> cs1(half_hd);
+	for (int i = 0; i < half_hd; ++i) {
+		int j_head = 2 * i;
+		freq[i] = j_head >= p->rotary_dim ? 0.f : 1.0f / powf(p->rope_theta, (float)j_head / (float)p->rotary_dim);
+		float val = 1 * freq[i];
+		cs1[i] = make_float2(cosf(val), sinf(val));
+	}
+	c->rope_freq = (float*)dev_alloc(half_hd * sizeof(float));
+	c->rope_cs = (float2*)dev_alloc(half_hd * sizeof(float2));
+	c->rope_cs1 = (float2*)dev_alloc(half_hd * sizeof(float2));
+	HIP_CHECK(hipMemcpy(c->rope_freq, freq.data(), half_hd * sizeof(float), hipMemcpyHostToDevice));
+	HIP_CHECK(hipMemcpy(c->rope_cs1, cs1.data(), half_hd * sizeof(float2), hipMemcpyHostToDevice));
+
+	// logits land in pinned host memory: the host sampler reads and overwrites them (src/sampler.c:55)
+	HIP_CHECK(hipHostMalloc((void**)&c->logits_h, (size_t)c->vocab * sizeof(float), hipHostMallocDefault));
+	memset(c->logits_h, 0, (size_t)c->vocab * sizeof(float));
+
+	switch (c->dbits) {
+	case 16:
+		set_lds_attrs<16>(c);
+		break;
+	case 8:
+		set_lds_attrs<8>(c);
+		break;
+	default:
+		set_lds_attrs<4>(c);
+	}
+
+	c->ba.ts = c->ts;
+	c->ba.x = c->x;
+	c->ba.embed = w->token_embedding_table;
+	c->ba.dim = c->dim;
+	c->ba.rope_freq = c->rope_freq;
+	c->ba.rope_cs = c->rope_cs;
+	c->ba.half_hd = half_hd;
+	void* ptrs[13] = {&c->ba.ts,  &c->ba.token, &c->ba.tok_src, &c->ba.pos,       &c->ba.kv_sink, &c->ba.kv_pos, &c->ba.kv_len,
+	                  &c->ba.x,   &c->ba.embed, &c->ba.dim,     &c->ba.rope_freq, &c->ba.rope_cs, &c->ba.half_hd};
+	memcpy(c->ba_ptrs, ptrs, sizeof(ptrs));
+
+	// what the host program may look at (src/infer.cu:101-112)
+	s->x = c->x;
+	s->xb = c->xb;
+	s->hb = c->he;
+	s->he = c->he;
+	s->q = c->q;
+	s->att = c->att;
+	s->key_cache = c->kc;
+	s->value_cache = c->vc;
+	s->logits = c->logits_h;
+
+	HIP_CHECK(hipDeviceSynchronize()); // uploads done; the host may unmap its copies
+	g_ctx[t] = c;
+}
+
+extern "C" void release_hip(struct Transformer* t) {
+	auto it = g_ctx.find(t);
+	if (it == g_ctx.end()) {
+		return;
+	}
+	Ctx* c = it->second;
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	for (auto& kv : c->graphs) {
+		if (kv.second.exec) {
+			HIP_CHECK(hipGraphExecDestroy(kv.second.exec));
+		}
+		if (kv.second.graph) {
+			HIP_CHECK(hipGraphDestroy(kv.second.graph));
+		}
+	}
+	for (hipEvent_t e : c->events) {
+		HIP_CHECK(hipEventDestroy(e));
+	}
+	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->logits_d, c->moe_w,  c->moe_e,
+	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc};
+	for (void* b : bufs) {
+		HIP_CHECK(hipFree(b));
+	}
+	HIP_CHECK(hipHostFree(c->logits_h));
+	if (g_prof_ctx == c) {
+		g_prof_ctx = nullptr;
+	}
+	memset(&t->state, 0, offsetof(struct RunState, kvbits));
+	t->state.key_cache = t->state.value_cache = nullptr;
+	delete c;
+	g_ctx.erase(it);
+}
+
+extern "C" float* forward_hip(struct Transformer* t, int token, int pos, unsigned flags) {
+	Ctx* c = ctx_of(t);
+	StepPlan sp = {};
+	sp.kv_only = (flags & FF_UPDATE_KV_ONLY) != 0;
+	sp.argmax = false;
+	sp.copy_logits = !sp.kv_only;
+	run_step(c, token, nullptr, pos, sp);
+	if (sp.kv_only) {
+		return NULL; // enqueued, not synchronised (src/infer.cu:724-727)
+	}
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	return c->logits_h;
+}
+
+extern "C" float* decode_greedy_hip(struct Transformer* t, int token, int pos, int n_steps, int* out_tokens) {
+	Ctx* c = ctx_of(t);
+	CALM_REQUIRE(n_steps > 0 && n_steps <= c->trace_cap, "n_steps out of range");
+	HIP_CHECK(hipMemsetAsync(c->trace_count, 0, sizeof(int), g_stream));
+	for (int i = 0; i < n_steps; ++i) {
+		StepPlan sp = {};
+		sp.argmax = true;
+		sp.copy_logits = (i == n_steps - 1);
+		run_step(c, i == 0 ? token : 0, i == 0 ? nullptr : c->next_tok, pos + i, sp);
+	}
+	HIP_CHECK(hipMemcpyAsync(out_tokens, c->trace, (size_t)n_steps * sizeof(int), hipMemcpyDeviceToHost, g_stream));
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	return c->logits_h;
+}
+
+extern "C" void perf_hip(void) {
+	Ctx* c = g_prof_ctx;
+	if (!c) {
+		return;
+	}
+	static const char* names[CALM_STAGE_COUNT] = {"matmul_qkv", "attn", "matmul_attn", "matmul_ffn_up", "matmul_ffn_down", "output"};
+	double total = 0;
+	uint64_t runs = 0;
+	for (int s = 0; s < CALM_STAGE_COUNT; ++s) {
+		total += c->prof[s].us;
+	}
+	runs = c->prof[CALM_STAGE_QKV].runs / (c->n_layers ? c->n_layers : 1);
+	if (!runs) {
+		return;
+	}
+	printf("\nforward_hip breakdown (over %llu runs, avg %.1f usec/run, event-timed eager launches):\n", (unsigned long long)runs, total / runs);
+	for (int s = 0; s < CALM_STAGE_COUNT; ++s) {
+		if (!c->prof[s].runs) {
+			continue;
+		}
+		printf("\t[%d] %16s: %4.1f%%; %8.1f usec/run, %7.1f GB/s\n", s, names[s], c->prof[s].us / total * 100, c->prof[s].us / runs,
+		       (double)c->prof[s].bytes / 1e9 / (c->prof[s].us / 1e6));
+	}
+}
+
+extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, uint64_t* bytes_per_launch) {
+	Ctx* c = ctx_of(t);
+	CALM_REQUIRE(stage >= 0 && stage < CALM_STAGE_COUNT && iters > 0, "bad stage / iters");
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	TokState ts;
+	HIP_CHECK(hipMemcpy(&ts, c->ts, sizeof(ts), hipMemcpyDeviceToHost));
+	int kv_len = ts.kv_len > 0 ? ts.kv_len : 1;
+	if (bytes_per_launch) {
+		*bytes_per_launch = stage_bytes(c, stage, kv_len);
+	}
+	int n_split = kv_len <= g_split_t ? 1 : (kv_len + g_split_t - 1) / g_split_t;
+	auto one = [&](int l) {
+#define ST(db, kvb)                                  \
+	if (c->dbits == db && c->kvbits == kvb) {        \
+		switch (stage) {                             \
+		case CALM_STAGE_QKV:                         \
+			launch_qkv<db, kvb>(c, l);               \
+			break;                                   \
+		case CALM_STAGE_ATTN:                        \
+			launch_attn<kvb>(c, l, n_split);         \
+			break;                                   \
+		case CALM_STAGE_ATTN_OUT:                    \
+			launch_attn_out<db>(c, l);               \
+			break;                                   \
+		case CALM_STAGE_FFN_UP:                      \
+			launch_ffn_up<db>(c, l);                 \
+			break;                                   \
+		case CALM_STAGE_FFN_DOWN:                    \
+			launch_ffn_down<db>(c, l);               \
+			break;                                   \
+		case CALM_STAGE_OUTPUT:                      \
+			launch_output<db>(c);                    \
+			break;                                   \
+		}                                            \
+	}
+		ST(16, 16) ST(8, 16) ST(4, 16) ST(16, 8) ST(8, 8) ST(4, 8)
+#undef ST
+	};
+	hipEvent_t e0, e1;
+	HIP_CHECK(hipEventCreate(&e0));
+	HIP_CHECK(hipEventCreate(&e1));
+	for (int l = 0; l < c->n_layers; ++l) { // warm-up sweep
+		one(l);
+	}
+	HIP_CHECK(hipEventRecord(e0, g_stream));
+	for (int it = 0; it < iters; ++it) {
+		for (int l = 0; l < c->n_layers; ++l) {
+			one(l);
+		}
+	}
+	HIP_CHECK(hipEventRecord(e1, g_stream));
+	HIP_CHECK(hipEventSynchronize(e1));
+	HIP_CHECK(hipGetLastError());
+	float ms = 0;
+	HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	HIP_CHECK(hipEventDestroy(e0));
+	HIP_CHECK(hipEventDestroy(e1));
+	return (double)ms * 1e3 / ((double)iters * c->n_layers);
+}
+
+// ================================================================ test hooks ==================
+
+namespace {
+
+template <class F>
+void by_dbits(int dbits, F f) {
+	switch (dbits) {
+	case 16:
+		f(std::integral_constant<int, 16>());
+		break;
+	case 8:
+		f(std::integral_constant<int, 8>());
+		break;
+	case 4:
+		f(std::integral_constant<int, 4>());
+		break;
+	default:
+		CALM_REQUIRE(false, "dbits must be 4, 8 or 16");
+	}
+}
+
+} // namespace
+
+extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, float* out, int n, int d) {
+	init_hip();
+	CALM_REQUIRE(n % (128 / dbits) == 0 && d % 4 == 0, "n must be a multiple of 128/dbits and d of 4");
+	size_t wbytes = (size_t)n * d * dbits / 8;
+	void* dw = upload_hip((void*)w, wbytes);
+	float* dx = (float*)upload_hip((void*)x, n * sizeof(float));
+	float* dout = (float*)dev_alloc(d * sizeof(float));
+	HIP_CHECK(hipMemset(dout, 0, d * sizeof(float)));
+	by_dbits(dbits, [&](auto DBT) {
+		constexpr int DB = decltype(DBT)::value;
+		allow_lds(k_attn_out<DB>, lds_bytes<DB>(n));
+		hipLaunchKernelGGL((k_attn_out<DB>), dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+	});
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, dout, d * sizeof(float));
+	free_hip(dw), free_hip(dx), free_hip(dout);
+}
+
+extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float* x, const float* nw, float* out, int n, int d, float eps, int ln) {
+	init_hip();
+	CALM_REQUIRE(n % (128 / dbits) == 0, "n must be a multiple of 128/dbits");
+	size_t wbytes = (size_t)n * d * dbits / 8;
+	void* dw = upload_hip((void*)w, wbytes);
+	float* dx = (float*)upload_hip((void*)x, n * sizeof(float));
+	float* dnw = (float*)upload_hip((void*)nw, n * sizeof(float));
+	float* dout = (float*)dev_alloc(d * sizeof(float));
+	by_dbits(dbits, [&](auto DBT) {
+		constexpr int DB = decltype(DBT)::value;
+		allow_lds(k_output<DB>, lds_bytes<DB>(n));
+		int ntasks = (d + Shape<DB>::NR - 1) / Shape<DB>::NR;
+		hipLaunchKernelGGL((k_output<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+	});
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, dout, d * sizeof(float));
+	free_hip(dw), free_hip(dx), free_hip(dnw), free_hip(dout);
+}
+
+extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const uint16_t* vcache, float* out, int n_heads, int n_kv_heads, int head_dim,
+                                   int seq_len, int kv_len, int n_split) {
+	init_hip();
+	CALM_REQUIRE(head_dim % 8 == 0 && n_heads % n_kv_heads == 0 && n_split >= 1 && n_split <= MAX_SPLIT, "bad attention test shape");
+	int kv_dim = n_kv_heads * head_dim, q_dim = n_heads * head_dim;
+	// oracle layout [seq_len][kv_dim] -> backend layout [kv_head][seq_len][head_dim]
+	std::vector<uint16_t> kk((size_t)seq_len * kv_dim), vv((size_t)seq_len * kv_dim);
+	for (int t = 0; t < seq_len; ++t) {
+		for (int h = 0; h < n_kv_heads; ++h) {
+			for (int d = 0; d < head_dim; ++d) {
+				kk[((size_t)h * seq_len + t) * head_dim + d] = kcache[(size_t)t * kv_dim + h * head_dim + d];
+				vv[((size_t)h * seq_len + t) * head_dim + d] = vcache[(size_t)t * kv_dim + h * head_dim + d];
+			}
+		}
+	}
+	Ctx c;
+	c.head_dim = head_dim, c.n_heads = n_heads, c.n_kv_heads = n_kv_heads, c.kv_mul = n_heads / n_kv_heads, c.seq_len = seq_len;
+	c.kv_layer_bytes = kk.size() * 2;
+	c.kc = upload_hip(kk.data(), kk.size() * 2);
+	c.vc = upload_hip(vv.data(), vv.size() * 2);
+	c.q = (float*)upload_hip((void*)q, q_dim * sizeof(float));
+	c.att = (float*)dev_alloc(q_dim * sizeof(float));
+	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 2) * sizeof(float));
+	TokState ts = {};
+	ts.kv_len = kv_len;
+	c.ts = (TokState*)upload_hip(&ts, sizeof(ts));
+	c.lpr = 4;
+	while (c.lpr * 8 < head_dim) {
+		c.lpr *= 2;
+	}
+	launch_attn<16>(&c, 0, n_split);
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, c.att, q_dim * sizeof(float));
+	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts);
+}
+
+extern "C" int calm_hip_test_argmax(const float* logits, int n) {
+	init_hip();
+	float* dl = (float*)upload_hip((void*)logits, n * sizeof(float));
+	int* dn = (int*)dev_alloc(2 * sizeof(int));
+	HIP_CHECK(hipMemset(dn, 0, 2 * sizeof(int)));
+	hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, g_stream, dl, n, dn, (int*)nullptr, dn + 1);
+	HIP_CHECK(hipGetLastError());
+	int r = -2;
+	download_hip(&r, dn, sizeof(int));
+	free_hip(dl), free_hip(dn);
+	return r;
+}
+
+extern "C" void calm_hip_read_kv(struct Transformer* t, int layer, int which, uint16_t* host) {
+	Ctx* c = ctx_of(t);
+	CALM_REQUIRE(c->kvbits == 16 && layer >= 0 && layer < c->n_layers, "calm_hip_read_kv: fp16 cache only");
+	std::vector<uint16_t> tmp(c->kv_layer_bytes / 2);
+	download_hip(tmp.data(), (char*)(which ? c->vc : c->kc) + (size_t)layer * c->kv_layer_bytes, c->kv_layer_bytes);
+	for (int h = 0; h < c->n_kv_heads; ++h) {
+		for (int p = 0; p < c->seq_len; ++p) {
+			memcpy(host + (size_t)p * c->kv_dim + h * c->head_dim, tmp.data() + ((size_t)h * c->seq_len + p) * c->head_dim, c->head_dim * 2);
+		}
+	}
+}
+
+namespace {
+template <bool NT>
+__global__ __launch_bounds__(256) void k_membench(const u32x4* src, size_t n16, unsigned* sink) {
+	unsigned acc = 0;
+	size_t stride = (size_t)gridDim.x * 256 * 8;
+	for (size_t i = (size_t)blockIdx.x * 256 * 8 + threadIdx.x; i < n16; i += stride) {
+		u32x4 v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			size_t j = i + (size_t)u * 256;
+			if (j < n16) {
+				v[u] = NT ? __builtin_nontemporal_load(src + j) : src[j];
+			} else {
+				v[u] = (u32x4){0u, 0u, 0u, 0u};
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			acc += v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+		}
+	}
+	if (acc == 0x9e3779b9u) {
+		*sink = acc; // never true in practice; keeps the loads alive
+	}
+}
+} // namespace
+
+extern "C" double calm_hip_membench(size_t bytes, int nt, int iters) {
+	init_hip();
+	size_t n16 = bytes / 16;
+	u32x4* buf = (u32x4*)dev_alloc(n16 * 16);
+	unsigned* sink = (unsigned*)dev_alloc(4);
+	HIP_CHECK(hipMemset(buf, 0x5a, n16 * 16));
+	int blocks = g_ncu * 8;
+	auto go = [&]() {
+		if (nt) {
+			hipLaunchKernelGGL(k_membench<true>, dim3(blocks), dim3(256), 0, g_stream, buf, n16, sink);
+		} else {
+			hipLaunchKernelGGL(k_membench<false>, dim3(blocks), dim3(256), 0, g_stream, buf, n16, sink);
+		}
+	};
+	go();
+	hipEvent_t e0, e1;
+	HIP_CHECK(hipEventCreate(&e0));
+	HIP_CHECK(hipEventCreate(&e1));
+	HIP_CHECK(hipEventRecord(e0, g_stream));
+	for (int i = 0; i < iters; ++i) {
+		go();
+	}
+	HIP_CHECK(hipEventRecord(e1, g_stream));
+	HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	HIP_CHECK(hipEventDestroy(e0));
+	HIP_CHECK(hipEventDestroy(e1));
+	free_hip(buf), free_hip(sink);
+	return (double)n16 * 16 * iters / 1e9 / ((double)ms / 1e3);
+}

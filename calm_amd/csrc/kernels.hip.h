@@ -1,0 +1,1022 @@
+// kernels.hip.h -- gfx950 (MI355X, wave64) device code of the calm decode step.
+//
+// One decode step = a chain of bandwidth-bound dequant-matvecs over every active weight byte
+// (2 FLOP per weight byte at fp8: HBM-bound, no MFMA) plus a handful of tiny vector ops.  The
+// functional spec is the reference CPU path src/infer.c:311-472; citations below are into the
+// reference tree.  Shape of the solution:
+//
+//   * one WAVE (64 lanes) per output row (or row group), 16 bytes per lane per load
+//     (global_load_dwordx4, 1 KiB per wave-instruction, non-temporal: weights are read once);
+//   * the activation vector lives in LDS as fp32 in a lane-interleaved ("swizzled") layout so
+//     that every ds_read_b128 of a wave touches 64 consecutive 16-byte slots (conflict-free);
+//   * each workgroup issues its first weight loads BEFORE it builds the activation vector
+//     (norm prologue), so HBM is streaming while the prologue runs;
+//   * fp32 accumulation, wave-shuffle reduction, fused epilogues (bias/clip/RoPE/KV-append,
+//     residual add, gated activation, MoE weighting);
+//   * per-token scalars (token, pos, kv slot) live in a device-resident TokState so the whole
+//     step can be replayed from a hipGraph.
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace calm {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// per-token scalars, written by k_begin_token, read by every other kernel
+struct TokState {
+	int token;
+	int pos;
+	int kv_sink; // 0, or CALM_KV_SINKS once pos >= seq_len   (src/infer.c:330)
+	int kv_pos;  // cache slot the new K/V row goes to          (src/infer.c:331)
+	int kv_len;  // number of valid cache rows                   (src/infer.c:332)
+	int pad[3];
+};
+
+// weights per 16-byte lane-load and float4s of activation it pairs with
+template <int DB>
+struct Fmt {
+	static constexpr int G = 128 / DB; // fp16: 8, fp8: 16, gf4: 32
+	static constexpr int F4 = G / 4;
+};
+
+__device__ __forceinline__ int lane_id() {
+	return threadIdx.x & 63;
+}
+__device__ __forceinline__ int wave_id() {
+	// wave-uniform by construction; tell the compiler so it lands in an SGPR
+	return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		v += __shfl_xor(v, o);
+	}
+	return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		v = fmaxf(v, __shfl_xor(v, o));
+	}
+	return v;
+}
+
+// ---------------------------------------------------------------- weight decode ---------------
+
+// fp8 e5m2 == OCP bf8 on gfx950; exact.  (reference src/infer.c:28-35: bits << 8 as binary16)
+__device__ __forceinline__ f32x2 bf8x2_lo(unsigned w) {
+	return __builtin_amdgcn_cvt_pk_f32_bf8((int)w, false);
+}
+__device__ __forceinline__ f32x2 bf8x2_hi(unsigned w) {
+	return __builtin_amdgcn_cvt_pk_f32_bf8((int)w, true);
+}
+__device__ __forceinline__ float bf8_byte0(unsigned w) {
+	return __builtin_amdgcn_cvt_f32_bf8((int)w, 0);
+}
+
+__device__ __forceinline__ float half_bits_to_float(unsigned short h) {
+	return __half2float(__ushort_as_half(h));
+}
+
+// scalar decode of element idx of a weight tensor (embedding gather; src/infer.c:334-347)
+template <int DB>
+__device__ __forceinline__ float decode_elem(const void* w, size_t idx) {
+	if constexpr (DB == 16) {
+		return half_bits_to_float(((const unsigned short*)w)[idx]);
+	} else if constexpr (DB == 8) {
+		unsigned b = ((const unsigned char*)w)[idx];
+		return bf8_byte0(b);
+	} else {
+		unsigned v = ((const unsigned*)w)[idx >> 3];
+		float s = bf8_byte0(v) * -0.25f; // src/infer.c:38
+		int q = (int)((v >> (8 + 3 * (idx & 7))) & 7) - 4;
+		return (float)q * s;
+	}
+}
+
+// acc += dot(16-byte lane-load `v`, its G activations), as a 2-wide accumulator (even/odd columns)
+// so that every multiply-add is a v_pk_fma_f32 on register pairs that are already adjacent: the
+// converted weight pair, the activation pair from ds_read_b128, the accumulator pair.
+// xp points at this lane's first float4 of the chunk in the swizzled LDS image; float4 #i of the
+// lane is at xp[i * 64].
+template <int DB>
+__device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
+	if constexpr (DB == 16) {
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			f32x4 x = xp[i * 64];
+			unsigned w0 = v[2 * i], w1 = v[2 * i + 1];
+			f32x2 a = {half_bits_to_float((unsigned short)(w0 & 0xffff)), half_bits_to_float((unsigned short)(w0 >> 16))};
+			f32x2 b = {half_bits_to_float((unsigned short)(w1 & 0xffff)), half_bits_to_float((unsigned short)(w1 >> 16))};
+			acc = __builtin_elementwise_fma(a, x.lo, acc);
+			acc = __builtin_elementwise_fma(b, x.hi, acc);
+		}
+	} else if constexpr (DB == 8) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			f32x4 x = xp[i * 64];
+			acc = __builtin_elementwise_fma(bf8x2_lo(v[i]), x.lo, acc);
+			acc = __builtin_elementwise_fma(bf8x2_hi(v[i]), x.hi, acc);
+		}
+	} else {
+		// gf4: word = 8-bit e5m2 scale + 8 x 3-bit codes, w_k = (q_k - 4) * scale / -4
+		// (src/infer.c:37-40).  Sum the integer-weighted activations per word, scale once.
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			unsigned w = v[j];
+			f32x4 x0 = xp[(2 * j) * 64], x1 = xp[(2 * j + 1) * 64];
+			float s = bf8_byte0(w) * -0.25f;
+			f32x2 q0 = {(float)((int)((w >> 8) & 7) - 4), (float)((int)((w >> 11) & 7) - 4)};
+			f32x2 q1 = {(float)((int)((w >> 14) & 7) - 4), (float)((int)((w >> 17) & 7) - 4)};
+			f32x2 q2 = {(float)((int)((w >> 20) & 7) - 4), (float)((int)((w >> 23) & 7) - 4)};
+			f32x2 q3 = {(float)((int)((w >> 26) & 7) - 4), (float)((int)((w >> 29) & 7) - 4)};
+			f32x2 t = q0 * x0.lo;
+			t = __builtin_elementwise_fma(q1, x0.hi, t);
+			t = __builtin_elementwise_fma(q2, x1.lo, t);
+			t = __builtin_elementwise_fma(q3, x1.hi, t);
+			f32x2 s2 = {s, s};
+			acc = __builtin_elementwise_fma(s2, t, acc);
+		}
+	}
+	return acc;
+}
+
+// ---------------------------------------------------------------- activation staging ----------
+
+// Swizzled LDS image of an n-float vector for weight format DB.  Logical float4 p (columns
+// 4p..4p+3) belongs to chunk p / (16G), lane (p % 16G) / F4, sub-index i = p % F4 and is stored at
+// float4 slot chunk*16G + i*64 + lane: a wave reading "its float4 #i" hits 64 consecutive slots.
+template <int DB>
+__device__ __forceinline__ int swz4(int p) {
+	constexpr int G = Fmt<DB>::G, F4 = Fmt<DB>::F4;
+	int chunk = p / (16 * G), r = p % (16 * G);
+	return chunk * 16 * G + (r % F4) * 64 + r / F4;
+}
+
+// number of float4 slots the image of n floats occupies (whole chunks; the tail is zero-filled)
+template <int DB>
+__host__ __device__ constexpr int xs_slots(int n) {
+	return ((n + 64 * Fmt<DB>::G - 1) / (64 * Fmt<DB>::G)) * 16 * Fmt<DB>::G;
+}
+
+// block-wide sum; every thread gets the same value.  red: >= BLOCK/64 floats of LDS.
+template <int BLOCK>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+	constexpr int NW = BLOCK / 64;
+	v = wave_sum(v);
+	__syncthreads(); // protect red from the previous use
+	if (lane_id() == 0) {
+		red[threadIdx.x >> 6] = v;
+	}
+	__syncthreads();
+	float s = 0.f;
+#pragma unroll
+	for (int i = 0; i < NW; ++i) {
+		s += red[i];
+	}
+	return s;
+}
+
+// Stage src[0..n) into the swizzled image xs4, optionally normalised:
+//   normw == nullptr : plain copy
+//   else             : (x - mean) * rsqrt(var + eps) * normw, mean = 0 unless ln   (src/infer.c:183-207)
+// If dump != nullptr, block 0 also writes the staged (unswizzled) vector there (norm_par models
+// need the attention-norm output again in the FFN, src/infer.c:417-420).
+// Ends with a __syncthreads(): the image is readable on return.
+template <int DB, int BLOCK>
+__device__ __forceinline__ void stage_x(float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
+                                        int n, float eps, bool ln, float* dump) {
+	constexpr int MAXV = 8;
+	const int tid = threadIdx.x;
+	const int n4 = n >> 2;
+	const int slots = xs_slots<DB>(n);
+	const float4* src4 = (const float4*)src;
+
+	float4 v[MAXV];
+#pragma unroll
+	for (int i = 0; i < MAXV; ++i) {
+		int p = tid + i * BLOCK;
+		v[i] = p < n4 ? src4[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+
+	float mean = 0.f, scale = 1.f;
+	if (normw) {
+		if (ln) {
+			float s = 0.f;
+#pragma unroll
+			for (int i = 0; i < MAXV; ++i) {
+				s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+			}
+			for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
+				float4 t = src4[p];
+				s += (t.x + t.y) + (t.z + t.w);
+			}
+			mean = block_sum<BLOCK>(s, red) / (float)n;
+		}
+		float ss = 0.f;
+#pragma unroll
+		for (int i = 0; i < MAXV; ++i) {
+			int p = tid + i * BLOCK;
+			if (p < n4) {
+				float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+				ss += (a * a + b * b) + (c * c + d * d);
+			}
+		}
+		for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
+			float4 t = src4[p];
+			float a = t.x - mean, b = t.y - mean, c = t.z - mean, d = t.w - mean;
+			ss += (a * a + b * b) + (c * c + d * d);
+		}
+		float var = block_sum<BLOCK>(ss, red) / (float)n;
+		scale = 1.0f / sqrtf(var + eps);
+	}
+
+	const float4* w4 = (const float4*)normw;
+	auto emit = [&](int p, float4 t) {
+		if (normw) {
+			float4 g = w4[p];
+			t.x = (t.x - mean) * scale * g.x;
+			t.y = (t.y - mean) * scale * g.y;
+			t.z = (t.z - mean) * scale * g.z;
+			t.w = (t.w - mean) * scale * g.w;
+		}
+		xs4[swz4<DB>(p)] = t;
+		if (dump && blockIdx.x == 0) {
+			((float4*)dump)[p] = t;
+		}
+	};
+#pragma unroll
+	for (int i = 0; i < MAXV; ++i) {
+		int p = tid + i * BLOCK;
+		if (p < n4) {
+			emit(p, v[i]);
+		}
+	}
+	for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
+		emit(p, src4[p]);
+	}
+	// zero the tail of the last chunk so masked-off lanes multiply 0 * 0
+	for (int p = n4 + tid; p < slots; p += BLOCK) {
+		xs4[swz4<DB>(p)] = make_float4(0.f, 0.f, 0.f, 0.f);
+	}
+	__syncthreads();
+}
+
+// ---------------------------------------------------------------- the row engine --------------
+
+// A tile = U consecutive 1-KiB wave-loads of each of NR rows, held in registers.
+template <int NR, int U>
+struct Tile {
+	u32x4 w[U][NR];
+};
+
+// FULL: every row is a whole number of 1-KiB wave-loads (nl % 64 == 0), so no lane is ever masked
+template <int DB, int NR, int U, bool FULL>
+__device__ __forceinline__ void tile_load(Tile<NR, U>& t, const unsigned char* const (&rows)[NR], int k0, int nl, int lane) {
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		const int li = (k0 + u) * 64 + lane; // index of this lane's 16-byte piece within the row
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			if (FULL ? (k0 + u) * 64 < nl : li < nl) {
+				t.w[u][r] = __builtin_nontemporal_load((const u32x4*)rows[r] + li);
+			} else {
+				t.w[u][r] = (u32x4){0u, 0u, 0u, 0u};
+			}
+		}
+	}
+}
+
+template <int DB, int NR, int U>
+__device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR], const float4* xs4, int k0, int nl, int lane) {
+	constexpr int G = Fmt<DB>::G;
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+		if ((k0 + u) * 64 < nl) { // wave-uniform: skip chunks past the end of the row
+			const f32x4* xp = (const f32x4*)xs4 + (k0 + u) * 16 * G + lane;
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				acc[r] = dot16<DB>(t.w[u][r], xp, acc[r]);
+			}
+		}
+	}
+}
+
+// Runs `ntasks` row-group tasks over the workgroup's waves.  Wave-task t (t = first, first +
+// stride, ...) owns NR rows given by rows_of(t, rows).  stage() builds the LDS activation image and
+// must end with a barrier; it is called AFTER the first tile's loads have been issued so that the
+// weight stream starts before the prologue.  epi(t, acc) runs on every lane with the reduced sums.
+template <int DB, int NR, int U, bool FULL, class RowsFn, class StageFn, class EpiFn>
+__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, RowsFn rows_of, StageFn stage, EpiFn epi) {
+	const int lane = lane_id();
+	const int nl = n / Fmt<DB>::G;
+	const unsigned char* rows[NR];
+	Tile<NR, U> tile;
+	f32x2 acc2[NR];
+	float acc[NR];
+
+	int t = first;
+	const bool has = t < ntasks;
+	if (has) {
+		rows_of(t, rows);
+		tile_load<DB, NR, U, FULL>(tile, rows, 0, nl, lane);
+	}
+	stage();
+	if (!has) {
+		return;
+	}
+#pragma unroll
+	for (int r = 0; r < NR; ++r) {
+		acc2[r] = (f32x2){0.f, 0.f};
+	}
+	tile_fma<DB, NR, U>(tile, acc2, xs4, 0, nl, lane);
+	for (int k0 = U; k0 * 64 < nl; k0 += U) {
+		tile_load<DB, NR, U, FULL>(tile, rows, k0, nl, lane);
+		tile_fma<DB, NR, U>(tile, acc2, xs4, k0, nl, lane);
+	}
+#pragma unroll
+	for (int r = 0; r < NR; ++r) {
+		acc[r] = wave_sum(acc2[r][0] + acc2[r][1]);
+	}
+	epi(t, acc);
+
+	for (t += stride; t < ntasks; t += stride) {
+		rows_of(t, rows);
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			acc2[r] = (f32x2){0.f, 0.f};
+		}
+		for (int k0 = 0; k0 * 64 < nl; k0 += U) {
+			tile_load<DB, NR, U, FULL>(tile, rows, k0, nl, lane);
+			tile_fma<DB, NR, U>(tile, acc2, xs4, k0, nl, lane);
+		}
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			acc[r] = wave_sum(acc2[r][0] + acc2[r][1]);
+		}
+		epi(t, acc);
+	}
+}
+
+template <int DB, int NR, int U, class RowsFn, class StageFn, class EpiFn>
+__device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, RowsFn rows_of, StageFn stage, EpiFn epi) {
+	if ((n / Fmt<DB>::G) % 64 == 0) { // workgroup-uniform
+		run_rows_impl<DB, NR, U, true>(ntasks, first, stride, n, xs4, rows_of, stage, epi);
+	} else {
+		run_rows_impl<DB, NR, U, false>(ntasks, first, stride, n, xs4, rows_of, stage, epi);
+	}
+}
+
+// rows per task / tile depth per weight format: 8 x 1 KiB loads in flight per wave in all cases
+template <int DB>
+struct Shape {
+	static constexpr int NR = DB == 4 ? 4 : 2;
+	static constexpr int U = DB == 4 ? 2 : 4;
+};
+
+__device__ __forceinline__ float clipf(float x, float v) {
+	return x < -v ? -v : (x > v ? v : x); // src/infer.c:307-309
+}
+
+// ---------------------------------------------------------------- kernels ---------------------
+
+// token state + embedding row + this position's RoPE table.   (src/infer.c:329-347)
+// tok_src != nullptr: the token is read from device memory (device-side greedy decode).
+template <int DB>
+__global__ void k_begin_token(TokState* ts, int token, const int* tok_src, int pos, int kv_sink, int kv_pos, int kv_len, float* x, const void* embed,
+                              int dim, const float* rope_freq, float2* rope_cs, int half_hd) {
+	if (tok_src) {
+		token = *tok_src;
+	}
+	int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i == 0) {
+		ts->token = token;
+		ts->pos = pos;
+		ts->kv_sink = kv_sink;
+		ts->kv_pos = kv_pos;
+		ts->kv_len = kv_len;
+	}
+	if (i < dim) {
+		x[i] = decode_elem<DB>(embed, (size_t)token * dim + i);
+	}
+	if (i < half_hd) {
+		float val = (float)pos * rope_freq[i]; // src/infer.c:227-229
+		rope_cs[i] = make_float2(cosf(val), sinf(val));
+	}
+}
+
+// Advance the two attention-sink keys of every layer by one RoPE position (src/infer.c:383-394).
+// K cache layout: [layer][kv_head][seq_len][head_dim].  grid = (ceil(sink pairs / block), n_layers)
+template <int KVB>
+__global__ void k_rotate_sink(void* kc, const float2* rope_cs1, int n_kv_heads, int head_dim, int seq_len, int kv_sink) {
+	int half_hd = head_dim >> 1;
+	int idx = blockIdx.x * blockDim.x + threadIdx.x; // over (kv_head, r, pair)
+	int total = n_kv_heads * kv_sink * half_hd;
+	if (idx >= total) {
+		return;
+	}
+	int pair = idx % half_hd;
+	int r = (idx / half_hd) % kv_sink;
+	int h = idx / (half_hd * kv_sink);
+	size_t off = (((size_t)blockIdx.y * n_kv_heads + h) * seq_len + r) * head_dim + 2 * pair;
+	float2 cs = rope_cs1[pair];
+	if constexpr (KVB == 16) {
+		__half2* p = (__half2*)((__half*)kc + off);
+		float2 v = __half22float2(*p);
+		*p = __floats2half2_rn(v.x * cs.x - v.y * cs.y, v.x * cs.y + v.y * cs.x);
+	} else {
+		unsigned short* p = (unsigned short*)((unsigned char*)kc + off);
+		unsigned short b = *p;
+		f32x2 v = bf8x2_lo(b);
+		float a = v[0] * cs.x - v[1] * cs.y, c = v[0] * cs.y + v[1] * cs.x;
+		*p = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(a, c, 0, false) & 0xffff);
+	}
+}
+
+struct QkvArgs {
+	const float* x;
+	const float* norm_w;
+	const void *wq, *wk, *wv;
+	const float* bqkv;
+	float* q;
+	void *kc, *vc; // this layer's K / V cache: [kv_head][seq_len][head_dim]
+	float* xb_dump;
+	const TokState* ts;
+	const float2* rope_cs;
+	int dim, q_dim, kv_dim, head_dim, seq_len;
+	float eps, clip;
+	int ln;
+};
+
+// attention norm + fused q/k/v matvec + bias + clip + RoPE + KV append   (src/infer.c:352-381)
+// task = NR consecutive rows of the concatenated [wq; wk; wv]; rows come in RoPE pairs (2i, 2i+1).
+template <int DB, int KVB>
+__global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	float4* xs4 = (float4*)smem;
+	float* red = (float*)(xs4 + xs_slots<DB>(a.dim));
+	const int rows_total = a.q_dim + 2 * a.kv_dim;
+	const int ntasks = rows_total / NR;
+	const size_t row_bytes = (size_t)a.dim * DB / 8;
+	const int lane = lane_id();
+
+	auto row_ptr = [&](int j) -> const unsigned char* {
+		if (j < a.q_dim) {
+			return (const unsigned char*)a.wq + (size_t)j * row_bytes;
+		}
+		j -= a.q_dim;
+		if (j < a.kv_dim) {
+			return (const unsigned char*)a.wk + (size_t)j * row_bytes;
+		}
+		return (const unsigned char*)a.wv + (size_t)(j - a.kv_dim) * row_bytes;
+	};
+	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			rows[r] = row_ptr(t * NR + r);
+		}
+	};
+	auto stage = [&]() { stage_x<DB, 256>(xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
+	auto epi = [&](int t, float(&acc)[NR]) {
+		if (lane != 0) {
+			return;
+		}
+		const int kv_pos = a.ts->kv_pos;
+#pragma unroll
+		for (int r = 0; r < NR; r += 2) {
+			int j = t * NR + r; // even row of a pair
+			float v0 = acc[r], v1 = acc[r + 1];
+			if (a.bqkv) {
+				v0 += a.bqkv[j];
+				v1 += a.bqkv[j + 1];
+			}
+			v0 = clipf(v0, a.clip);
+			v1 = clipf(v1, a.clip);
+			if (j < a.q_dim + a.kv_dim) { // q or k: rotate the pair (src/infer.c:223-236)
+				int jl = j < a.q_dim ? j : j - a.q_dim;
+				float2 cs = a.rope_cs[(jl % a.head_dim) >> 1];
+				float r0 = v0 * cs.x - v1 * cs.y;
+				float r1 = v0 * cs.y + v1 * cs.x;
+				v0 = r0;
+				v1 = r1;
+			}
+			if (j < a.q_dim) {
+				*(float2*)(a.q + j) = make_float2(v0, v1);
+			} else {
+				int jl = j - a.q_dim;
+				void* cache = a.kc;
+				if (jl >= a.kv_dim) {
+					jl -= a.kv_dim;
+					cache = a.vc;
+				}
+				size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + kv_pos) * a.head_dim + (jl % a.head_dim);
+				if constexpr (KVB == 16) {
+					*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // RNE, as (half)x: src/infer.c:378-381
+				} else {
+					*(unsigned short*)((unsigned char*)cache + off) = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff);
+				}
+			}
+		}
+	};
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, rows_of, stage, epi);
+}
+
+// ---- attention --------------------------------------------------------------------------------
+
+struct AttnArgs {
+	const float* q;
+	const void *kc, *vc; // this layer's caches
+	float* out;          // (q_dim) normalised attention output, written when n_split == 1
+	float* partial;      // (n_heads, n_split, head_dim + 2) when n_split > 1: o[head_dim], m, l
+	const TokState* ts;
+	int head_dim, kv_mul, seq_len, n_split;
+};
+
+// merge two online-softmax states (m, l, o[8])
+__device__ __forceinline__ void sm_merge(float& m, float& l, float (&o)[8], float m2, float l2, const float (&o2)[8]) {
+	float M = fmaxf(m, m2);
+	float c1 = (m == -INFINITY) ? 0.f : __expf(m - M);
+	float c2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - M);
+	l = l * c1 + l2 * c2;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		o[i] = o[i] * c1 + o2[i] * c2;
+	}
+	m = M;
+}
+
+// One workgroup (4 waves) per (query head, kv split).  LPR lanes cover one cached row (8 dims per
+// lane, one 16-byte load for fp16), so a wave-load covers 64/LPR positions; the 4 waves interleave
+// tiles of positions.  Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are
+// computed in one pass with running (max, sum, out) per lane group -- algebraically the same
+// result as the reference's three loops.
+template <int KVB, int LPR>
+__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+	constexpr int RPW = 64 / LPR; // positions per wave-load
+	constexpr int NW = 4;
+	constexpr int UA = 4; // tiles in flight per wave
+	__shared__ float sm_m[NW], sm_l[NW];
+	__shared__ float sm_o[NW][LPR * 8];
+
+	const int lane = lane_id(), wave = wave_id();
+	const int h = blockIdx.x / a.n_split, split = blockIdx.x % a.n_split;
+	const int kvh = h / a.kv_mul;
+	const int r = lane % LPR, g = lane / LPR;
+	const int d0 = r * 8;
+	const bool dvalid = d0 < a.head_dim;
+	const int kv_len = a.ts->kv_len;
+	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
+	const int t0 = split * chunk;
+	const int t1 = min(kv_len, t0 + chunk);
+
+	float qv[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		qv[i] = dvalid ? a.q[h * a.head_dim + d0 + i] : 0.f;
+	}
+	const float sqrt_hd = sqrtf((float)a.head_dim);
+
+	float m = -INFINITY, l = 0.f, o[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		o[i] = 0.f;
+	}
+
+	constexpr int EB = KVB / 8; // bytes per element
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const size_t rstride = (size_t)a.head_dim * EB;
+
+	for (int tb = t0 + wave * RPW; tb < t1; tb += NW * RPW * UA) {
+		float kf[UA][8], vf[UA][8];
+		bool valid[UA];
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			int t = tb + u * NW * RPW + g;
+			valid[u] = t < t1;
+			if (valid[u] && dvalid) {
+				if constexpr (KVB == 16) {
+					u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
+					u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[i] & 0xffff));
+						kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[i] >> 16));
+						vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[i] & 0xffff));
+						vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[i] >> 16));
+					}
+				} else {
+					u32x2 kw = *(const u32x2*)(kbase + (size_t)t * rstride);
+					u32x2 vw = *(const u32x2*)(vbase + (size_t)t * rstride);
+#pragma unroll
+					for (int i = 0; i < 2; ++i) {
+						f32x2 k0 = bf8x2_lo(kw[i]), k1 = bf8x2_hi(kw[i]);
+						f32x2 v0 = bf8x2_lo(vw[i]), v1 = bf8x2_hi(vw[i]);
+						kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
+						vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+					}
+				}
+			} else {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					kf[u][i] = 0.f, vf[u][i] = 0.f;
+				}
+			}
+		}
+		float s[UA];
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			float d = 0.f;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				d = fmaf(qv[i], kf[u][i], d);
+			}
+#pragma unroll
+			for (int ofs = LPR / 2; ofs > 0; ofs >>= 1) {
+				d += __shfl_xor(d, ofs);
+			}
+			s[u] = valid[u] ? d / sqrt_hd : -INFINITY; // src/infer.c:247
+		}
+		float mn = m;
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			mn = fmaxf(mn, s[u]);
+		}
+		if (mn != -INFINITY) {
+			float c = (m == -INFINITY) ? 0.f : __expf(m - mn);
+			l *= c;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				o[i] *= c;
+			}
+#pragma unroll
+			for (int u = 0; u < UA; ++u) {
+				float p = valid[u] ? __expf(s[u] - mn) : 0.f;
+				l += p;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					o[i] = fmaf(p, vf[u][i], o[i]);
+				}
+			}
+			m = mn;
+		}
+	}
+
+	// merge the RPW lane groups of the wave
+#pragma unroll
+	for (int ofs = LPR; ofs < 64; ofs <<= 1) {
+		float m2 = __shfl_xor(m, ofs), l2 = __shfl_xor(l, ofs), o2[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			o2[i] = __shfl_xor(o[i], ofs);
+		}
+		sm_merge(m, l, o, m2, l2, o2);
+	}
+	// merge the waves through LDS
+	if (g == 0) {
+		if (r == 0) {
+			sm_m[wave] = m;
+			sm_l[wave] = l;
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			sm_o[wave][d0 + i] = o[i];
+		}
+	}
+	__syncthreads();
+	if (wave == 0 && g == 0) {
+		m = sm_m[0], l = sm_l[0];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			o[i] = sm_o[0][d0 + i];
+		}
+#pragma unroll
+		for (int w = 1; w < NW; ++w) {
+			float o2[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				o2[i] = sm_o[w][d0 + i];
+			}
+			sm_merge(m, l, o, sm_m[w], sm_l[w], o2);
+		}
+		if (dvalid) {
+			if (a.n_split == 1) {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					a.out[h * a.head_dim + d0 + i] = o[i] / l;
+				}
+			} else {
+				float* p = a.partial + ((size_t)h * a.n_split + split) * (a.head_dim + 2);
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					p[d0 + i] = o[i];
+				}
+				if (r == 0) {
+					p[a.head_dim] = m;
+					p[a.head_dim + 1] = l;
+				}
+			}
+		}
+	}
+}
+
+// merge the kv splits of every head: grid = n_heads, block = 64 (dims strided over lanes)
+__global__ void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
+	const int h = blockIdx.x;
+	const float* p = partial + (size_t)h * n_split * (head_dim + 2);
+	float M = -INFINITY;
+	for (int s = 0; s < n_split; ++s) {
+		M = fmaxf(M, p[s * (head_dim + 2) + head_dim]);
+	}
+	float L = 0.f;
+	for (int s = 0; s < n_split; ++s) {
+		float ms = p[s * (head_dim + 2) + head_dim];
+		L += (ms == -INFINITY) ? 0.f : p[s * (head_dim + 2) + head_dim + 1] * __expf(ms - M);
+	}
+	for (int d = threadIdx.x; d < head_dim; d += blockDim.x) {
+		float acc = 0.f;
+		for (int s = 0; s < n_split; ++s) {
+			float ms = p[s * (head_dim + 2) + head_dim];
+			acc += (ms == -INFINITY) ? 0.f : p[s * (head_dim + 2) + d] * __expf(ms - M);
+		}
+		out[h * head_dim + d] = acc / L;
+	}
+}
+
+// ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
+template <int DB>
+__global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	float4* xs4 = (float4*)smem;
+	float* red = (float*)(xs4 + xs_slots<DB>(q_dim));
+	const size_t row_bytes = (size_t)q_dim * DB / 8;
+	const int lane = lane_id();
+	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			rows[r] = (const unsigned char*)wo + (size_t)(t * NR + r) * row_bytes;
+		}
+	};
+	auto stage = [&]() { stage_x<DB, 256>(xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
+	auto epi = [&](int t, float(&acc)[NR]) {
+		if (lane == 0) {
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				x[t * NR + r] += acc[r];
+			}
+		}
+	};
+	run_rows<DB, NR, U>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, rows_of, stage, epi);
+}
+
+// ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
+
+struct FfnUpArgs {
+	const float* x;      // residual stream (normed here) or, for norm_par models, the saved xb
+	const float* norm_w; // nullptr => x is already normalised (norm_par)
+	const void *w1, *w3, *moegate;
+	float* he;      // (n_active, hidden)
+	float* moe_w;   // (n_active) routing weights, written by block 0
+	int* moe_e;     // (n_active) routed expert ids
+	int dim, hidden, n_experts, n_active;
+	float eps;
+	int ln, gelu;
+};
+
+__device__ __forceinline__ float act_silu(float x) {
+	return x / (1.0f + expf(-x)); // src/infer.c:273-275
+}
+__device__ __forceinline__ float act_gelu(float x) {
+	return 0.5f * x * (1.0f + tanhf(0.797885f * (x + 0.044715f * x * x * x))); // src/infer.c:269-271
+}
+
+// task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
+template <int DB>
+__global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int JP = NR / 2; // hidden units per task
+	float4* xs4 = (float4*)smem;
+	float* red = (float*)(xs4 + xs_slots<DB>(a.dim));
+	float* gate = red + 16;          // n_experts logits
+	float* sel_w = gate + 64;        // n_active
+	int* sel_e = (int*)(sel_w + 64); // n_active
+	const size_t row_bytes = (size_t)a.dim * DB / 8;
+	const int lane = lane_id(), wave = wave_id();
+	const int nact = a.n_active > 0 ? a.n_active : 1;
+	const int per_expert = a.hidden / JP;
+	const int ntasks = nact * per_expert;
+	const bool moe = a.n_experts > 0;
+
+	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
+		int k = t / per_expert, j = (t % per_expert) * JP;
+		int e = moe ? sel_e[k] : 0;
+		size_t base = ((size_t)e * a.hidden + j) * row_bytes;
+#pragma unroll
+		for (int p = 0; p < JP; ++p) {
+			rows[2 * p] = (const unsigned char*)a.w1 + base + p * row_bytes;
+			rows[2 * p + 1] = (const unsigned char*)a.w3 + base + p * row_bytes;
+		}
+	};
+	auto epi = [&](int t, float(&acc)[NR]) {
+		if (lane == 0) {
+			int k = t / per_expert, j = (t % per_expert) * JP;
+#pragma unroll
+			for (int p = 0; p < JP; ++p) {
+				float u = acc[2 * p], g = acc[2 * p + 1];
+				a.he[(size_t)k * a.hidden + j + p] = (a.gelu ? act_gelu(u) : act_silu(u)) * g; // src/infer.c:440-450
+			}
+		}
+	};
+
+	if (!moe) {
+		auto stage = [&]() { stage_x<DB, 256>(xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
+		run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, rows_of, stage, epi);
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
+			a.moe_w[0] = 1.0f; // src/infer.c:430-432
+			a.moe_e[0] = 0;
+		}
+		return;
+	}
+
+	// MoE: the routing decides which rows to stream, so it has to come first.  Every workgroup
+	// recomputes the gate (n_experts short rows, L2-resident) -- no cross-workgroup hand-off.
+	stage_x<DB, 256>(xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr);
+	{
+		const int nl = a.dim / Fmt<DB>::G;
+		for (int e = wave; e < a.n_experts; e += 4) {
+			const unsigned char* row = (const unsigned char*)a.moegate + (size_t)e * row_bytes;
+			f32x2 acc2 = {0.f, 0.f};
+			for (int k = 0; k * 64 < nl; ++k) {
+				int li = k * 64 + lane;
+				u32x4 w = li < nl ? *((const u32x4*)row + li) : (u32x4){0u, 0u, 0u, 0u};
+				acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * 16 * Fmt<DB>::G + lane, acc2);
+			}
+			float acc = wave_sum(acc2[0] + acc2[1]);
+			if (lane == 0) {
+				gate[e] = acc;
+			}
+		}
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			// top-k by logit, first maximum wins ties; weights = softmax over the selected logits
+			// (src/infer.c:277-305)
+			float max_val = -3.402823466e+38f;
+			for (int j = 0; j < a.n_experts; ++j) {
+				max_val = max_val < gate[j] ? gate[j] : max_val;
+			}
+			unsigned long long mask = 0;
+			float wsum = 0.f;
+			for (int k = 0; k < a.n_active; ++k) {
+				int best = -1;
+				for (int j = 0; j < a.n_experts; ++j) {
+					if ((mask & (1ull << j)) == 0 && (best == -1 || gate[j] > gate[best])) {
+						best = j;
+					}
+				}
+				sel_e[k] = best;
+				wsum += expf(gate[best] - max_val);
+				mask |= 1ull << best;
+			}
+			for (int k = 0; k < a.n_active; ++k) {
+				sel_w[k] = expf(gate[sel_e[k]] - max_val) / wsum;
+			}
+			if (blockIdx.x == 0) {
+				for (int k = 0; k < a.n_active; ++k) {
+					a.moe_w[k] = sel_w[k];
+					a.moe_e[k] = sel_e[k];
+				}
+			}
+		}
+		__syncthreads();
+	}
+	auto nostage = [&]() {};
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, rows_of, nostage, epi);
+}
+
+// ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
+// Experts are added in rank order (k = 0, 1, ...) by the same lane, so the sum order is the
+// reference's and is deterministic (the CUDA path's atomicAdd, src/infer.cu:618, is not).
+template <int DB, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
+                                                    int n_active) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int NW = BLOCK / 64;
+	float4* xs4 = (float4*)smem;
+	float* red = (float*)(xs4 + xs_slots<DB>(hidden));
+	const size_t row_bytes = (size_t)hidden * DB / 8;
+	const int lane = lane_id();
+	const int nact = n_active > 0 ? n_active : 1;
+	for (int k = 0; k < nact; ++k) {
+		const float wk = moe_w[k];
+		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes;
+		auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				rows[r] = wbase + (size_t)(t * NR + r) * row_bytes;
+			}
+		};
+		auto stage = [&]() {
+			if (k > 0) {
+				__syncthreads(); // everyone is done reading the previous expert's image
+			}
+			stage_x<DB, BLOCK>(xs4, red, he + (size_t)k * hidden, nullptr, hidden, 0.f, false, nullptr);
+		};
+		auto epi = [&](int t, float(&acc)[NR]) {
+			if (lane == 0) {
+#pragma unroll
+				for (int r = 0; r < NR; ++r) {
+					x[t * NR + r] += acc[r] * wk;
+				}
+			}
+		};
+		run_rows<DB, NR, U>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, rows_of, stage, epi);
+	}
+}
+
+// ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
+template <int DB>
+__global__ __launch_bounds__(256) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	float4* xs4 = (float4*)smem;
+	float* red = (float*)(xs4 + xs_slots<DB>(dim));
+	const size_t row_bytes = (size_t)dim * DB / 8;
+	const int lane = lane_id();
+	const int ntasks = (vocab + NR - 1) / NR;
+	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			int j = min(t * NR + r, vocab - 1); // ragged last task: re-read the last row, drop the result
+			rows[r] = (const unsigned char*)wcls + (size_t)j * row_bytes;
+		}
+	};
+	auto stage = [&]() { stage_x<DB, 256>(xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
+	auto epi = [&](int t, float(&acc)[NR]) {
+		if (lane == 0) {
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				if (t * NR + r < vocab) {
+					logits[t * NR + r] = acc[r];
+				}
+			}
+		}
+	};
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, rows_of, stage, epi);
+}
+
+// ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
+// single workgroup of 1024 threads; writes *next and, if trace, appends to trace[(*trace_count)++]
+__global__ __launch_bounds__(1024) void k_argmax(const float* logits, int n, int* next, int* trace, int* trace_count) {
+	__shared__ float sv[16];
+	__shared__ int si[16];
+	float best = -3.402823466e+38f; // -FLT_MAX: values must be strictly greater to be picked
+	int bi = -1;
+	for (int i = threadIdx.x; i < n; i += 1024) { // ascending per thread: strict > keeps the first
+		float v = logits[i];
+		if (v > best) {
+			best = v;
+			bi = i;
+		}
+	}
+	auto better = [](float v2, int i2, float v, int i) { return i2 >= 0 && (i < 0 || v2 > v || (v2 == v && i2 < i)); };
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		float v2 = __shfl_xor(best, o);
+		int i2 = __shfl_xor(bi, o);
+		if (better(v2, i2, best, bi)) {
+			best = v2;
+			bi = i2;
+		}
+	}
+	if (lane_id() == 0) {
+		sv[threadIdx.x >> 6] = best;
+		si[threadIdx.x >> 6] = bi;
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 16; ++w) {
+			if (better(sv[w], si[w], best, bi)) {
+				best = sv[w];
+				bi = si[w];
+			}
+		}
+		*next = bi;
+		if (trace) {
+			int slot = (*trace_count)++;
+			trace[slot] = bi;
+		}
+	}
+}
+
+} // namespace calm

@@ -1,0 +1,280 @@
+"""Host side of the decode path, mirroring the reference CLI's setup and loop (src/run.c).
+
+    HostModel      = main()'s model set-up: metadata -> struct Config (run.c:32-69), tensor lookup
+                     -> struct Weights (run.c:71-117), byte accounting (run.c:131-152,523-532)
+    HipBackend     = the backend binding: upload_hip per "model.*" tensor (run.c:550-561),
+                     prepare_hip (run.c:578-583), forward_hip through the C ABI (ctypes)
+    generate()     = the greedy decode loop with the reference's throughput/bandwidth accounting
+                     (run.c:167-256)
+
+The arithmetic all happens behind the C ABI in libcalm_hip.so; this module is plumbing.  There is
+deliberately NO CPU fallback here: without a GPU HipBackend raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import abi
+from .calmfile import DBITS, CalmFile
+
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcalm_hip.so")
+
+
+def load_lib() -> C.CDLL:
+    """dlopen libcalm_hip.so and declare the prototypes of include/calm_hip.h + calm_hip_test.h"""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -m calm_amd.build` (hipcc --offload-arch=gfx950)")
+    lib = C.CDLL(LIB_PATH)
+    T = C.POINTER(abi.Transformer)
+    fp = C.POINTER(C.c_float)
+    protos = {
+        "init_hip": (None, []),
+        "upload_hip": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+        "prepare_hip": (None, [T]),
+        "forward_hip": (fp, [T, C.c_int, C.c_int, C.c_uint]),
+        "perf_hip": (None, []),
+        "calm_hip_device_count": (C.c_int, []),
+        "calm_hip_device_name": (C.c_char_p, []),
+        "calm_hip_configure": (C.c_int, [C.c_char_p, C.c_int]),
+        "release_hip": (None, [T]),
+        "free_hip": (None, [C.c_void_p]),
+        "decode_greedy_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "perf_stage_hip": (C.c_double, [T, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
+        "calm_hip_test_matvec": (None, [C.c_int, C.c_void_p, fp, fp, C.c_int, C.c_int]),
+        "calm_hip_test_norm_matvec": (None, [C.c_int, C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int]),
+        "calm_hip_test_attn": (None, [fp, C.c_void_p, C.c_void_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+        "calm_hip_test_argmax": (C.c_int, [fp, C.c_int]),
+        "download_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
+        "calm_hip_read_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
+        "calm_hip_membench": (C.c_double, [C.c_size_t, C.c_int, C.c_int]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # raises AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+EXPORTS = [
+    "init_hip", "upload_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
+    "free_hip", "decode_greedy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
+    "calm_hip_test_argmax", "download_hip", "calm_hip_read_kv", "calm_hip_membench",
+]
+
+STAGES = ["qkv", "attn", "attn_out", "ffn_up", "ffn_down", "output"]
+
+
+def fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+class HostModel:
+    """a model held on the host: metadata + named tensors (numpy arrays or mmap views)"""
+
+    def __init__(self, tensors: Dict[str, np.ndarray], metadata: Dict[str, object], context: int = 0):
+        self.tensors = tensors
+        self.metadata = {k: str(v) for k, v in metadata.items()}
+        self.dtype = self.metadata["dtype"]
+        self.dbits = DBITS[self.dtype]
+        self.config = self._config(context)
+
+    @classmethod
+    def from_file(cls, path: str, context: int = 0) -> "HostModel":
+        f = CalmFile(path)
+        m = cls({n: f.tensor(n) for n in f.names()}, f.metadata, context)
+        m._file = f
+        return m
+
+    # -- src/run.c:32-69
+    def _config(self, context: int) -> abi.Config:
+        md = self.metadata
+        c = abi.Config()
+        c.dim = int(md["dim"])
+        c.hidden_dim = int(md["hidden_dim"])
+        c.n_layers = int(md["n_layers"])
+        c.n_heads = int(md["n_heads"])
+        c.n_kv_heads = int(md["n_kv_heads"])
+        c.vocab_size = int(md["vocab_size"])
+        c.head_dim = int(md["head_dim"])
+        msl = md.get("max_seq_len")
+        c.seq_len = int(msl) if msl is not None and int(msl) < 4096 else 4096  # run.c:41-43: capped at 4096 unless -c
+        if context:
+            c.seq_len = context
+        c.rope_theta = float(md["rope_theta"])
+        c.rotary_dim = int(md["rotary_dim"])
+        if "n_experts" in md:
+            c.n_experts = int(md["n_experts"])
+            c.n_experts_ac = int(md["n_experts_active"])
+        c.norm_eps = float(md.get("norm_eps", 1e-5))
+        c.act_gelu = md.get("act_type") == "gelu"
+        nt = md.get("norm_type", "")
+        c.norm_ln = nt.startswith("layernorm")
+        c.norm_par = nt == "layernorm_par"
+        c.qkv_clip = float(md["qkv_clip"]) if "qkv_clip" in md else float(np.finfo(np.float32).max)
+        return c
+
+    # -- src/run.c:131-152,523-532
+    def accounting(self):
+        def count(prefix, flt=None):
+            b = p = 0
+            for n, a in self.tensors.items():
+                if not n.startswith(prefix) or (flt and flt not in n):
+                    continue
+                p += a.size * (8 if a.dtype == np.int32 else 1)
+                b += a.nbytes
+            return b, p
+
+        n_bytes, n_params = count("model.")
+        n_bw = n_bytes - count("model.embed.")[0]
+        if "model.output.weight" not in self.tensors:
+            n_bw += self.tensors["model.embed.weight"].nbytes
+        if self.config.n_experts:
+            mlp = count("model.layers.", ".mlp.w")[0]
+            n_bw -= mlp
+            n_bw += mlp // self.config.n_experts * self.config.n_experts_ac
+        return n_params, n_bytes, n_bw
+
+    def kv_bandwidth(self, kvbits: int, pos: int) -> int:
+        """src/run.c:161-165"""
+        c = self.config
+        kv_len = c.seq_len if pos >= c.seq_len else pos + 1
+        return 2 * (kvbits // 8) * c.n_layers * (c.head_dim * c.n_kv_heads) * kv_len
+
+    # -- src/run.c:71-117 with `addr` supplying the pointer for each tensor (host or device)
+    def fill_transformer(self, t: abi.Transformer, addr: Callable[[str], int], kvbits: int = 16) -> None:
+        C.memmove(C.byref(t.config), C.byref(self.config), C.sizeof(abi.Config))
+        w = t.weights
+        w.dbits = self.dbits
+        cfg = self.config
+        has = lambda n: n in self.tensors
+        w.token_embedding_table = addr("model.embed.weight")
+        for l in range(cfg.n_layers):
+            p = f"model.layers.{l}."
+            w.rms_att_weight[l] = addr(p + "attn.norm.weight")
+            if not cfg.norm_par:
+                w.rms_ffn_weight[l] = addr(p + "mlp.norm.weight")
+            w.wq[l] = addr(p + "attn.wq.weight")
+            w.wk[l] = addr(p + "attn.wk.weight")
+            w.wv[l] = addr(p + "attn.wv.weight")
+            w.wo[l] = addr(p + "attn.wo.weight")
+            if has(p + "attn.wqkv.bias"):
+                w.bqkv[l] = addr(p + "attn.wqkv.bias")
+            if cfg.n_experts:
+                w.moegate[l] = addr(p + "moegate.weight")
+            w.w1[l] = addr(p + "mlp.w1.weight")
+            w.w2[l] = addr(p + "mlp.w2.weight")
+            w.w3[l] = addr(p + "mlp.w3.weight")
+        w.rms_final_weight = addr("model.norm.weight")
+        w.wcls = addr("model.output.weight") if has("model.output.weight") else w.token_embedding_table
+        t.state.kvbits = kvbits
+        t.n_params, t.n_bytes, t.n_bandwidth = self.accounting()
+
+
+class HipBackend:
+    """binds a HostModel to libcalm_hip.so exactly the way src/run.c:550-596 binds a GPU backend"""
+
+    def __init__(self, model: HostModel, kvbits: int = 16, stream=None):
+        """stream: optional iterable of (name, array) supplying the tensor bytes one at a time (buffers
+        may be reused between items -- each is uploaded before the next is drawn); model.tensors then
+        only needs shape/dtype placeholders (calmfile.stub_tensors)"""
+        self.lib = load_lib()
+        if self.lib.calm_hip_device_count() <= 0:
+            raise RuntimeError("no HIP device visible: the calm_amd backend has no CPU fallback")
+        self.model = model
+        self.t = abi.Transformer()
+        self._dev: Dict[str, int] = {}
+        self.lib.init_hip()
+        for name, a in (stream if stream is not None else model.tensors.items()):
+            if name.startswith("model."):  # run.c:556-558
+                a = np.ascontiguousarray(a)
+                self._dev[name] = self.lib.upload_hip(a.ctypes.data, a.nbytes)
+        model.fill_transformer(self.t, lambda n: self._dev[n], kvbits)
+        self.lib.prepare_hip(C.byref(self.t))
+        self.vocab = model.config.vocab_size
+
+    def forward(self, token: int, pos: int, flags: int = 0) -> Optional[np.ndarray]:
+        """-> view of the backend's logits buffer (valid until the next call), or None for KV-only"""
+        p = self.lib.forward_hip(C.byref(self.t), token, pos, flags)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def decode_greedy(self, token: int, pos: int, n_steps: int):
+        out = (C.c_int * n_steps)()
+        p = self.lib.decode_greedy_hip(C.byref(self.t), token, pos, n_steps, out)
+        return np.array(out[:], dtype=np.int64), np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def stage_us(self, stage: int, iters: int = 4):
+        b = C.c_uint64(0)
+        us = self.lib.perf_stage_hip(C.byref(self.t), stage, iters, C.byref(b))
+        return us, b.value
+
+    def read_state(self, field: str, count: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.float32)
+        self.lib.download_hip(out.ctypes.data, getattr(self.t.state, field), out.nbytes)
+        return out
+
+    def read_kv(self, layer: int, which: int) -> np.ndarray:
+        c = self.model.config
+        out = np.empty((c.seq_len, c.head_dim * c.n_kv_heads), dtype=np.uint16)
+        self.lib.calm_hip_read_kv(C.byref(self.t), layer, which, out.ctypes.data)
+        return out.view(np.float16)
+
+    def close(self):
+        if self.t is not None:
+            self.lib.release_hip(C.byref(self.t))
+            for d in self._dev.values():
+                self.lib.free_hip(d)
+            self._dev.clear()
+            self.t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def argmax_first(logits: np.ndarray) -> int:
+    """greedy sampler of the reference (src/sampler.c:34-42): first index of the strict maximum"""
+    return int(np.argmax(logits))
+
+
+def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int, pos_offset: int = 0, kvbits: int = 16):
+    """greedy decode loop of src/run.c:167-256 (temperature 0): returns (tokens, stats).
+
+    The first len(prompt)-1 positions are KV-only prompt steps; timing covers the whole loop, and
+    tok/s = positions / elapsed with prompt positions included, like the reference (run.c:249-253).
+    """
+    FF = abi.FF_UPDATE_KV_ONLY
+    n_prompt = len(prompt_tokens)
+    token = int(prompt_tokens[0])
+    pos = 0
+    out: List[int] = []
+    read_bytes = 0
+    _, _, n_bw = model.accounting()
+    t0 = time.perf_counter()
+    while pos < steps:
+        flags = FF if pos < n_prompt - 1 else 0
+        logits = backend.forward(token, pos + pos_offset, flags)
+        read_bytes += n_bw + model.kv_bandwidth(kvbits, pos + pos_offset)
+        if pos < n_prompt - 1:
+            nxt = int(prompt_tokens[pos + 1])
+        else:
+            nxt = argmax_first(logits)
+        pos += 1
+        out.append(nxt)
+        token = nxt
+    dt = time.perf_counter() - t0
+    stats = {"tokens": pos, "seconds": dt, "tok_s": pos / dt, "GBps": read_bytes / 1e9 / dt, "read_bytes": read_bytes}
+    return out, stats

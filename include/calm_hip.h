@@ -1,0 +1,108 @@
+/*
+ * calm_hip.h -- C ABI of the MI355X (gfx950) infer backend: libcalm_hip.so
+ *
+ * The first four entry points are exactly what calm's host program binds for a GPU backend
+ * (reference src/run.c:22-25 declares upload_cuda / prepare_cuda / forward_cuda / perf_cuda and
+ * src/run.c:27-30 the Metal quartet incl. init_metal); they keep the same signatures, argument
+ * meaning, call order and error behaviour (no error returns: any HIP failure prints a message
+ * and abort()s, like CUDA_CHECK in reference src/infer.cu:12-20).
+ *
+ * Call order (reference src/run.c:550-612):
+ *     [init_hip]  ->  upload_hip(tensor) for every "model.*" tensor  ->  host fills struct Weights
+ *     with the returned device pointers  ->  host sets state.kvbits  ->  prepare_hip(t)
+ *     ->  t->forward = forward_hip  ->  forward_hip(t, token, pos, flags) once per token.
+ *
+ * Everything below the "extensions" line is new surface that the reference does not have; the
+ * drop-in path never needs it.
+ */
+#ifndef CALM_HIP_H
+#define CALM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "calm_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the drop-in quartet (+ optional init) ------------------------------------------------ */
+
+/* replaces init_metal (src/run.c:27,566): optional; selects the device (env CALM_HIP_DEVICE or
+ * LOCAL_RANK, default 0) and creates the stream. upload_hip/prepare_hip call it lazily. */
+void init_hip(void);
+
+/* replaces upload_cuda (src/run.c:22,557; src/infer.cu:69-71): copies `size` bytes from `host`
+ * into freshly allocated device memory and returns the DEVICE pointer, which the host stores
+ * back into tensor->data. Asynchronous w.r.t. the host buffer only until prepare_hip, which
+ * synchronises; the mmap must stay mapped until then (it does: src/run.c:515,637). */
+void* upload_hip(void* host, size_t size);
+
+/* replaces prepare_cuda (src/run.c:23,580; src/infer.cu:73-131): allocates activations, the KV
+ * cache (state.kvbits must already be 8 or 16) and the host-visible logits buffer, and snapshots
+ * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits. */
+void prepare_hip(struct Transformer* transformer);
+
+/* replaces forward_cuda (src/run.c:24,581; src/infer.cu:743-759): one decode step for `token`
+ * at absolute position `pos` (may exceed seq_len: rolling KV buffer with CALM_KV_SINKS sinks;
+ * may go backwards between calls). Returns state.logits (vocab_size floats, host memory, valid
+ * until the next call, caller may overwrite) after synchronising; with FF_UPDATE_KV_ONLY returns
+ * NULL after enqueueing the work without synchronising (src/infer.cu:724-727). */
+float* forward_hip(struct Transformer* transformer, int token, int pos, unsigned flags);
+
+/* replaces perf_cuda (src/run.c:25,629-633; src/infer.cu:761-801): prints a per-stage
+ * time / algorithmic-GB/s table accumulated while env CALM_HIP_PROF=1; otherwise a no-op. */
+void perf_hip(void);
+
+/* ---- extensions (not needed by the drop-in path) ------------------------------------------ */
+
+/* number of visible HIP devices (0 => no GPU; every other entry point aborts in that case) */
+int calm_hip_device_count(void);
+
+/* frees everything prepare_hip allocated for this transformer (the reference never frees,
+ * src/run.c:636; tests load many models per process). Uploaded weights are NOT freed here. */
+void release_hip(struct Transformer* transformer);
+
+/* frees one buffer returned by upload_hip */
+void free_hip(void* device);
+
+/* Greedy decode of n_steps tokens entirely on the device (argmax on the GPU, next token fed
+ * back without a host round trip); equals n_steps calls of forward_hip + sample_argmax
+ * (reference src/sampler.c:34-42: first index of the strict maximum). Writes the n_steps sampled
+ * token ids to out_tokens; returns state.logits of the last step. */
+float* decode_greedy_hip(struct Transformer* transformer, int token, int pos, int n_steps, int* out_tokens);
+
+/* Stage timer for roofline reporting: launches the kernel of `stage` for every layer in turn
+ * (so successive launches stream different weights and cannot hit the 256 MiB Infinity Cache),
+ * `iters` sweeps, bracketed by hipEvents on the backend's own stream.
+ * Returns the average duration of ONE launch in microseconds and stores the algorithmic bytes
+ * one launch reads (reference accounting, src/infer.cu:692-699) in *bytes_per_launch. */
+enum CalmHipStage {
+	CALM_STAGE_QKV = 0,      /* norm + wq/wk/wv matvec + bias + clip + RoPE + KV append */
+	CALM_STAGE_ATTN = 1,     /* KV-cache attention (online softmax) */
+	CALM_STAGE_ATTN_OUT = 2, /* wo matvec + residual */
+	CALM_STAGE_FFN_UP = 3,   /* norm + [moe gate] + act(w1 x) * (w3 x) */
+	CALM_STAGE_FFN_DOWN = 4, /* w2 matvec + weighted residual */
+	CALM_STAGE_OUTPUT = 5,   /* final norm + classifier */
+	CALM_STAGE_COUNT = 6,
+};
+double perf_stage_hip(struct Transformer* transformer, int stage, int iters, uint64_t* bytes_per_launch);
+
+/* name of the HIP device in use (static storage) */
+const char* calm_hip_device_name(void);
+
+/* Run-time knobs (same as the CALM_HIP_* environment variables read by init_hip):
+ *   "graph"   1 = replay each step from a hipGraph (default), 0 = eager launches
+ *   "prof"    1 = eager launches bracketed by per-stage events, reported by perf_hip
+ *   "bpc"     cap on resident 256-thread workgroups per CU when sizing grids (default 4)
+ *   "split_t" cached positions per attention KV split (default 1024)
+ * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.
+ * Changing "bpc"/"split_t" only affects graphs captured afterwards. */
+int calm_hip_configure(const char* key, int value);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CALM_HIP_H */

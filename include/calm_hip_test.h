@@ -1,0 +1,54 @@
+/*
+ * calm_hip_test.h -- unit-level entry points of libcalm_hip.so used by tests/ and bench.py.
+ *
+ * They run the SAME device kernels as forward_hip on caller-provided host buffers (uploaded
+ * internally), so a parity failure of a whole decode step can be localised to one kernel.  The
+ * reference has no counterpart (it has no tests); semantics cite src/infer.c.
+ */
+#ifndef CALM_HIP_TEST_H
+#define CALM_HIP_TEST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "calm_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* out[d] = W(d,n) . x[n]   -- the row engine without a norm prologue (src/infer.c:209-221).
+ * w: d rows of n weights stored as dbits (16 fp16 / 8 fp8-e5m2 / 4 gf4 words). Host pointers. */
+void calm_hip_test_matvec(int dbits, const void* w, const float* x, float* out, int n, int d);
+
+/* out[d] = W(d,n) . norm(x)[n], norm = RMSNorm or bias-free LayerNorm with weight nw
+ * (src/infer.c:183-207 then :209-221) -- the row engine with its norm prologue. */
+void calm_hip_test_norm_matvec(int dbits, const void* w, const float* x, const float* nw, float* out, int n, int d, float eps, int ln);
+
+/* One attention call over a caller-provided fp16 KV cache in the ORACLE's layout
+ * [seq_len][kv_dim] (src/infer.c:355-357); it is re-laid out to the backend's private layout
+ * internally.  q: (n_heads*head_dim), out: (n_heads*head_dim).  n_split > 1 exercises the
+ * split-KV path + merge kernel. */
+void calm_hip_test_attn(const float* q, const uint16_t* kcache, const uint16_t* vcache, float* out, int n_heads, int n_kv_heads, int head_dim,
+                        int seq_len, int kv_len, int n_split);
+
+/* first index of the strict maximum (reference src/sampler.c:34-42), computed on the device */
+int calm_hip_test_argmax(const float* logits, int n);
+
+/* copy `size` bytes of device memory (e.g. t->state.x, a KV cache) back to the host */
+void download_hip(void* host, const void* device, size_t size);
+
+/* Re-layout helper: reads this backend's K or V cache of one layer into the oracle's
+ * [seq_len][kv_dim] fp16 layout (host).  which: 0 = K, 1 = V.  Only for kvbits == 16. */
+void calm_hip_read_kv(struct Transformer* transformer, int layer, int which, uint16_t* host);
+
+/* Streaming-read micro-benchmark: sums `bytes` of device memory with 16-byte loads
+ * (nt != 0: non-temporal) `iters` times; returns GB/s.  bytes <= 128 MiB stays in the 256 MiB
+ * Infinity Cache after the first pass, bytes >= 1 GiB measures HBM. */
+double calm_hip_membench(size_t bytes, int nt, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* CALM_HIP_TEST_H */

@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory FROM THE REFERENCE ITSELF.
+
+The reference ships no golden vectors for the decode path, so parity is pinned
+against outputs of the reference's own CPU backend: oracle/_ref/libcalm_ref.so is the untouched
+/root/reference/src/infer.c (built by `make -C oracle ref`).  This script can therefore only run
+where /root/reference exists (the build container); its outputs are committed:
+
+    <case>.calm   the synthetic model (real file format, tiny shape, seeded weights)
+    <case>.npz    tokens[T]  -- greedy token stream of the reference (teacher-forcing input)
+                  logits[T, vocab] -- the reference's logits at every step
+                  k_last / v_last  -- layer-0 KV cache rows after the last step (fp16 bits)
+    cli_tiny_fp16.txt -- stdout+stderr throughput-line hash of the reference CLI (run_cpu) on one case
+
+Usage:  python tests/golden/make_golden.py
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from calm_amd import calmfile as cf  # noqa: E402
+from calm_amd.host import HostModel  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+# name -> (spec kwargs, dtype, steps, first token)
+CASES = {
+    "tiny_fp16": (dict(), "fp16", 24),
+    "tiny_fp8": (dict(), "fp8", 24),
+    "tiny_gf4": (dict(), "gf4", 24),
+    "moe_fp8": (dict(n_experts=4, n_experts_active=2), "fp8", 24),
+    "ln_gelu_clip_fp16": (dict(norm_type="layernorm", qkv_clip=2.0, act_type="gelu"), "fp16", 24),
+    "par_fp8": (dict(norm_type="layernorm_par"), "fp8", 24),
+    "bias_tied_gf4": (dict(qkv_bias=True, tied=True), "gf4", 24),
+    # pos runs past seq_len: rolling buffer + attention-sink re-rotation (src/infer.c:329-332,383-394)
+    "sink_fp16": (dict(max_seq_len=16), "fp16", 40),
+    # ragged shapes: rows that are not a whole number of 1-KiB wave-loads, head_dim 32, kv_mul 1, odd vocab
+    "ragged_fp8": (dict(dim=96, hidden_dim=176, head_dim=32, n_heads=3, n_kv_heads=3, vocab_size=301), "fp8", 16),
+}
+FIRST_TOKEN = 5
+
+
+def main():
+    if not oracle.have_ref():
+        sys.exit("oracle/_ref/libcalm_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    for name, (kw, dtype, steps) in CASES.items():
+        spec = cf.tiny_spec(name, **kw)
+        path = os.path.join(HERE, name + ".calm")
+        cf.write_synth(path, spec, dtype, seed=1234)
+        model = HostModel.from_file(path)
+        ref = oracle.RefBackend(model)
+        toks, logits = [], []
+        tok = FIRST_TOKEN
+        for pos in range(steps):
+            lg = ref.forward(tok, pos, 0).copy()
+            toks.append(tok)
+            logits.append(lg)
+            tok = int(np.argmax(lg))
+        np.savez_compressed(
+            os.path.join(HERE, name + ".npz"),
+            tokens=np.array(toks, dtype=np.int32),
+            logits=np.stack(logits).astype(np.float32),
+            k_last=ref.kv(0, 0).view(np.uint16).copy(),
+            v_last=ref.kv(0, 1).view(np.uint16).copy(),
+        )
+        print(f"{name}: {os.path.getsize(path)} B model, {steps} steps, |logit|max {np.abs(logits[-1]).max():.3g}")
+
+    # the reference CLI end to end (tokenizer + sampler + generate loop) on one case
+    env = dict(os.environ, CALM_CPU="1", OMP_NUM_THREADS="2")
+    r = subprocess.run([oracle.RUN_CPU, os.path.join(HERE, "tiny_fp16.calm"), "-i", "abc abc", "-t", "0", "-n", "32"], env=env, capture_output=True, text=True, check=True)
+    with open(os.path.join(HERE, "cli_tiny_fp16.txt"), "w") as f:
+        f.write(r.stdout.splitlines()[1] + "\n")  # line 0 is the model banner (path dependent), line 1 the decoded text
+    print("cli:", r.stdout.splitlines()[1][:80])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,88 @@
+"""The drop-in boundary: struct layout of include/calm_abi.h and the exported C symbols."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from calm_amd import abi
+from conftest import REFERENCE, ROOT
+
+
+def test_ctypes_layout_matches_frozen_numbers():
+    assert abi.layout() == abi.FROZEN_LAYOUT
+
+
+OFFSET_PROG = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include HDR
+#define P(k, v) printf("%s %zu\n", k, (size_t)(v))
+int main(void) {
+	P("sizeof(Config)", sizeof(struct Config)); P("sizeof(Weights)", sizeof(struct Weights));
+	P("sizeof(RunState)", sizeof(struct RunState)); P("sizeof(Transformer)", sizeof(struct Transformer));
+	P("Config.qkv_clip", offsetof(struct Config, qkv_clip)); P("Config.act_gelu", offsetof(struct Config, act_gelu));
+	P("Weights.token_embedding_table", offsetof(struct Weights, token_embedding_table));
+	P("Weights.rms_final_weight", offsetof(struct Weights, rms_final_weight)); P("Weights.wcls", offsetof(struct Weights, wcls));
+	P("Weights.bqkv", offsetof(struct Weights, bqkv)); P("Weights.moegate", offsetof(struct Weights, moegate));
+	P("RunState.logits", offsetof(struct RunState, logits)); P("RunState.kvbits", offsetof(struct RunState, kvbits));
+	P("RunState.key_cache", offsetof(struct RunState, key_cache)); P("Transformer.weights", offsetof(struct Transformer, weights));
+	P("Transformer.state", offsetof(struct Transformer, state)); P("Transformer.n_params", offsetof(struct Transformer, n_params));
+	P("Transformer.n_bandwidth", offsetof(struct Transformer, n_bandwidth)); P("Transformer.forward", offsetof(struct Transformer, forward));
+	return 0;
+}
+"""
+
+
+def _offsets(header, tmp_path, tag):
+    src = tmp_path / f"off_{tag}.c"
+    src.write_text(OFFSET_PROG)
+    exe = tmp_path / f"off_{tag}"
+    subprocess.run(["gcc", f'-DHDR="{header}"', str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    return {k: int(v) for k, v in (line.rsplit(" ", 1) for line in out.splitlines())}
+
+
+def test_c_header_layout_matches_frozen_numbers(tmp_path):
+    assert _offsets(os.path.join(ROOT, "include", "calm_abi.h"), tmp_path, "ours") == abi.FROZEN_LAYOUT
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference tree not on this box")
+def test_layout_matches_reference_model_h(tmp_path):
+    """include/calm_abi.h must be byte-for-byte layout compatible with the reference's src/model.h"""
+    assert _offsets(os.path.join(REFERENCE, "src", "model.h"), tmp_path, "ref") == abi.FROZEN_LAYOUT
+
+
+def _declared_functions(header):
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b([a-z_][a-z0-9_]*)\s*\([^;{}]*\)\s*;", text))
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    """libcalm_hip.so loads (no GPU needed) and exports everything include/*.h declares"""
+    from calm_amd.host import EXPORTS
+
+    declared = _declared_functions(os.path.join(ROOT, "include", "calm_hip.h")) | _declared_functions(os.path.join(ROOT, "include", "calm_hip_test.h"))
+    declared.discard("forward")  # the function-pointer member of struct Transformer
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(hiplib, name), f"libcalm_hip.so does not export {name}"
+    assert declared == set(EXPORTS), (declared ^ set(EXPORTS))
+
+
+def test_device_count_is_safe_without_gpu(hiplib):
+    assert hiplib.calm_hip_device_count() >= 0
+
+
+def test_product_never_touches_the_oracle():
+    """no file under calm_amd/ may import, link or dlopen anything from oracle/"""
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "calm_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|liboracle|libcalm_ref|oracle/", txt) and f != "build.py":
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad

@@ -1,0 +1,57 @@
+"""Host-side logic: config parsing, the generate loop and its accounting (no GPU)."""
+import numpy as np
+
+from calm_amd import abi
+from calm_amd import calmfile as cf
+from calm_amd.host import HostModel, argmax_first, generate
+from conftest import load_golden
+from oracle import oracle
+
+
+def test_config_defaults_and_caps():
+    t, md = cf.synth_model(cf.tiny_spec(max_seq_len=8192), "fp16")
+    m = HostModel(t, md)
+    assert m.config.seq_len == 4096  # src/run.c:41-43 caps the context unless -c is given
+    assert HostModel(t, md, context=512).config.seq_len == 512
+    assert m.config.qkv_clip == np.finfo(np.float32).max and not m.config.norm_ln and not m.config.act_gelu
+    t, md = cf.synth_model(cf.tiny_spec(norm_type="layernorm_par", act_type="gelu", qkv_clip=8.0), "fp8")
+    m = HostModel(t, md)
+    assert m.config.norm_ln and m.config.norm_par and m.config.act_gelu and m.config.qkv_clip == 8.0
+
+
+def test_fill_transformer_tied_and_optional_tensors():
+    t, md = cf.synth_model(cf.tiny_spec(tied=True, qkv_bias=True), "fp8")
+    m = HostModel(t, md)
+    tr = abi.Transformer()
+    addrs = {n: i + 1 for i, n in enumerate(t)}
+    m.fill_transformer(tr, lambda n: addrs[n])
+    assert tr.weights.wcls == tr.weights.token_embedding_table == addrs["model.embed.weight"]
+    assert tr.weights.bqkv[1] == addrs["model.layers.1.attn.wqkv.bias"] and not tr.weights.moegate[0]
+    assert tr.weights.dbits == 8 and tr.state.kvbits == 16
+
+
+def test_generate_loop_matches_reference_token_stream():
+    """generate() over the oracle backend reproduces the reference's greedy stream (golden tokens)"""
+    model, z = load_golden("tiny_fp8")
+    o = oracle.OracleBackend(model)
+    steps = len(z["tokens"])
+    out, stats = generate(o, model, [int(z["tokens"][0])], steps)
+    assert out[:-1] == [int(t) for t in z["tokens"][1:]]
+    _, _, n_bw = model.accounting()
+    assert stats["tokens"] == steps
+    assert stats["read_bytes"] == steps * n_bw + sum(model.kv_bandwidth(16, p) for p in range(steps))
+
+
+def test_generate_prompt_positions_are_kv_only():
+    calls = []
+
+    class Fake:
+        def forward(self, token, pos, flags):
+            calls.append((token, pos, flags))
+            return None if flags else np.array([0.0, 2.0, 1.0], dtype=np.float32)
+
+    model, _ = load_golden("tiny_fp8")
+    out, _ = generate(Fake(), model, [7, 8, 9], 5)
+    assert calls == [(7, 0, 1), (8, 1, 1), (9, 2, 0), (1, 3, 0), (1, 4, 0)]
+    assert out == [8, 9, 1, 1, 1]
+    assert argmax_first(np.array([1.0, 5.0, 5.0])) == 1
