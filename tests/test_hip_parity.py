@@ -1,0 +1,280 @@
+"""Parity of the HIP path against the oracle -- the GPU tests proper.  Everything goes through the
+C ABI of libcalm_hip.so (ctypes); the oracle (oracle/) is only the checker.
+
+Tolerances (stated once, used everywhere):
+  KERNEL_TOL 2e-5  single kernels: fp32 tree sums vs the oracle's sequential fp32 sums
+  LOGIT_TOL  1e-3  whole decode steps, max|delta| / max|logit| per token -- the north-star bound for
+                   fp16; fp8 and gf4 decode exactly and activations stay fp32, so the same bound is
+                   the stated tolerance for them too
+Integer / index results (argmax, routed experts, greedy token streams) must be identical.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from calm_amd import abi
+from calm_amd import calmfile as cf
+from calm_amd.host import HipBackend, HostModel, argmax_first, fptr, generate
+from conftest import GOLDEN_CASES, load_golden, rel_err
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+KERNEL_TOL = 2e-5
+LOGIT_TOL = 1e-3
+
+
+def _rand_w(rng, d, n, dtype, sigma=None):
+    w = (rng.standard_normal((d, n)).astype(np.float32) * (sigma or n ** -0.5)).astype(np.float16).astype(np.float32)
+    return np.ascontiguousarray(cf.quantize(w, dtype))
+
+
+# ---------------------------------------------------------------- single kernels ---------------
+
+def test_fp8_decode_is_exact_for_all_256_codes(hiplib):
+    """row i holds code i in column 0: W . e0 returns every code's decoded value"""
+    w = np.zeros((256, 16), dtype=np.uint8)
+    w[:, 0] = np.arange(256)
+    x = np.zeros(16, dtype=np.float32)
+    x[0] = 1.0
+    out = np.empty(256, dtype=np.float32)
+    hiplib.calm_hip_test_matvec(8, w.ctypes.data, fptr(x), fptr(out), 16, 256)
+    ref = cf.fp8_e5m2_to_f32(np.arange(256, dtype=np.uint8))
+    finite = np.isfinite(ref)
+    assert np.array_equal(out[finite], ref[finite])
+    assert np.array_equal(np.isnan(out), np.isnan(ref)) and np.array_equal(out[np.isinf(ref)], ref[np.isinf(ref)])
+
+
+def test_gf4_and_fp16_decode_exact(hiplib):
+    rng = np.random.default_rng(0)
+    words = rng.integers(0, 2**32, size=(64, 4), dtype=np.uint64).astype(np.uint32)
+    words = (words & 0xFFFFFF7F) | 0x30  # keep scales finite and moderate
+    dec = cf.gf4_to_f32(words.view(np.int32))  # (64, 32)
+    halves = rng.integers(0, 2**16, size=(64, 32), dtype=np.uint64).astype(np.uint16)
+    halves[(halves & 0x7C00) == 0x7C00] = 0x3C00
+    for k in range(32):
+        x = np.zeros(32, dtype=np.float32)
+        x[k] = 1.0
+        out = np.empty(64, dtype=np.float32)
+        hiplib.calm_hip_test_matvec(4, words.ctypes.data, fptr(x), fptr(out), 32, 64)
+        assert np.array_equal(out, dec[:, k]), k
+        hiplib.calm_hip_test_matvec(16, halves.ctypes.data, fptr(x), fptr(out), 32, 64)
+        assert np.array_equal(out, halves.view(np.float16)[:, k].astype(np.float32)), k
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp8", "gf4"])
+@pytest.mark.parametrize("n,d", [(32, 4), (96, 12), (176, 64), (2048, 256), (4096, 512), (5632, 64), (14336, 32), (6144, 48)])
+def test_matvec_matches_oracle(hiplib, dtype, n, d):
+    if n % (128 // cf.DBITS[dtype]):
+        pytest.skip("row not a whole number of 16-byte pieces for this format")
+    rng = np.random.default_rng(n * 7 + d)
+    w = _rand_w(rng, d, n, dtype)
+    x = rng.standard_normal(n).astype(np.float32)
+    out = np.empty(d, dtype=np.float32)
+    hiplib.calm_hip_test_matvec(cf.DBITS[dtype], w.ctypes.data, fptr(x), fptr(out), n, d)
+    ref = oracle.matvec(w, x, cf.DBITS[dtype], n, d)
+    assert rel_err(out, ref) < KERNEL_TOL
+
+
+def test_matvec_is_linear_at_full_size(hiplib):
+    """size-independent property at the BASELINE width: W.(2^k x) == 2^k (W.x) bit for bit"""
+    rng = np.random.default_rng(1)
+    w = _rand_w(rng, 256, 14336, "fp8")
+    x = rng.standard_normal(14336).astype(np.float32)
+    a, b = np.empty(256, dtype=np.float32), np.empty(256, dtype=np.float32)
+    hiplib.calm_hip_test_matvec(8, w.ctypes.data, fptr(x), fptr(a), 14336, 256)
+    x8 = x * np.float32(8)
+    hiplib.calm_hip_test_matvec(8, w.ctypes.data, fptr(x8), fptr(b), 14336, 256)
+    assert np.array_equal(a * np.float32(8), b)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp8", "gf4"])
+@pytest.mark.parametrize("ln", [0, 1])
+@pytest.mark.parametrize("n,d", [(96, 301), (4096, 1000), (6144, 130)])
+def test_norm_matvec_matches_oracle(hiplib, dtype, ln, n, d):
+    if n % (128 // cf.DBITS[dtype]):
+        pytest.skip("row granularity")
+    rng = np.random.default_rng(n + d + ln)
+    w = _rand_w(rng, d, n, dtype)
+    x = (rng.standard_normal(n) * 3 + (0.7 if ln else 0)).astype(np.float32)
+    nw = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+    out = np.empty(d, dtype=np.float32)
+    hiplib.calm_hip_test_norm_matvec(cf.DBITS[dtype], w.ctypes.data, fptr(x), fptr(nw), fptr(out), n, d, 1e-5, ln)
+    ref = oracle.matvec(w, oracle.norm(x, nw, 1e-5, bool(ln)), cf.DBITS[dtype], n, d)
+    assert rel_err(out, ref) < KERNEL_TOL
+
+
+@pytest.mark.parametrize("n_heads,n_kv,head_dim", [(4, 2, 16), (3, 3, 32), (32, 4, 64), (32, 8, 128), (6, 1, 96), (8, 8, 256)])
+@pytest.mark.parametrize("kv_len,n_split", [(1, 1), (7, 1), (256, 1), (1000, 1), (1000, 4), (37, 5)])
+def test_attention_matches_oracle(hiplib, n_heads, n_kv, head_dim, kv_len, n_split):
+    rng = np.random.default_rng(n_heads * 1000 + head_dim + kv_len)
+    seq_len = max(kv_len, 8)
+    kv_dim = n_kv * head_dim
+    q = rng.standard_normal(n_heads * head_dim).astype(np.float32)
+    k = (rng.standard_normal((seq_len, kv_dim)) * 0.7).astype(np.float16)
+    v = rng.standard_normal((seq_len, kv_dim)).astype(np.float16)
+    out = np.empty(n_heads * head_dim, dtype=np.float32)
+    hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
+    ref = oracle.attention(q, k, v, n_heads, n_kv, head_dim, kv_len)
+    assert rel_err(out, ref) < KERNEL_TOL
+
+
+def test_attention_softmax_is_stable_for_huge_scores(hiplib):
+    """scores of +-1e4: the reference subtracts the max (src/infer.c:252-257); so must we"""
+    rng = np.random.default_rng(3)
+    q = (rng.standard_normal(4 * 64) * 100).astype(np.float32)
+    k = (rng.standard_normal((64, 2 * 64)) * 100).astype(np.float16)
+    v = rng.standard_normal((64, 2 * 64)).astype(np.float16)
+    out = np.empty(4 * 64, dtype=np.float32)
+    hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out), 4, 2, 64, 64, 64, 1)
+    ref = oracle.attention(q, k, v, 4, 2, 64, 64)
+    assert np.isfinite(out).all() and rel_err(out, ref) < 1e-4
+
+
+def test_device_argmax_is_first_strict_maximum(hiplib):
+    rng = np.random.default_rng(4)
+    for n in (5, 1024, 32000, 128256):
+        lg = rng.standard_normal(n).astype(np.float32)
+        assert hiplib.calm_hip_test_argmax(fptr(lg), n) == oracle.argmax(lg) == int(np.argmax(lg))
+        j = int(rng.integers(0, n))
+        lg[j] = lg.max()  # an exact tie: the lower index wins
+        assert hiplib.calm_hip_test_argmax(fptr(lg), n) == oracle.argmax(lg)
+    lg = np.array([np.nan, -3.0, np.nan, -3.0], dtype=np.float32)
+    assert hiplib.calm_hip_test_argmax(fptr(lg), 4) == oracle.argmax(lg) == 1
+
+
+# ---------------------------------------------------------------- whole decode steps ------------
+
+@pytest.mark.parametrize("graph", [1, 0])
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_golden_logits_teacher_forced(hiplib, case, graph):
+    """the reference's own logits (tests/golden, from src/infer.c) reproduced by forward_hip"""
+    model, z = load_golden(case)
+    hiplib.calm_hip_configure(b"graph", graph)
+    b = HipBackend(model)
+    try:
+        worst = 0.0
+        for pos, tok in enumerate(z["tokens"]):
+            lg = b.forward(int(tok), pos, 0)
+            ref = z["logits"][pos]
+            worst = max(worst, rel_err(lg, ref))
+            top2 = np.partition(ref, -2)[-2:]
+            if top2[1] - top2[0] > 4 * LOGIT_TOL * np.abs(ref).max():
+                assert argmax_first(lg) == int(np.argmax(ref)), pos
+        assert worst < LOGIT_TOL, worst
+        # the KV cache the steps left behind (layer 0), against the reference's cache
+        k = b.read_kv(0, 0).astype(np.float32)
+        v = b.read_kv(0, 1).astype(np.float32)
+        kg = z["k_last"].view(np.float16).astype(np.float32)
+        vg = z["v_last"].view(np.float16).astype(np.float32)
+        assert np.abs(k - kg).max() <= 2e-3 * max(np.abs(kg).max(), 1.0)
+        assert np.abs(v - vg).max() <= 2e-3 * max(np.abs(vg).max(), 1.0)
+    finally:
+        b.close()
+        hiplib.calm_hip_configure(b"graph", 1)
+
+
+@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4"])
+def test_greedy_stream_identical_and_device_decode_agrees(hiplib, case):
+    """free-running greedy decode: forward_hip + host argmax, generate(), and the device-side
+    decode_greedy_hip all produce the reference's token stream"""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    b = HipBackend(model)
+    try:
+        out, stats = generate(b, model, [toks[0]], len(toks))
+        assert out[:-1] == toks[1:]
+        dev, last_logits = b.decode_greedy(toks[0], 0, len(toks))
+        assert list(dev[:-1]) == toks[1:]
+        assert rel_err(last_logits, z["logits"][-1]) < LOGIT_TOL
+    finally:
+        b.close()
+
+
+def test_kv_only_prompt_steps_then_logits(hiplib):
+    model, z = load_golden("tiny_fp16")
+    toks = [int(t) for t in z["tokens"]]
+    b = HipBackend(model)
+    try:
+        for pos, tok in enumerate(toks[:10]):
+            assert b.forward(tok, pos, abi.FF_UPDATE_KV_ONLY) is None
+        lg = b.forward(toks[10], 10, 0)
+        assert rel_err(lg, z["logits"][10]) < LOGIT_TOL
+        # positions may go backwards (perplexity mode resets pos, src/run.c:296): replay from 0
+        for pos, tok in enumerate(toks[:5]):
+            lg = b.forward(tok, pos, 0)
+        assert rel_err(lg, z["logits"][4]) < LOGIT_TOL
+    finally:
+        b.close()
+
+
+def test_logits_buffer_is_host_writable_and_steps_are_deterministic(hiplib):
+    model, z = load_golden("tiny_fp8")
+    b = HipBackend(model)
+    try:
+        a1 = b.forward(5, 0, 0).copy()
+        lg = b.forward(5, 0, 0)
+        lg[:] = 0  # the sampler overwrites logits in place (src/sampler.c:55)
+        a2 = b.forward(5, 0, 0).copy()
+        assert np.array_equal(a1, a2)
+    finally:
+        b.close()
+
+
+def test_attention_split_path_inside_forward(hiplib):
+    """force the split-KV attention (+ merge kernel) inside whole steps and compare with unsplit"""
+    model, z = load_golden("tiny_fp16")
+    toks = [int(t) for t in z["tokens"]]
+    old = hiplib.calm_hip_configure(b"split_t", 4)
+    b = HipBackend(model)
+    try:
+        for pos, tok in enumerate(toks):
+            lg = b.forward(tok, pos, 0)
+            assert rel_err(lg, z["logits"][pos]) < LOGIT_TOL
+    finally:
+        b.close()
+        hiplib.calm_hip_configure(b"split_t", old)
+
+
+@pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 1), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1), ("dbrx-132b", "fp8", 1)])
+def test_full_width_layer_reduced_models_match_oracle(hiplib, name, dtype, layers):
+    """BASELINE.json shapes at full width and vocabulary, depth cut so the CPU oracle takes seconds"""
+    spec = cf.SPECS[name]
+    tensors, md = cf.synth_model_big(spec, dtype, seed=3, n_layers=layers)
+    model = HostModel(tensors, md, context=64)
+    o = oracle.OracleBackend(model)
+    b = HipBackend(model)
+    try:
+        tok = 11
+        for pos in range(6):
+            lo = o.forward(tok, pos, 0)
+            lg = b.forward(tok, pos, 0)
+            assert rel_err(lg, lo) < LOGIT_TOL, (pos, rel_err(lg, lo))
+            tok = oracle.argmax(lo)
+    finally:
+        b.close()
+        o.close()
+
+
+def test_mistral7b_full_depth_properties(hiplib):
+    """BASELINE config 2 at full size (32 layers, 7.1 GB fp8, streamed to the GPU): size-independent
+    properties -- bitwise determinism, graph == eager, device decode == host-sampled decode,
+    pos-rewind idempotence -- plus the reference accounting of the bytes one step reads"""
+    spec = cf.SPECS["mistral-7b"]
+    model = HostModel(cf.stub_tensors(spec, "fp8"), spec.metadata("fp8"))
+    assert model.accounting()[2] == 7_111_458_816
+    b = HipBackend(model, stream=cf.synth_stream_big(spec, "fp8", seed=5))
+    try:
+        toks, _ = generate(b, model, [17], 24)
+        ref_last = b.forward(toks[-2], 23, 0).copy()
+        dev, last = b.decode_greedy(17, 0, 24)
+        assert list(dev) == toks
+        assert np.array_equal(last, ref_last)
+        hiplib.calm_hip_configure(b"graph", 0)
+        toks_eager, _ = generate(b, model, [17], 24)
+        hiplib.calm_hip_configure(b"graph", 1)
+        assert toks_eager == toks
+        assert np.isfinite(ref_last).all() and np.abs(ref_last).max() < 1e4
+    finally:
+        b.close()

@@ -1,0 +1,38 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, profiles.  Everything lands in gpurun_out/.
+# usage: tools/gpu_round.sh [tag]
+TAG=${1:-r01}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+echo "== device" | tee $OUT/summary.txt
+(rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; free -g | head -2) >> $OUT/summary.txt 2>&1
+
+echo "== kernel + tiny-model parity tests" | tee -a $OUT/summary.txt
+timeout 900 python -m pytest tests -m gpu -q -x --deselect tests/test_hip_parity.py::test_mistral7b_full_depth_properties \
+    -k "not full_width" > $OUT/pytest_small.log 2>&1
+echo "exit $?" >> $OUT/summary.txt; tail -15 $OUT/pytest_small.log >> $OUT/summary.txt
+
+echo "== smoke" | tee -a $OUT/summary.txt
+timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "exit $?" >> $OUT/summary.txt; tail -3 $OUT/smoke.log >> $OUT/summary.txt
+
+echo "== full-width / full-depth parity tests" | tee -a $OUT/summary.txt
+timeout 1200 python -m pytest tests -m gpu -q -k "full_width or full_depth" > $OUT/pytest_big.log 2>&1
+echo "exit $?" >> $OUT/summary.txt; tail -15 $OUT/pytest_big.log >> $OUT/summary.txt
+
+echo "== bench" | tee -a $OUT/summary.txt
+timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
+tail -c 3000 $OUT/bench.json >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.txt
+
+echo "== membench" | tee -a $OUT/summary.txt
+timeout 300 python tools/membench.py > $OUT/membench.txt 2>&1; cat $OUT/membench.txt >> $OUT/summary.txt
+
+echo "== rocprof kernel trace of the bench command" | tee -a $OUT/summary.txt
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --no-cpu --steps 64 --warmup 8 > $OUT/prof_bench.log 2>&1
+echo "exit $?" >> $OUT/summary.txt
+find $OUT/prof -name "*stats*" | head >> $OUT/summary.txt
+for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f >> $OUT/summary.txt; cp $f $OUT/kernel_stats.csv; done
+# the raw trace is large: keep only the stats
+find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
+cat $OUT/summary.txt
