@@ -10,7 +10,7 @@ echo "== device" | tee $OUT/summary.txt
 (rocminfo | grep -E "Marketing Name|gfx" | head -4; nproc; free -g | head -2) >> $OUT/summary.txt 2>&1
 
 echo "== kernel + tiny-model parity tests" | tee -a $OUT/summary.txt
-timeout 900 python -m pytest tests -m gpu -q -x --deselect tests/test_hip_parity.py::test_mistral7b_full_depth_properties \
+timeout 900 python -m pytest tests -m gpu -q --deselect tests/test_hip_parity.py::test_mistral7b_full_depth_properties \
     -k "not full_width" > $OUT/pytest_small.log 2>&1
 echo "exit $?" >> $OUT/summary.txt; tail -15 $OUT/pytest_small.log >> $OUT/summary.txt
 
