@@ -123,12 +123,10 @@ def main():
     toks, stats = generate(be, model, [first_token], args.steps)  # ends synchronised: forward_hip returned logits
     elapsed = time.perf_counter() - t0
     barrier()
-    if dist is not None:
-        import torch
+    from calm_amd.replicas import aggregate_throughput
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    agg = aggregate_throughput(dist, args.steps, elapsed)
+    elapsed = agg["elapsed"]
 
     if rank != 0:
         be.close()
@@ -137,7 +135,7 @@ def main():
         return
 
     n_params, n_bytes, n_bw = model.accounting()
-    tok_s = world * args.steps / elapsed
+    tok_s = agg["value"]
     step_bytes = stats["read_bytes"] / args.steps  # reference accounting: n_bandwidth + KV bytes (src/run.c:211-212)
     achieved = step_bytes * args.steps / elapsed / 1e9  # per GPU
 

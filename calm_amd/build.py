@@ -1,6 +1,6 @@
 """Build recipes (explicit hipcc / gcc invocations, in-tree outputs).
 
-    python -m calm_amd.build            # libcalm_hip.so (+ calm_hip_run CLI)
+    python -m calm_amd.build            # libcalm_hip.so
     python -m calm_amd.build --all      # + the oracle checker and, when /root/reference exists, oracle/_ref
 
 The product is calm_amd/libcalm_hip.so: hand-written HIP for gfx950 behind the C ABI of
@@ -16,7 +16,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "calm_amd", "csrc")
 LIB_HIP = os.path.join(ROOT, "calm_amd", "libcalm_hip.so")
-RUN_HIP = os.path.join(ROOT, "calm_amd", "calm_hip_run")
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REFERENCE = os.environ.get("CALM_REFERENCE", "/root/reference")
 
@@ -46,9 +45,6 @@ def build_hip(force: bool = False) -> str:
     srcs = hip_sources()
     if force or not _newer(LIB_HIP, srcs):
         _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP, os.path.join(CSRC, "infer_hip.hip")])
-    host_src = os.path.join(CSRC, "run_hip.cpp")
-    if os.path.exists(host_src) and (force or not _newer(RUN_HIP, srcs + [LIB_HIP])):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-o", RUN_HIP, host_src, LIB_HIP, "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"])
     return LIB_HIP
 
 

@@ -278,3 +278,19 @@ def test_mistral7b_full_depth_properties(hiplib):
         assert np.isfinite(ref_last).all() and np.abs(ref_last).max() < 1e4
     finally:
         b.close()
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip (reference CLI linked to libcalm_hip.so) not built")
+def test_reference_cli_runs_on_the_hip_backend():
+    """the drop-in proof: the reference's UNMODIFIED run.c, bound to libcalm_hip.so by renaming its four
+    cuda externs, decodes the same text on the GPU as on its own CPU backend"""
+    import subprocess
+
+    from conftest import GOLDEN
+
+    env = dict(os.environ)
+    env.pop("CALM_CPU", None)
+    r = subprocess.run([oracle.RUN_HIP, os.path.join(GOLDEN, "tiny_fp16.calm"), "-i", "abc abc", "-t", "0", "-n", "32"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.splitlines()[1] + "\n" == open(os.path.join(GOLDEN, "cli_tiny_fp16.txt")).read()
+    assert "tok/s" in r.stderr
