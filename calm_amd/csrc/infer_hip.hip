@@ -50,7 +50,7 @@ constexpr int MAX_SPLIT = 64;
 hipStream_t g_stream;
 int g_device = -1;
 int g_ncu = 256;
-int g_bpc = 4;       // cap on resident 256-thread workgroups per CU when sizing grids
+int g_bpc = 3;       // cap on resident 256-thread workgroups per CU when sizing grids
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 1024; // kv positions per attention split
@@ -61,10 +61,19 @@ int env_int(const char* name, int dflt) {
 	return v && *v ? atoi(v) : dflt;
 }
 
+// Kernels issue unconditional, unclamped 16-byte loads that may run past the end of a row / vector
+// (kernels.hip.h: stage_load, tile_load); every device buffer carries this much slack behind it.
+constexpr size_t DEV_PAD = 64 * 1024;
+
 void* dev_alloc(size_t size) {
 	void* p = nullptr;
-	HIP_CHECK(hipMalloc(&p, size ? size : 16));
+	HIP_CHECK(hipMalloc(&p, size + DEV_PAD));
 	return p;
+}
+
+// float4 registers per thread the staging prologue needs for an n-float vector at `block` threads
+inline bool stage_v4(int n, int block) {
+	return n <= 4 * 4 * block;
 }
 
 struct StageProf {
@@ -192,7 +201,11 @@ void launch_qkv(Ctx* c, int l) {
 	a.dim = c->dim, a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len;
 	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
 	int ntasks = (c->q_dim + 2 * c->kv_dim) / Shape<DB>::NR;
-	hipLaunchKernelGGL((k_qkv<DB, KVB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+	if (stage_v4(c->dim, 256)) {
+		hipLaunchKernelGGL((k_qkv<DB, KVB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+	} else {
+		hipLaunchKernelGGL((k_qkv<DB, KVB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+	}
 }
 
 template <int KVB, int LPR>
@@ -205,7 +218,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.partial = c->partial;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
-	hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads * n_split), dim3(256), 0, g_stream, a);
+	hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads * n_split), dim3(ATTN_BLOCK), 0, g_stream, a);
 	if (n_split > 1) {
 		hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
 	}
@@ -232,8 +245,13 @@ void launch_attn(Ctx* c, int l, int n_split) {
 template <int DB>
 void launch_attn_out(Ctx* c, int l) {
 	int ntasks = c->dim / Shape<DB>::NR;
-	hipLaunchKernelGGL((k_attn_out<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->q_dim), g_stream, c->x, c->att, c->t->weights.wo[l], c->dim,
-	                   c->q_dim);
+	if (stage_v4(c->q_dim, 256)) {
+		hipLaunchKernelGGL((k_attn_out<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->q_dim), g_stream, c->x, c->att, c->t->weights.wo[l],
+		                   c->dim, c->q_dim);
+	} else {
+		hipLaunchKernelGGL((k_attn_out<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->q_dim), g_stream, c->x, c->att, c->t->weights.wo[l],
+		                   c->dim, c->q_dim);
+	}
 }
 
 template <int DB>
@@ -249,23 +267,37 @@ void launch_ffn_up(Ctx* c, int l) {
 	a.eps = p->norm_eps, a.ln = p->norm_ln, a.gelu = p->act_gelu;
 	int nact = c->n_active > 0 ? c->n_active : 1;
 	int ntasks = nact * (c->hidden / (Shape<DB>::NR / 2));
-	hipLaunchKernelGGL((k_ffn_up<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+	if (stage_v4(c->dim, 256)) {
+		hipLaunchKernelGGL((k_ffn_up<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+	} else {
+		hipLaunchKernelGGL((k_ffn_up<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
+	}
 }
 
 template <int DB>
 void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
 	int ntasks = c->dim / Shape<DB>::NR;
-	hipLaunchKernelGGL((k_ffn_down<DB, BLOCK>), dim3(pick_blocks(ntasks, BLOCK / 64)), dim3(BLOCK), lds_bytes<DB>(c->hidden), g_stream, c->x, c->he,
-	                   c->t->weights.w2[l], c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+	if (stage_v4(c->hidden, BLOCK)) {
+		hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, 4>), dim3(pick_blocks(ntasks, BLOCK / 64)), dim3(BLOCK), lds_bytes<DB>(c->hidden), g_stream, c->x, c->he,
+		                   c->t->weights.w2[l], c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+	} else {
+		hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, 8>), dim3(pick_blocks(ntasks, BLOCK / 64)), dim3(BLOCK), lds_bytes<DB>(c->hidden), g_stream, c->x, c->he,
+		                   c->t->weights.w2[l], c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+	}
 }
 
 template <int DB>
 void launch_output(Ctx* c) {
 	struct Config* p = &c->t->config;
 	int ntasks = (c->vocab + Shape<DB>::NR - 1) / Shape<DB>::NR;
-	hipLaunchKernelGGL((k_output<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
-	                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
+	if (stage_v4(c->dim, 256)) {
+		hipLaunchKernelGGL((k_output<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, c->logits_d, c->x,
+		                   c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
+	} else {
+		hipLaunchKernelGGL((k_output<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, c->logits_d, c->x,
+		                   c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
+	}
 }
 
 void launch_argmax(Ctx* c) {
@@ -450,12 +482,18 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp) {
 
 template <int DB>
 void set_lds_attrs(Ctx* c) {
-	allow_lds(k_qkv<DB, 16>, lds_bytes<DB>(c->dim));
-	allow_lds(k_qkv<DB, 8>, lds_bytes<DB>(c->dim));
-	allow_lds(k_attn_out<DB>, lds_bytes<DB>(c->q_dim));
-	allow_lds(k_ffn_up<DB>, lds_bytes<DB>(c->dim));
-	allow_lds(k_ffn_down<DB, 512>, lds_bytes<DB>(c->hidden));
-	allow_lds(k_output<DB>, lds_bytes<DB>(c->dim));
+	allow_lds(k_qkv<DB, 16, 4>, lds_bytes<DB>(c->dim));
+	allow_lds(k_qkv<DB, 16, 8>, lds_bytes<DB>(c->dim));
+	allow_lds(k_qkv<DB, 8, 4>, lds_bytes<DB>(c->dim));
+	allow_lds(k_qkv<DB, 8, 8>, lds_bytes<DB>(c->dim));
+	allow_lds(k_attn_out<DB, 4>, lds_bytes<DB>(c->q_dim));
+	allow_lds(k_attn_out<DB, 8>, lds_bytes<DB>(c->q_dim));
+	allow_lds(k_ffn_up<DB, 4>, lds_bytes<DB>(c->dim));
+	allow_lds(k_ffn_up<DB, 8>, lds_bytes<DB>(c->dim));
+	allow_lds(k_ffn_down<DB, 512, 4>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_ffn_down<DB, 512, 8>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_output<DB, 4>, lds_bytes<DB>(c->dim));
+	allow_lds(k_output<DB, 8>, lds_bytes<DB>(c->dim));
 }
 
 } // namespace
@@ -514,7 +552,7 @@ extern "C" void init_hip(void) {
 	hipDeviceProp_t prop;
 	HIP_CHECK(hipGetDeviceProperties(&prop, dev));
 	g_ncu = prop.multiProcessorCount;
-	snprintf(g_devname, sizeof(g_devname), "%s", prop.name);
+	snprintf(g_devname, sizeof(g_devname), "%s", prop.name[0] ? prop.name : prop.gcnArchName);
 	HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
 	g_device = dev;
 	g_bpc = env_int("CALM_HIP_BPC", g_bpc);
@@ -839,8 +877,13 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 	HIP_CHECK(hipMemset(dout, 0, d * sizeof(float)));
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		allow_lds(k_attn_out<DB>, lds_bytes<DB>(n));
-		hipLaunchKernelGGL((k_attn_out<DB>), dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+		if (stage_v4(n, 256)) {
+			allow_lds(k_attn_out<DB, 4>, lds_bytes<DB>(n));
+			hipLaunchKernelGGL((k_attn_out<DB, 4>), dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+		} else {
+			allow_lds(k_attn_out<DB, 8>, lds_bytes<DB>(n));
+			hipLaunchKernelGGL((k_attn_out<DB, 8>), dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+		}
 	});
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, dout, d * sizeof(float));
@@ -857,9 +900,14 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 	float* dout = (float*)dev_alloc(d * sizeof(float));
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		allow_lds(k_output<DB>, lds_bytes<DB>(n));
 		int ntasks = (d + Shape<DB>::NR - 1) / Shape<DB>::NR;
-		hipLaunchKernelGGL((k_output<DB>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+		if (stage_v4(n, 256)) {
+			allow_lds(k_output<DB, 4>, lds_bytes<DB>(n));
+			hipLaunchKernelGGL((k_output<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+		} else {
+			allow_lds(k_output<DB, 8>, lds_bytes<DB>(n));
+			hipLaunchKernelGGL((k_output<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+		}
 	});
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, dout, d * sizeof(float));

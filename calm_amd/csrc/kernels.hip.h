@@ -21,12 +21,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace calm {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// explicit global address space: a pointer selected between two provenances (weights / dummy) would
+// otherwise degrade to FLAT loads, which tick lgkmcnt as well as vmcnt and serialise against LDS
+typedef const __attribute__((address_space(1))) u32x4* gptr16;
 
 // per-token scalars, written by k_begin_token, read by every other kernel
 struct TokState {
@@ -53,12 +58,27 @@ __device__ __forceinline__ int wave_id() {
 	return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		v += __shfl_xor(v, o);
-	}
+// Sum over the 64 lanes with DPP row operations (VALU only; no LDS crossbar round trips):
+// quad swaps, row_shr:4, row_shr:8 leave each 16-lane row's total in its lanes 12..15, row_bcast:15
+// and row_bcast:31 carry the totals across rows.  The full sum is valid in LANE 63 only.
+constexpr int RED_LANE = 63;
+__device__ __forceinline__ float wave_sum63(float v) {
+	auto dpp = [](float x, auto ctrl, auto row_mask) {
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true));
+	};
+	using I = std::integral_constant<int, 0>;
+	(void)sizeof(I);
+	v += dpp(v, std::integral_constant<int, 0xb1>(), std::integral_constant<int, 0xf>());  // quad_perm [1,0,3,2]
+	v += dpp(v, std::integral_constant<int, 0x4e>(), std::integral_constant<int, 0xf>());  // quad_perm [2,3,0,1]
+	v += dpp(v, std::integral_constant<int, 0x114>(), std::integral_constant<int, 0xf>()); // row_shr:4
+	v += dpp(v, std::integral_constant<int, 0x118>(), std::integral_constant<int, 0xf>()); // row_shr:8
+	v += dpp(v, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>()); // row_bcast:15 into rows 1,3
+	v += dpp(v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>()); // row_bcast:31 into rows 2,3
 	return v;
+}
+// same, broadcast to every lane (one v_readlane)
+__device__ __forceinline__ float wave_sum(float v) {
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum63(v)), RED_LANE));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -184,27 +204,44 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 	return s;
 }
 
-// Stage src[0..n) into the swizzled image xs4, optionally normalised:
-//   normw == nullptr : plain copy
-//   else             : (x - mean) * rsqrt(var + eps) * normw, mean = 0 unless ln   (src/infer.c:183-207)
+// Staging an n-float vector into the swizzled image happens in two halves so that a kernel can issue
+// the vector's global loads BEFORE its first weight tile (vmcnt retires in order: the prologue must
+// not have to wait for the weight loads queued behind it) and finish after:
+//   stage_load   : issue the loads of src into V float4 registers per thread
+//   stage_finish : normalise (optional), write the LDS image, barrier
+//     normw == nullptr : plain copy
+//     else             : (x - mean) * rsqrt(var + eps) * normw, mean = 0 unless ln   (src/infer.c:183-207)
 // If dump != nullptr, block 0 also writes the staged (unswizzled) vector there (norm_par models
 // need the attention-norm output again in the FFN, src/infer.c:417-420).
-// Ends with a __syncthreads(): the image is readable on return.
-template <int DB, int BLOCK>
-__device__ __forceinline__ void stage_x(float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
-                                        int n, float eps, bool ln, float* dump) {
-	constexpr int MAXV = 8;
+// Every load is UNCONDITIONAL and unclamped -- it may read up to 4*V*BLOCK floats regardless of n;
+// the surplus is masked where it is used.  (A load behind a branch makes the number of outstanding
+// loads unknowable to the compiler, which then waits with vmcnt(0), i.e. for the weight tile too;
+// a clamped index costs a 64-bit address per load.)  Every device buffer is therefore allocated
+// with DEV_PAD bytes of slack (infer_hip.hip).  Vectors longer than 4*V*BLOCK floats fall back to
+// re-reading global memory for the excess.
+template <int V>
+struct StageRegs {
+	float4 v[V];
+};
+
+template <int BLOCK, int V>
+__device__ __forceinline__ void stage_load(StageRegs<V>& sr, const float* __restrict__ src) {
+	const float4* src4 = (const float4*)src + threadIdx.x;
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		sr.v[i] = src4[i * BLOCK];
+	}
+}
+
+template <int DB, int BLOCK, int V>
+__device__ __forceinline__ void stage_finish(const StageRegs<V>& sr, float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
+                                             int n, float eps, bool ln, float* dump) {
+	constexpr int MAXV = V;
 	const int tid = threadIdx.x;
 	const int n4 = n >> 2;
 	const int slots = xs_slots<DB>(n);
 	const float4* src4 = (const float4*)src;
-
-	float4 v[MAXV];
-#pragma unroll
-	for (int i = 0; i < MAXV; ++i) {
-		int p = tid + i * BLOCK;
-		v[i] = p < n4 ? src4[p] : make_float4(0.f, 0.f, 0.f, 0.f);
-	}
+	const float4(&v)[MAXV] = sr.v;
 
 	float mean = 0.f, scale = 1.f;
 	if (normw) {
@@ -212,7 +249,9 @@ __device__ __forceinline__ void stage_x(float4* xs4, float* red, const float* __
 			float s = 0.f;
 #pragma unroll
 			for (int i = 0; i < MAXV; ++i) {
-				s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+				if (tid + i * BLOCK < n4) {
+					s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+				}
 			}
 			for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
 				float4 t = src4[p];
@@ -238,14 +277,20 @@ __device__ __forceinline__ void stage_x(float4* xs4, float* red, const float* __
 		scale = 1.0f / sqrtf(var + eps);
 	}
 
-	const float4* w4 = (const float4*)normw;
-	auto emit = [&](int p, float4 t) {
+	// norm weights: unconditional loads as well (over-read into the padding is harmless)
+	float4 g[MAXV];
+	if (normw) {
+#pragma unroll
+		for (int i = 0; i < MAXV; ++i) {
+			g[i] = ((const float4*)normw)[tid + i * BLOCK];
+		}
+	}
+	auto emit = [&](int p, float4 t, float4 gw) {
 		if (normw) {
-			float4 g = w4[p];
-			t.x = (t.x - mean) * scale * g.x;
-			t.y = (t.y - mean) * scale * g.y;
-			t.z = (t.z - mean) * scale * g.z;
-			t.w = (t.w - mean) * scale * g.w;
+			t.x = (t.x - mean) * scale * gw.x;
+			t.y = (t.y - mean) * scale * gw.y;
+			t.z = (t.z - mean) * scale * gw.z;
+			t.w = (t.w - mean) * scale * gw.w;
 		}
 		xs4[swz4<DB>(p)] = t;
 		if (dump && blockIdx.x == 0) {
@@ -256,11 +301,11 @@ __device__ __forceinline__ void stage_x(float4* xs4, float* red, const float* __
 	for (int i = 0; i < MAXV; ++i) {
 		int p = tid + i * BLOCK;
 		if (p < n4) {
-			emit(p, v[i]);
+			emit(p, v[i], g[i]);
 		}
 	}
 	for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
-		emit(p, src4[p]);
+		emit(p, src4[p], normw ? ((const float4*)normw)[p] : make_float4(0.f, 0.f, 0.f, 0.f));
 	}
 	// zero the tail of the last chunk so masked-off lanes multiply 0 * 0
 	for (int p = n4 + tid; p < slots; p += BLOCK) {
@@ -277,33 +322,37 @@ struct Tile {
 	u32x4 w[U][NR];
 };
 
-// FULL: every row is a whole number of 1-KiB wave-loads (nl % 64 == 0), so no lane is ever masked
+// FULL: every row is a whole number of 1-KiB wave-loads (nl % 64 == 0), so no lane is ever masked.
+// Loads are always issued and never clamped: the last step of a row may run up to U-1 KiB past the
+// row's end (into the next row, or into the DEV_PAD slack behind the tensor); that data is ignored
+// (whole chunk) or zeroed (partial chunk) in tile_fma.  In practice the neighbouring wave is
+// streaming those very lines, so the over-read costs L2 bandwidth, not HBM bandwidth.
 template <int DB, int NR, int U, bool FULL>
 __device__ __forceinline__ void tile_load(Tile<NR, U>& t, const unsigned char* const (&rows)[NR], int k0, int nl, int lane) {
 #pragma unroll
 	for (int u = 0; u < U; ++u) {
-		const int li = (k0 + u) * 64 + lane; // index of this lane's 16-byte piece within the row
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
-			if (FULL ? (k0 + u) * 64 < nl : li < nl) {
-				t.w[u][r] = __builtin_nontemporal_load((const u32x4*)rows[r] + li);
-			} else {
-				t.w[u][r] = (u32x4){0u, 0u, 0u, 0u};
-			}
+			t.w[u][r] = __builtin_nontemporal_load((gptr16)rows[r] + (k0 + u) * 64 + lane);
 		}
 	}
 }
 
-template <int DB, int NR, int U>
+template <int DB, int NR, int U, bool FULL>
 __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR], const float4* xs4, int k0, int nl, int lane) {
 	constexpr int G = Fmt<DB>::G;
 #pragma unroll
 	for (int u = 0; u < U; ++u) {
 		if ((k0 + u) * 64 < nl) { // wave-uniform: skip chunks past the end of the row
 			const f32x4* xp = (const f32x4*)xs4 + (k0 + u) * 16 * G + lane;
+			const bool live = FULL || (k0 + u) * 64 + lane < nl;
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
-				acc[r] = dot16<DB>(t.w[u][r], xp, acc[r]);
+				u32x4 w = t.w[u][r];
+				if (!FULL) {
+					w = live ? w : (u32x4){0u, 0u, 0u, 0u};
+				}
+				acc[r] = dot16<DB>(w, xp, acc[r]);
 			}
 		}
 	}
@@ -312,22 +361,31 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // Runs `ntasks` row-group tasks over the workgroup's waves.  Wave-task t (t = first, first +
 // stride, ...) owns NR rows given by rows_of(t, rows).  stage() builds the LDS activation image and
 // must end with a barrier; it is called AFTER the first tile's loads have been issued so that the
-// weight stream starts before the prologue.  epi(t, acc) runs on every lane with the reduced sums.
-template <int DB, int NR, int U, bool FULL, class RowsFn, class StageFn, class EpiFn>
-__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, RowsFn rows_of, StageFn stage, EpiFn epi) {
+// weight stream starts before the prologue.  pre() issues the activation loads ahead of that tile.
+// epi(t, acc) runs on every lane; the reduced sums are valid in lane RED_LANE only.
+//
+// The tile stream is software-pipelined one step deep across k-steps AND across tasks: the loads of
+// step s+1 are issued before the multiply-adds (and the reduction / epilogue) of step s, so every
+// wave keeps up to 2 x 8 KiB in flight and HBM never waits for a wave's reduction tail.  The two
+// register tiles alternate through a 2x-unrolled loop body so all tile indices are compile-time.
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class EpiFn>
+__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                              StageFn stage, EpiFn epi) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
-	const unsigned char* rows[NR];
-	Tile<NR, U> tile;
+	const unsigned char* rows[2][NR];
+	Tile<NR, U> tile[2];
 	f32x2 acc2[NR];
 	float acc[NR];
 
+	// NOTHING below issues a load conditionally: a wave without work, and the step after a wave's last
+	// one, load from `dummy` (a small L2-resident buffer with DEV_PAD slack) and discard the data, so
+	// the compiler's vmcnt bookkeeping is exact and every wait is "the previous tile, not this one".
 	int t = first;
 	const bool has = t < ntasks;
-	if (has) {
-		rows_of(t, rows);
-		tile_load<DB, NR, U, FULL>(tile, rows, 0, nl, lane);
-	}
+	pre(); // issues the activation vector's loads: they must retire before, not behind, the weight tile
+	rows_of(min(t, ntasks - 1), rows[0]);
+	tile_load<DB, NR, U, FULL>(tile[0], rows[0], 0, nl, lane);
 	stage();
 	if (!has) {
 		return;
@@ -336,41 +394,51 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	for (int r = 0; r < NR; ++r) {
 		acc2[r] = (f32x2){0.f, 0.f};
 	}
-	tile_fma<DB, NR, U>(tile, acc2, xs4, 0, nl, lane);
-	for (int k0 = U; k0 * 64 < nl; k0 += U) {
-		tile_load<DB, NR, U, FULL>(tile, rows, k0, nl, lane);
-		tile_fma<DB, NR, U>(tile, acc2, xs4, k0, nl, lane);
-	}
+	int k0 = 0;
+	for (;;) {
 #pragma unroll
-	for (int r = 0; r < NR; ++r) {
-		acc[r] = wave_sum(acc2[r][0] + acc2[r][1]);
-	}
-	epi(t, acc);
-
-	for (t += stride; t < ntasks; t += stride) {
-		rows_of(t, rows);
+		for (int ph = 0; ph < 2; ++ph) {
+			int nk0 = k0 + U, nt = t;
+			const bool last_k = nk0 * 64 >= nl; // this step finishes the task's rows
+			if (last_k) {
+				nk0 = 0;
+				nt = t + stride;
+			}
+			const bool more = nt < ntasks;
+			if (last_k) {
+				rows_of(min(nt, ntasks - 1), rows[ph ^ 1]);
+			}
 #pragma unroll
-		for (int r = 0; r < NR; ++r) {
-			acc2[r] = (f32x2){0.f, 0.f};
-		}
-		for (int k0 = 0; k0 * 64 < nl; k0 += U) {
-			tile_load<DB, NR, U, FULL>(tile, rows, k0, nl, lane);
-			tile_fma<DB, NR, U>(tile, acc2, xs4, k0, nl, lane);
-		}
+			for (int r = 0; r < NR; ++r) {
+				const unsigned char* nr = last_k ? rows[ph ^ 1][r] : rows[ph][r];
+				rows[ph ^ 1][r] = more ? nr : (const unsigned char*)dummy;
+			}
+			tile_load<DB, NR, U, FULL>(tile[ph ^ 1], rows[ph ^ 1], more ? nk0 : 0, nl, lane);
+			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, xs4, k0, nl, lane);
+			if (last_k) {
 #pragma unroll
-		for (int r = 0; r < NR; ++r) {
-			acc[r] = wave_sum(acc2[r][0] + acc2[r][1]);
+				for (int r = 0; r < NR; ++r) {
+					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
+					acc2[r] = (f32x2){0.f, 0.f};
+				}
+				epi(t, acc);
+			}
+			if (!more) {
+				return;
+			}
+			t = nt;
+			k0 = nk0;
 		}
-		epi(t, acc);
 	}
 }
 
-template <int DB, int NR, int U, class RowsFn, class StageFn, class EpiFn>
-__device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, RowsFn rows_of, StageFn stage, EpiFn epi) {
+template <int DB, int NR, int U, class RowsFn, class PreFn, class StageFn, class EpiFn>
+__device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                         StageFn stage, EpiFn epi) {
 	if ((n / Fmt<DB>::G) % 64 == 0) { // workgroup-uniform
-		run_rows_impl<DB, NR, U, true>(ntasks, first, stride, n, xs4, rows_of, stage, epi);
+		run_rows_impl<DB, NR, U, true>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, epi);
 	} else {
-		run_rows_impl<DB, NR, U, false>(ntasks, first, stride, n, xs4, rows_of, stage, epi);
+		run_rows_impl<DB, NR, U, false>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, epi);
 	}
 }
 
@@ -457,7 +525,7 @@ struct QkvArgs {
 
 // attention norm + fused q/k/v matvec + bias + clip + RoPE + KV append   (src/infer.c:352-381)
 // task = NR consecutive rows of the concatenated [wq; wk; wv]; rows come in RoPE pairs (2i, 2i+1).
-template <int DB, int KVB>
+template <int DB, int KVB, int V>
 __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -484,12 +552,14 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 			rows[r] = row_ptr(t * NR + r);
 		}
 	};
-	auto stage = [&]() { stage_x<DB, 256>(xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
+	StageRegs<V> sr;
+	auto pre = [&]() { stage_load<256>(sr, a.x); };
+	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
+	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
 	auto epi = [&](int t, float(&acc)[NR]) {
-		if (lane != 0) {
+		if (lane != RED_LANE) {
 			return;
 		}
-		const int kv_pos = a.ts->kv_pos;
 #pragma unroll
 		for (int r = 0; r < NR; r += 2) {
 			int j = t * NR + r; // even row of a pair
@@ -526,7 +596,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 			}
 		}
 	};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, rows_of, stage, epi);
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -553,15 +623,17 @@ __device__ __forceinline__ void sm_merge(float& m, float& l, float (&o)[8], floa
 	m = M;
 }
 
-// One workgroup (4 waves) per (query head, kv split).  LPR lanes cover one cached row (8 dims per
-// lane, one 16-byte load for fp16), so a wave-load covers 64/LPR positions; the 4 waves interleave
+constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions in flight per round
+
+// One workgroup (16 waves) per (query head, kv split).  LPR lanes cover one cached row (8 dims per
+// lane, one 16-byte load for fp16), so a wave-load covers 64/LPR positions; the 16 waves interleave
 // tiles of positions.  Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are
 // computed in one pass with running (max, sum, out) per lane group -- algebraically the same
 // result as the reference's three loops.
 template <int KVB, int LPR>
-__global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
+__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
-	constexpr int NW = 4;
+	constexpr int NW = ATTN_BLOCK / 64;
 	constexpr int UA = 4; // tiles in flight per wave
 	__shared__ float sm_m[NW], sm_l[NW];
 	__shared__ float sm_o[NW][LPR * 8];
@@ -570,8 +642,8 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 	const int h = blockIdx.x / a.n_split, split = blockIdx.x % a.n_split;
 	const int kvh = h / a.kv_mul;
 	const int r = lane % LPR, g = lane / LPR;
-	const int d0 = r * 8;
-	const bool dvalid = d0 < a.head_dim;
+	const bool dvalid = r * 8 < a.head_dim;
+	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
 	const int kv_len = a.ts->kv_len;
 	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
 	const int t0 = split * chunk;
@@ -580,7 +652,8 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 	float qv[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		qv[i] = dvalid ? a.q[h * a.head_dim + d0 + i] : 0.f;
+		float qi = a.q[h * a.head_dim + d0 + i];
+		qv[i] = dvalid ? qi : 0.f;
 	}
 	const float sqrt_hd = sqrtf((float)a.head_dim);
 
@@ -602,7 +675,8 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 		for (int u = 0; u < UA; ++u) {
 			int t = tb + u * NW * RPW + g;
 			valid[u] = t < t1;
-			if (valid[u] && dvalid) {
+			t = min(t, kv_len - 1); // always load (clamped); masked below -- keeps the vmcnt bookkeeping exact
+			{
 				if constexpr (KVB == 16) {
 					u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
 					u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
@@ -623,11 +697,6 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 						kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
 						vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
 					}
-				}
-			} else {
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					kf[u][i] = 0.f, vf[u][i] = 0.f;
 				}
 			}
 		}
@@ -686,9 +755,11 @@ __global__ __launch_bounds__(256) void k_attn(AttnArgs a) {
 			sm_m[wave] = m;
 			sm_l[wave] = l;
 		}
+		if (dvalid) {
 #pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			sm_o[wave][d0 + i] = o[i];
+			for (int i = 0; i < 8; ++i) {
+				sm_o[wave][d0 + i] = o[i];
+			}
 		}
 	}
 	__syncthreads();
@@ -752,7 +823,7 @@ __global__ void k_attn_merge(const float* partial, float* out, int head_dim, int
 }
 
 // ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
-template <int DB>
+template <int DB, int V>
 __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -766,16 +837,18 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 			rows[r] = (const unsigned char*)wo + (size_t)(t * NR + r) * row_bytes;
 		}
 	};
-	auto stage = [&]() { stage_x<DB, 256>(xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
+	StageRegs<V> sr;
+	auto pre = [&]() { stage_load<256>(sr, att); };
+	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
 	auto epi = [&](int t, float(&acc)[NR]) {
-		if (lane == 0) {
+		if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
 				x[t * NR + r] += acc[r];
 			}
 		}
 	};
-	run_rows<DB, NR, U>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, rows_of, stage, epi);
+	run_rows<DB, NR, U>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, epi);
 }
 
 // ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
@@ -800,7 +873,7 @@ __device__ __forceinline__ float act_gelu(float x) {
 }
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
-template <int DB>
+template <int DB, int V>
 __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -828,7 +901,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		}
 	};
 	auto epi = [&](int t, float(&acc)[NR]) {
-		if (lane == 0) {
+		if (lane == RED_LANE) {
 			int k = t / per_expert, j = (t % per_expert) * JP;
 #pragma unroll
 			for (int p = 0; p < JP; ++p) {
@@ -838,9 +911,11 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		}
 	};
 
+	StageRegs<V> sr;
 	if (!moe) {
-		auto stage = [&]() { stage_x<DB, 256>(xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, rows_of, stage, epi);
+		auto pre = [&]() { stage_load<256>(sr, a.x); };
+		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
+		run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -850,7 +925,8 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 
 	// MoE: the routing decides which rows to stream, so it has to come first.  Every workgroup
 	// recomputes the gate (n_experts short rows, L2-resident) -- no cross-workgroup hand-off.
-	stage_x<DB, 256>(xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr);
+	stage_load<256>(sr, a.x);
+	stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr);
 	{
 		const int nl = a.dim / Fmt<DB>::G;
 		for (int e = wave; e < a.n_experts; e += 4) {
@@ -899,14 +975,14 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		}
 		__syncthreads();
 	}
-	auto nostage = [&]() {};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, rows_of, nostage, epi);
+	auto nothing = [&]() {};
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, nothing, nothing, epi);
 }
 
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
 // Experts are added in rank order (k = 0, 1, ...) by the same lane, so the sum order is the
 // reference's and is deterministic (the CUDA path's atomicAdd, src/infer.cu:618, is not).
-template <int DB, int BLOCK>
+template <int DB, int BLOCK, int V>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -926,26 +1002,28 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 				rows[r] = wbase + (size_t)(t * NR + r) * row_bytes;
 			}
 		};
+		StageRegs<V> sr;
+		auto pre = [&]() { stage_load<BLOCK>(sr, he + (size_t)k * hidden); };
 		auto stage = [&]() {
 			if (k > 0) {
 				__syncthreads(); // everyone is done reading the previous expert's image
 			}
-			stage_x<DB, BLOCK>(xs4, red, he + (size_t)k * hidden, nullptr, hidden, 0.f, false, nullptr);
+			stage_finish<DB, BLOCK>(sr, xs4, red, he + (size_t)k * hidden, nullptr, hidden, 0.f, false, nullptr);
 		};
 		auto epi = [&](int t, float(&acc)[NR]) {
-			if (lane == 0) {
+			if (lane == RED_LANE) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					x[t * NR + r] += acc[r] * wk;
 				}
 			}
 		};
-		run_rows<DB, NR, U>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, rows_of, stage, epi);
+		run_rows<DB, NR, U>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, epi);
 	}
 }
 
 // ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
-template <int DB>
+template <int DB, int V>
 __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -961,9 +1039,11 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 			rows[r] = (const unsigned char*)wcls + (size_t)j * row_bytes;
 		}
 	};
-	auto stage = [&]() { stage_x<DB, 256>(xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
+	StageRegs<V> sr;
+	auto pre = [&]() { stage_load<256>(sr, x); };
+	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
 	auto epi = [&](int t, float(&acc)[NR]) {
-		if (lane == 0) {
+		if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
 				if (t * NR + r < vocab) {
@@ -972,7 +1052,7 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 			}
 		}
 	};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, rows_of, stage, epi);
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----

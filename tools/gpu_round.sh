@@ -25,11 +25,11 @@ echo "== bench" | tee -a $OUT/summary.txt
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
 tail -c 3000 $OUT/bench.json >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.txt
 
-echo "== membench" | tee -a $OUT/summary.txt
-timeout 300 python tools/membench.py > $OUT/membench.txt 2>&1; cat $OUT/membench.txt >> $OUT/summary.txt
+echo "== tune" | tee -a $OUT/summary.txt
+timeout 600 python tools/tune.py > $OUT/tune.txt 2>&1; cat $OUT/tune.txt >> $OUT/summary.txt
 
 echo "== rocprof kernel trace of the bench command" | tee -a $OUT/summary.txt
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --no-cpu --steps 64 --warmup 8 > $OUT/prof_bench.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --no-cpu --no-device-greedy --steps 64 --warmup 8 > $OUT/prof_bench.log 2>&1
 echo "exit $?" >> $OUT/summary.txt
 find $OUT/prof -name "*stats*" | head >> $OUT/summary.txt
 for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f >> $OUT/summary.txt; cp $f $OUT/kernel_stats.csv; done
