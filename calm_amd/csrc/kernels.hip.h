@@ -222,14 +222,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 template <int V>
 struct StageRegs {
 	float4 v[V];
+	float4 g[V]; // norm weight (or a harmless second copy of src when there is no norm)
 };
 
 template <int BLOCK, int V>
-__device__ __forceinline__ void stage_load(StageRegs<V>& sr, const float* __restrict__ src) {
+__device__ __forceinline__ void stage_load(StageRegs<V>& sr, const float* __restrict__ src, const float* __restrict__ normw) {
 	const float4* src4 = (const float4*)src + threadIdx.x;
+	const float4* g4 = (const float4*)(normw ? normw : src) + threadIdx.x;
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		sr.v[i] = src4[i * BLOCK];
+	}
+#pragma unroll
+	for (int i = 0; i < V; ++i) {
+		sr.g[i] = g4[i * BLOCK];
 	}
 }
 
@@ -277,14 +283,7 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V>& sr, float4* xs4
 		scale = 1.0f / sqrtf(var + eps);
 	}
 
-	// norm weights: unconditional loads as well (over-read into the padding is harmless)
-	float4 g[MAXV];
-	if (normw) {
-#pragma unroll
-		for (int i = 0; i < MAXV; ++i) {
-			g[i] = ((const float4*)normw)[tid + i * BLOCK];
-		}
-	}
+	const float4(&g)[MAXV] = sr.g;
 	auto emit = [&](int p, float4 t, float4 gw) {
 		if (normw) {
 			t.x = (t.x - mean) * scale * gw.x;
@@ -364,81 +363,115 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // weight stream starts before the prologue.  pre() issues the activation loads ahead of that tile.
 // epi(t, acc) runs on every lane; the reduced sums are valid in lane RED_LANE only.
 //
-// The tile stream is software-pipelined one step deep across k-steps AND across tasks: the loads of
-// step s+1 are issued before the multiply-adds (and the reduction / epilogue) of step s, so every
-// wave keeps up to 2 x 8 KiB in flight and HBM never waits for a wave's reduction tail.  The two
+// The tile stream is software-pipelined two steps deep across k-steps AND across tasks (see the body),
+// so every wave keeps up to 2 x 8 KiB in flight and HBM never waits for a wave's reduction tail.  The two
 // register tiles alternate through a 2x-unrolled loop body so all tile indices are compile-time.
-template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class EpiFn>
+// aux_of(t, aux) may issue small loads the epilogue needs (residual value, RoPE pair); it runs before the
+// task's last multiply-add so that latency hides behind it.  epi(t, acc, aux): sums valid in lane RED_LANE.
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                              StageFn stage, EpiFn epi) {
+                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
 	const unsigned char* rows[2][NR];
 	Tile<NR, U> tile[2];
 	f32x2 acc2[NR];
-	float acc[NR];
+	float acc[NR], aux[NR];
 
-	// NOTHING below issues a load conditionally: a wave without work, and the step after a wave's last
-	// one, load from `dummy` (a small L2-resident buffer with DEV_PAD slack) and discard the data, so
-	// the compiler's vmcnt bookkeeping is exact and every wait is "the previous tile, not this one".
-	int t = first;
-	const bool has = t < ntasks;
-	pre(); // issues the activation vector's loads: they must retire before, not behind, the weight tile
-	rows_of(min(t, ntasks - 1), rows[0]);
-	tile_load<DB, NR, U, FULL>(tile[0], rows[0], 0, nl, lane);
+	// The stream of tile steps (task t, k-offset k0) is walked with TWO steps always in flight:
+	//   prologue : issue step 0 and step 1, then build the LDS image (stage) while they fly;
+	//   step s   : [last step of a task: issue the epilogue's small loads (aux_of)]
+	//              multiply-add tile s  ->  re-issue that register tile with step s+2
+	//              [last step of a task: reduce, epilogue]
+	// NOTHING issues a load conditionally: past the end of a wave's work the "next step" reads
+	// `dummy` (a small L2-resident buffer with DEV_PAD slack) and the data is dropped, so the
+	// compiler's vmcnt bookkeeping is exact and every wait is "the tile two issues ago".
+	auto advance = [&](int& t, int& k0, bool& live) { // -> the step after (t, k0)
+		k0 += U;
+		if (k0 * 64 >= nl) {
+			k0 = 0;
+			t += stride;
+			live = live && t < ntasks;
+		}
+	};
+	auto issue = [&](int ph, int t, int k0, bool live) {
+		if (k0 == 0 || !live) {
+			rows_of(min(t, ntasks - 1), rows[ph]);
+		}
+		if (!live) {
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				rows[ph][r] = (const unsigned char*)dummy;
+			}
+		}
+		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? k0 : 0, nl, lane);
+	};
+
+	pre(); // the activation vector's loads go first: they must retire before, not behind, the tiles
+	int t = first, k0 = 0;   // step being consumed
+	bool live = t < ntasks;
+	int t1 = t, k1 = 0;      // step s+1
+	bool live1 = live;
+	issue(0, t, 0, live);
+	advance(t1, k1, live1);
+	if (k1 != 0) { // same task, next k-offset: same rows
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			rows[1][r] = rows[0][r];
+		}
+	}
+	issue(1, t1, k1, live1);
 	stage();
-	if (!has) {
+	if (!live) {
 		return;
 	}
 #pragma unroll
 	for (int r = 0; r < NR; ++r) {
 		acc2[r] = (f32x2){0.f, 0.f};
 	}
-	int k0 = 0;
 	for (;;) {
 #pragma unroll
 		for (int ph = 0; ph < 2; ++ph) {
-			int nk0 = k0 + U, nt = t;
-			const bool last_k = nk0 * 64 >= nl; // this step finishes the task's rows
+			// (t, k0) lives in tile[ph]; (t1, k1) in tile[ph ^ 1]
+			const bool last_k = (k0 + U) * 64 >= nl;
 			if (last_k) {
-				nk0 = 0;
-				nt = t + stride;
+				aux_of(t, aux);
 			}
-			const bool more = nt < ntasks;
-			if (last_k) {
-				rows_of(min(nt, ntasks - 1), rows[ph ^ 1]);
-			}
-#pragma unroll
-			for (int r = 0; r < NR; ++r) {
-				const unsigned char* nr = last_k ? rows[ph ^ 1][r] : rows[ph][r];
-				rows[ph ^ 1][r] = more ? nr : (const unsigned char*)dummy;
-			}
-			tile_load<DB, NR, U, FULL>(tile[ph ^ 1], rows[ph ^ 1], more ? nk0 : 0, nl, lane);
 			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, xs4, k0, nl, lane);
+			int t2 = t1, k2 = k1;
+			bool live2 = live1;
+			advance(t2, k2, live2);
+			if (k2 != 0 && live2) { // continues the task of step s+1: same rows
+#pragma unroll
+				for (int r = 0; r < NR; ++r) {
+					rows[ph][r] = rows[ph ^ 1][r];
+				}
+			}
+			issue(ph, t2, k2, live2);
 			if (last_k) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
 					acc2[r] = (f32x2){0.f, 0.f};
 				}
-				epi(t, acc);
+				epi(t, acc, aux);
 			}
-			if (!more) {
+			if (!live1) {
 				return;
 			}
-			t = nt;
-			k0 = nk0;
+			t = t1, k0 = k1;
+			t1 = t2, k1 = k2, live1 = live2;
 		}
 	}
 }
 
-template <int DB, int NR, int U, class RowsFn, class PreFn, class StageFn, class EpiFn>
+template <int DB, int NR, int U, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                         StageFn stage, EpiFn epi) {
+                                         StageFn stage, AuxFn aux_of, EpiFn epi) {
 	if ((n / Fmt<DB>::G) % 64 == 0) { // workgroup-uniform
-		run_rows_impl<DB, NR, U, true>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, epi);
+		run_rows_impl<DB, NR, U, true>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 	} else {
-		run_rows_impl<DB, NR, U, false>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, epi);
+		run_rows_impl<DB, NR, U, false>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 	}
 }
 
@@ -537,14 +570,13 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 	const int lane = lane_id();
 
 	auto row_ptr = [&](int j) -> const unsigned char* {
-		if (j < a.q_dim) {
-			return (const unsigned char*)a.wq + (size_t)j * row_bytes;
-		}
-		j -= a.q_dim;
-		if (j < a.kv_dim) {
-			return (const unsigned char*)a.wk + (size_t)j * row_bytes;
-		}
-		return (const unsigned char*)a.wv + (size_t)(j - a.kv_dim) * row_bytes;
+		// j is wave-uniform: keep the three-way choice in scalar selects (an if-chain over the three
+		// kernel-argument pointers gets turned into a scratch-memory lookup table by the optimiser)
+		j = __builtin_amdgcn_readfirstlane(j);
+		const bool is_q = j < a.q_dim, is_k = j < a.q_dim + a.kv_dim;
+		const unsigned char* base = (const unsigned char*)(is_q ? a.wq : (is_k ? a.wk : a.wv));
+		const int jl = j - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
+		return base + (size_t)jl * row_bytes;
 	};
 	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
 #pragma unroll
@@ -553,10 +585,21 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 		}
 	};
 	StageRegs<V> sr;
-	auto pre = [&]() { stage_load<256>(sr, a.x); };
+	auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
 	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
-	auto epi = [&](int t, float(&acc)[NR]) {
+	// aux = (cos, sin) of each row pair's RoPE angle, fetched before the task's last multiply-add
+	auto aux_of = [&](int t, float(&aux)[NR]) {
+#pragma unroll
+		for (int r = 0; r < NR; r += 2) {
+			int j = t * NR + r;
+			int jl = j < a.q_dim ? j : j - a.q_dim;
+			float2 cs = a.rope_cs[(jl % a.head_dim) >> 1]; // v rows: an unused but in-bounds entry
+			aux[r] = cs.x;
+			aux[r + 1] = cs.y;
+		}
+	};
+	auto epi = [&](int t, float(&acc)[NR], float(&aux)[NR]) {
 		if (lane != RED_LANE) {
 			return;
 		}
@@ -571,10 +614,8 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 			v0 = clipf(v0, a.clip);
 			v1 = clipf(v1, a.clip);
 			if (j < a.q_dim + a.kv_dim) { // q or k: rotate the pair (src/infer.c:223-236)
-				int jl = j < a.q_dim ? j : j - a.q_dim;
-				float2 cs = a.rope_cs[(jl % a.head_dim) >> 1];
-				float r0 = v0 * cs.x - v1 * cs.y;
-				float r1 = v0 * cs.y + v1 * cs.x;
+				float r0 = v0 * aux[r] - v1 * aux[r + 1];
+				float r1 = v0 * aux[r + 1] + v1 * aux[r];
 				v0 = r0;
 				v1 = r1;
 			}
@@ -596,7 +637,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 			}
 		}
 	};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, epi);
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -838,17 +879,23 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 		}
 	};
 	StageRegs<V> sr;
-	auto pre = [&]() { stage_load<256>(sr, att); };
+	auto pre = [&]() { stage_load<256>(sr, att, nullptr); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
-	auto epi = [&](int t, float(&acc)[NR]) {
+	auto aux_of = [&](int t, float(&aux)[NR]) { // the residual values this task adds to
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			aux[r] = x[t * NR + r];
+		}
+	};
+	auto epi = [&](int t, float(&acc)[NR], float(&aux)[NR]) {
 		if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
-				x[t * NR + r] += acc[r];
+				x[t * NR + r] = aux[r] + acc[r];
 			}
 		}
 	};
-	run_rows<DB, NR, U>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, epi);
+	run_rows<DB, NR, U>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
@@ -900,7 +947,8 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 			rows[2 * p + 1] = (const unsigned char*)a.w3 + base + p * row_bytes;
 		}
 	};
-	auto epi = [&](int t, float(&acc)[NR]) {
+	auto no_aux = [&](int, float(&)[NR]) {};
+	auto epi = [&](int t, float(&acc)[NR], float(&)[NR]) {
 		if (lane == RED_LANE) {
 			int k = t / per_expert, j = (t % per_expert) * JP;
 #pragma unroll
@@ -913,9 +961,9 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 
 	StageRegs<V> sr;
 	if (!moe) {
-		auto pre = [&]() { stage_load<256>(sr, a.x); };
+		auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, epi);
+		run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -925,7 +973,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 
 	// MoE: the routing decides which rows to stream, so it has to come first.  Every workgroup
 	// recomputes the gate (n_experts short rows, L2-resident) -- no cross-workgroup hand-off.
-	stage_load<256>(sr, a.x);
+	stage_load<256>(sr, a.x, a.norm_w);
 	stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr);
 	{
 		const int nl = a.dim / Fmt<DB>::G;
@@ -976,7 +1024,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		__syncthreads();
 	}
 	auto nothing = [&]() {};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, nothing, nothing, epi);
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, nothing, nothing, no_aux, epi);
 }
 
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
@@ -1003,22 +1051,28 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 			}
 		};
 		StageRegs<V> sr;
-		auto pre = [&]() { stage_load<BLOCK>(sr, he + (size_t)k * hidden); };
+		auto pre = [&]() { stage_load<BLOCK>(sr, he + (size_t)k * hidden, nullptr); };
 		auto stage = [&]() {
 			if (k > 0) {
 				__syncthreads(); // everyone is done reading the previous expert's image
 			}
 			stage_finish<DB, BLOCK>(sr, xs4, red, he + (size_t)k * hidden, nullptr, hidden, 0.f, false, nullptr);
 		};
-		auto epi = [&](int t, float(&acc)[NR]) {
+		auto aux_of = [&](int t, float(&aux)[NR]) { // residual so far (same lane wrote it for k > 0)
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				aux[r] = x[t * NR + r];
+			}
+		};
+		auto epi = [&](int t, float(&acc)[NR], float(&aux)[NR]) {
 			if (lane == RED_LANE) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
-					x[t * NR + r] += acc[r] * wk;
+					x[t * NR + r] = aux[r] + acc[r] * wk;
 				}
 			}
 		};
-		run_rows<DB, NR, U>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, epi);
+		run_rows<DB, NR, U>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, aux_of, epi);
 	}
 }
 
@@ -1040,9 +1094,10 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 		}
 	};
 	StageRegs<V> sr;
-	auto pre = [&]() { stage_load<256>(sr, x); };
+	auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
-	auto epi = [&](int t, float(&acc)[NR]) {
+	auto no_aux = [&](int, float(&)[NR]) {};
+	auto epi = [&](int t, float(&acc)[NR], float(&)[NR]) {
 		if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
@@ -1052,7 +1107,7 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 			}
 		}
 	};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, epi);
+	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
