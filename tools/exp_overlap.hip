@@ -1,0 +1,312 @@
+// exp_overlap.hip -- EXPERIMENT (not product code): can the weight stream of kernel k+1 overlap the tail
+// of kernel k?  Emulates one decode step as a chain of dependent streaming kernels (sizes of a
+// Mistral-7B fp8 layer: 25.2 / 16.8 / 117.4 / 58.7 MB) in two modes:
+//
+//   mode 0  plain: one stream, kernel boundary between dependent kernels (what forward_hip does today)
+//   mode 1  chained: kernels alternate between two streams; kernel k+1 issues its first weight loads,
+//           then waits on a device-side completion counter of kernel k (agent-scope release/acquire per
+//           cdna_hip_programming.md Guideline 16), then reads k's output vector.
+//
+// Each kernel: 256 blocks x 512 threads; every wave streams 8 KiB tasks with 16 KiB in flight; the
+// prologue reads the 16 KiB "activation" vector produced by the previous kernel (all blocks need all of
+// it) and reduces it; the epilogue writes the wave's results into the next activation vector.
+// The final activation vector must be bit-identical between the modes.
+//
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_overlap.so tools/exp_overlap.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#define CK(x)                                                                                   \
+	do {                                                                                        \
+		hipError_t e_ = (x);                                                                    \
+		if (e_ != hipSuccess) {                                                                 \
+			fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+			abort();                                                                            \
+		}                                                                                       \
+	} while (0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr16;
+
+constexpr int BLOCK = 512;
+constexpr int NW = BLOCK / 64;
+constexpr int VEC = 4096; // floats in the activation vector
+
+struct KArgs {
+	const void* w;      // weights of this kernel
+	size_t ntasks;      // 8 KiB tasks
+	const float* xin;   // activation vector written by the previous kernel
+	float* xout;        // activation vector this kernel writes (VEC floats; each task adds into one slot)
+	unsigned* done_prev; // completion counter of the previous kernel (chained mode) or nullptr
+	unsigned expect_prev;
+	unsigned* done_me;
+	unsigned* timeout; // set to 1 if a bounded spin gave up
+	int chained;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		v += __shfl_xor(v, o);
+	}
+	return v;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_stream(KArgs a) {
+	__shared__ float red[NW];
+	__shared__ float xs[VEC];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const size_t W = (size_t)gridDim.x * NW;
+	size_t t = (size_t)blockIdx.x * NW + wave;
+
+	// 1. first two tasks' loads (16 KiB per wave) go out immediately
+	u32x4 tile[2][8];
+	size_t t0 = t < a.ntasks ? t : 0, t1 = t + W < a.ntasks ? t + W : 0;
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {
+		tile[0][u] = __builtin_nontemporal_load((gptr16)a.w + t0 * 512 + u * 64 + lane);
+	}
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {
+		tile[1][u] = __builtin_nontemporal_load((gptr16)a.w + t1 * 512 + u * 64 + lane);
+	}
+
+	// 2. dependency on the previous kernel
+	if (a.chained && a.done_prev) {
+		if (threadIdx.x == 0) {
+			unsigned spins = 0;
+			while (__hip_atomic_load(a.done_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.expect_prev) {
+				__builtin_amdgcn_s_sleep(8);
+				if (++spins > (1u << 22)) {
+					*a.timeout = 1;
+					break;
+				}
+			}
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		}
+		__syncthreads();
+	}
+
+	// 3. prologue: every block reads the whole activation vector, reduces it (emulates the norm)
+	float4 xv[2];
+	xv[0] = ((const float4*)a.xin)[threadIdx.x];
+	xv[1] = ((const float4*)a.xin)[threadIdx.x + BLOCK];
+	float ss = xv[0].x * xv[0].x + xv[0].y * xv[0].y + xv[0].z * xv[0].z + xv[0].w * xv[0].w + xv[1].x * xv[1].x + xv[1].y * xv[1].y + xv[1].z * xv[1].z +
+	           xv[1].w * xv[1].w;
+	ss = wave_sum(ss);
+	if (lane == 0) {
+		red[wave] = ss;
+	}
+	((float4*)xs)[threadIdx.x] = xv[0];
+	((float4*)xs)[threadIdx.x + BLOCK] = xv[1];
+	__syncthreads();
+	float tot = 0.f;
+#pragma unroll
+	for (int i = 0; i < NW; ++i) {
+		tot += red[i];
+	}
+	const float scale = 1.0f / sqrtf(tot / VEC + 1e-5f);
+
+	// 4. stream: two tasks always in flight
+	for (;;) {
+#pragma unroll
+		for (int ph = 0; ph < 2; ++ph) {
+			if (t >= a.ntasks) {
+				goto finish;
+			}
+			unsigned acc = 0;
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				acc += (tile[ph][u][0] ^ tile[ph][u][1]) + (tile[ph][u][2] ^ tile[ph][u][3]);
+			}
+			size_t t2 = t + 2 * W;
+			size_t tl = t2 < a.ntasks ? t2 : 0;
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				tile[ph][u] = __builtin_nontemporal_load((gptr16)a.w + tl * 512 + u * 64 + lane);
+			}
+			float v = wave_sum((float)(acc & 0xffff) * (1.0f / 65536.0f)) * scale * xs[(t * 7) % VEC];
+			if (lane == 0 && t < VEC) { // one writer per slot: the result is independent of timing
+				float r = v + (float)(t % 13);
+				if (a.chained) {
+					__hip_atomic_store(a.xout + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1 write-through
+				} else {
+					a.xout[t] = r;
+				}
+			}
+			t += W;
+		}
+	}
+finish:
+	if (a.chained) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__hip_atomic_fetch_add(a.done_me, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+// concurrency probe: do two kernels on two streams run at the same time?
+__global__ void k_wait_flag(unsigned* flag, unsigned* seen, unsigned long long* cycles) {
+	if (threadIdx.x == 0) {
+		unsigned long long t0 = wall_clock64();
+		unsigned ok = 0;
+		for (unsigned i = 0; i < (1u << 20); ++i) {
+			if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+				ok = 1;
+				break;
+			}
+			__builtin_amdgcn_s_sleep(16);
+		}
+		seen[blockIdx.x] = ok;
+		cycles[blockIdx.x] = wall_clock64() - t0;
+	}
+}
+__global__ void k_set_flag(unsigned* flag) {
+	if (threadIdx.x == 0 && blockIdx.x == 0) {
+		__hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
+extern "C" int exp_concurrency(int nblocks) {
+	hipStream_t s0, s1;
+	CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+	CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+	unsigned *flag, *seen;
+	unsigned long long* cyc;
+	CK(hipMalloc(&flag, 4));
+	CK(hipMalloc(&seen, 4 * nblocks));
+	CK(hipMalloc(&cyc, 8 * nblocks));
+	CK(hipMemset(flag, 0, 4));
+	CK(hipMemset(seen, 0, 4 * nblocks));
+	hipLaunchKernelGGL(k_wait_flag, dim3(nblocks), dim3(256), 0, s0, flag, seen, cyc);
+	hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, s1, flag);
+	CK(hipDeviceSynchronize());
+	std::vector<unsigned> h(nblocks);
+	std::vector<unsigned long long> c(nblocks);
+	CK(hipMemcpy(h.data(), seen, 4 * nblocks, hipMemcpyDeviceToHost));
+	CK(hipMemcpy(c.data(), cyc, 8 * nblocks, hipMemcpyDeviceToHost));
+	int ok = 0;
+	unsigned long long mx = 0;
+	for (int i = 0; i < nblocks; ++i) {
+		ok += h[i];
+		mx = c[i] > mx ? c[i] : mx;
+	}
+	printf("concurrency probe: %d / %d waiting blocks saw the flag set by a kernel on another stream (max wait %llu ticks @100MHz)\n", ok, nblocks, mx);
+	CK(hipFree(flag));
+	CK(hipFree(seen));
+	CK(hipFree(cyc));
+	return ok;
+}
+
+// One "token" = n_layers x 4 dependent streaming kernels.  Returns microseconds per layer; *checksum = sum of final vector.
+extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, double* checksum, int grid) {
+	static const size_t sizes[4] = {25165824, 16777216, 117440512, 58720256};
+	const int NK = 4;
+	hipStream_t s[2];
+	CK(hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking));
+	CK(hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking));
+	// weights: distinct buffers per layer (beyond the 256 MiB Infinity Cache in total)
+	std::vector<void*> w(n_layers * NK);
+	for (int l = 0; l < n_layers; ++l) {
+		for (int k = 0; k < NK; ++k) {
+			CK(hipMalloc(&w[l * NK + k], sizes[k] + 65536));
+			CK(hipMemset(w[l * NK + k], 0x11 + l + k, sizes[k] + 65536));
+		}
+	}
+	float* xbuf[2];
+	CK(hipMalloc(&xbuf[0], VEC * 4 + 65536));
+	CK(hipMalloc(&xbuf[1], VEC * 4 + 65536));
+	std::vector<float> x0(VEC);
+	for (int i = 0; i < VEC; ++i) {
+		x0[i] = 0.001f * (i % 97) + 0.5f;
+	}
+	unsigned *done, *timeout;
+	const int total = n_layers * NK;
+	CK(hipMalloc(&done, 4 * (total + 1)));
+	CK(hipMalloc(&timeout, 4));
+	CK(hipMemset(timeout, 0, 4));
+
+	auto enqueue = [&](bool capture_fork) {
+		// x0 upload + counters reset happen on s[0] before everything
+		CK(hipMemcpyAsync(xbuf[0], x0.data(), VEC * 4, hipMemcpyHostToDevice, s[0]));
+		CK(hipMemsetAsync(done, 0, 4 * (total + 1), s[0]));
+		hipEvent_t fork, join;
+		if (mode == 1) {
+			CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+			CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+			CK(hipEventRecord(fork, s[0]));
+			CK(hipStreamWaitEvent(s[1], fork, 0));
+		}
+		for (int i = 0; i < total; ++i) {
+			KArgs a;
+			a.w = w[i];
+			a.ntasks = sizes[i % NK] / 8192;
+			a.xin = xbuf[i & 1];
+			a.xout = xbuf[(i + 1) & 1];
+			a.done_prev = i > 0 ? done + (i - 1) : nullptr;
+			a.expect_prev = grid;
+			a.done_me = done + i;
+			a.timeout = timeout;
+			a.chained = mode;
+			hipLaunchKernelGGL(k_stream, dim3(grid), dim3(BLOCK), 0, s[mode == 1 ? (i & 1) : 0], a);
+		}
+		if (mode == 1) {
+			CK(hipEventRecord(join, s[1]));
+			CK(hipStreamWaitEvent(s[0], join, 0));
+		}
+	};
+
+	hipGraph_t graph = nullptr;
+	hipGraphExec_t exec = nullptr;
+	if (use_graph) {
+		CK(hipStreamBeginCapture(s[0], hipStreamCaptureModeThreadLocal));
+		enqueue(true);
+		CK(hipStreamEndCapture(s[0], &graph));
+		CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+	}
+	auto run = [&]() {
+		if (use_graph) {
+			CK(hipGraphLaunch(exec, s[0]));
+		} else {
+			enqueue(false);
+		}
+	};
+	run();
+	CK(hipDeviceSynchronize());
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	CK(hipEventRecord(e0, s[0]));
+	for (int i = 0; i < iters; ++i) {
+		run();
+	}
+	CK(hipEventRecord(e1, s[0]));
+	CK(hipDeviceSynchronize());
+	float ms = 0;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	std::vector<float> xf(VEC);
+	CK(hipMemcpy(xf.data(), xbuf[total & 1], VEC * 4, hipMemcpyDeviceToHost));
+	double cs = 0;
+	for (int i = 0; i < VEC; ++i) {
+		cs += xf[i] * (1 + i % 5);
+	}
+	*checksum = cs;
+	unsigned to = 0;
+	CK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost));
+	if (to) {
+		printf("  !! a bounded spin timed out (mode %d)\n", mode);
+	}
+	for (void* p : w) {
+		CK(hipFree(p));
+	}
+	CK(hipFree(xbuf[0]));
+	CK(hipFree(xbuf[1]));
+	CK(hipFree(done));
+	CK(hipFree(timeout));
+	return (double)ms * 1e3 / ((double)iters * n_layers);
+}

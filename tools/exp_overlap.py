@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Driver of the kernel-overlap experiment (tools/exp_overlap.hip); run on the GPU box."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+here = os.path.dirname(os.path.abspath(__file__))
+so = os.path.join(here, "libexp_overlap.so")
+src = os.path.join(here, "exp_overlap.hip")
+if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so, src], check=True)
+if "--build-only" in sys.argv:
+    sys.exit(0)
+lib = C.CDLL(so)
+lib.exp_concurrency.restype = C.c_int
+lib.exp_chain.restype = C.c_double
+lib.exp_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+lib.exp_concurrency(256)
+L = 8
+for grid in (256, 512):
+    for graph in (1, 0):
+        for mode in (0, 1):
+            cs = C.c_double(0)
+            us = lib.exp_chain(mode, graph, L, 6, C.byref(cs), grid)
+            print(f"grid={grid} graph={graph} mode={'chained' if mode else 'plain  '}: {us:7.2f} us/layer  ({218.1/us*1e3/1e3:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)

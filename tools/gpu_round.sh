@@ -25,6 +25,9 @@ echo "== bench" | tee -a $OUT/summary.txt
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
 tail -c 3000 $OUT/bench.json >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.txt
 
+echo "== overlap experiment" | tee -a $OUT/summary.txt
+timeout 300 python tools/exp_overlap.py > $OUT/exp_overlap.txt 2>&1; cat $OUT/exp_overlap.txt >> $OUT/summary.txt
+
 echo "== tune" | tee -a $OUT/summary.txt
 timeout 600 python tools/tune.py > $OUT/tune.txt 2>&1; cat $OUT/tune.txt >> $OUT/summary.txt
 
