@@ -50,7 +50,7 @@ constexpr int MAX_SPLIT = 64;
 hipStream_t g_stream;
 int g_device = -1;
 int g_ncu = 256;
-int g_bpc = 3;       // cap on resident 256-thread workgroups per CU when sizing grids
+int g_bpc = 2;       // cap on resident 256-thread workgroups per CU when sizing grids (measured: 2 beats 3 and 4)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 1024; // kv positions per attention split

@@ -322,17 +322,19 @@ struct Tile {
 };
 
 // FULL: every row is a whole number of 1-KiB wave-loads (nl % 64 == 0), so no lane is ever masked.
-// Loads are always issued and never clamped: the last step of a row may run up to U-1 KiB past the
-// row's end (into the next row, or into the DEV_PAD slack behind the tensor); that data is ignored
-// (whole chunk) or zeroed (partial chunk) in tile_fma.  In practice the neighbouring wave is
-// streaming those very lines, so the over-read costs L2 bandwidth, not HBM bandwidth.
+// Loads are always issued.  FULL rows clamp surplus chunks of a row's last step to the row's last KiB;
+// ragged rows (!FULL) may run up to U KiB past the row's end (into the next row, or into the DEV_PAD
+// slack behind the tensor) and zero that data in tile_fma.
 template <int DB, int NR, int U, bool FULL>
 __device__ __forceinline__ void tile_load(Tile<NR, U>& t, const unsigned char* const (&rows)[NR], int k0, int nl, int lane) {
 #pragma unroll
 	for (int u = 0; u < U; ++u) {
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
-			t.w[u][r] = __builtin_nontemporal_load((gptr16)rows[r] + (k0 + u) * 64 + lane);
+			// FULL: clamp the (wave-uniform) chunk index into the row -- a surplus chunk re-reads the row's
+			// last KiB (cache hit) instead of pulling the next row's first KiB from HBM a second time
+			const int c = FULL ? min(k0 + u, (nl >> 6) - 1) : k0 + u;
+			t.w[u][r] = __builtin_nontemporal_load((gptr16)rows[r] + c * 64 + lane);
 		}
 	}
 }
@@ -685,16 +687,58 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	const int r = lane % LPR, g = lane / LPR;
 	const bool dvalid = r * 8 < a.head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
-	const int kv_len = a.ts->kv_len;
-	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
-	const int t0 = split * chunk;
-	const int t1 = min(kv_len, t0 + chunk);
+	constexpr int EB = KVB / 8; // bytes per element
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const size_t rstride = (size_t)a.head_dim * EB;
+
+	// One round = UA wave-loads of K and of V.  Loads are unconditional: rows are clamped to the cache
+	// extent (seq_len rows exist; rows past kv_len hold zeros or stale values) and masked afterwards.
+	u32x4 kw[UA], vw[UA];
+	auto load_round = [&](int tb) {
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			int t = min(tb + u * NW * RPW + g, a.seq_len - 1);
+			if constexpr (KVB == 16) {
+				kw[u] = *(const u32x4*)(kbase + (size_t)t * rstride);
+				vw[u] = *(const u32x4*)(vbase + (size_t)t * rstride);
+			} else {
+				u32x2 k2 = *(const u32x2*)(kbase + (size_t)t * rstride);
+				u32x2 v2 = *(const u32x2*)(vbase + (size_t)t * rstride);
+				kw[u] = (u32x4){k2[0], k2[1], 0u, 0u};
+				vw[u] = (u32x4){v2[0], v2[1], 0u, 0u};
+			}
+		}
+	};
+
+	// The first round goes out before kv_len (a scalar load of TokState) and q have arrived: ts, q, K
+	// and V are all in flight together, so the kernel's latency chain is one memory round trip, not
+	// three.  (With n_split > 1 the split's first row depends on kv_len; long contexts are
+	// bandwidth-bound and do not care.)
+	float qraw[8]; // issued first: plain loads, consumed after the K/V round is in flight
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		qraw[i] = a.q[h * a.head_dim + d0 + i];
+	}
+	int tb = wave * RPW;
+	int t1;
+	if (a.n_split == 1) {
+		load_round(tb);
+		// kv_len through the VECTOR memory pipe, issued behind the K/V loads: it returns in order with them,
+		// so waiting for it costs nothing extra (a scalar load would be waited for ahead of the K/V issue)
+		t1 = __builtin_amdgcn_readfirstlane(*(const volatile int*)&a.ts->kv_len);
+	} else {
+		const int kv_len = a.ts->kv_len;
+		const int chunk = (kv_len + a.n_split - 1) / a.n_split;
+		tb += split * chunk;
+		t1 = min(kv_len, split * chunk + chunk);
+		load_round(tb);
+	}
 
 	float qv[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		float qi = a.q[h * a.head_dim + d0 + i];
-		qv[i] = dvalid ? qi : 0.f;
+		qv[i] = dvalid ? qraw[i] : 0.f;
 	}
 	const float sqrt_hd = sqrtf((float)a.head_dim);
 
@@ -704,43 +748,38 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 		o[i] = 0.f;
 	}
 
-	constexpr int EB = KVB / 8; // bytes per element
-	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const size_t rstride = (size_t)a.head_dim * EB;
-
-	for (int tb = t0 + wave * RPW; tb < t1; tb += NW * RPW * UA) {
+	for (;;) {
 		float kf[UA][8], vf[UA][8];
 		bool valid[UA];
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {
-			int t = tb + u * NW * RPW + g;
-			valid[u] = t < t1;
-			t = min(t, kv_len - 1); // always load (clamped); masked below -- keeps the vmcnt bookkeeping exact
-			{
-				if constexpr (KVB == 16) {
-					u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
-					u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
+			valid[u] = tb + u * NW * RPW + g < t1;
+			if constexpr (KVB == 16) {
 #pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[i] & 0xffff));
-						kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[i] >> 16));
-						vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[i] & 0xffff));
-						vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[i] >> 16));
-					}
-				} else {
-					u32x2 kw = *(const u32x2*)(kbase + (size_t)t * rstride);
-					u32x2 vw = *(const u32x2*)(vbase + (size_t)t * rstride);
+				for (int i = 0; i < 4; ++i) {
+					kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[u][i] & 0xffff));
+					kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[u][i] >> 16));
+					vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[u][i] & 0xffff));
+					vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[u][i] >> 16));
+				}
+			} else {
 #pragma unroll
-					for (int i = 0; i < 2; ++i) {
-						f32x2 k0 = bf8x2_lo(kw[i]), k1 = bf8x2_hi(kw[i]);
-						f32x2 v0 = bf8x2_lo(vw[i]), v1 = bf8x2_hi(vw[i]);
-						kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
-						vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
-					}
+				for (int i = 0; i < 2; ++i) {
+					f32x2 k0 = bf8x2_lo(kw[u][i]), k1 = bf8x2_hi(kw[u][i]);
+					f32x2 v0 = bf8x2_lo(vw[u][i]), v1 = bf8x2_hi(vw[u][i]);
+					kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
+					vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+				}
+			}
+			if (!valid[u]) { // stale rows may hold anything, including Inf/NaN patterns
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					kf[u][i] = 0.f, vf[u][i] = 0.f;
 				}
 			}
 		}
+		const int tbn = tb + NW * RPW * UA;
+		load_round(tbn); // next round (clamped; dropped if past the end)
 		float s[UA];
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {
@@ -778,6 +817,10 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			}
 			m = mn;
 		}
+		if (tbn >= t1) {
+			break;
+		}
+		tb = tbn;
 	}
 
 	// merge the RPW lane groups of the wave

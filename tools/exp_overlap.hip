@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_stream(KArgs a) {
 			unsigned spins = 0;
 			while (__hip_atomic_load(a.done_prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.expect_prev) {
 				__builtin_amdgcn_s_sleep(8);
-				if (++spins > (1u << 22)) {
+				if (++spins > (1u << 16)) {
 					*a.timeout = 1;
 					break;
 				}
@@ -92,8 +92,19 @@ __global__ __launch_bounds__(BLOCK) void k_stream(KArgs a) {
 
 	// 3. prologue: every block reads the whole activation vector, reduces it (emulates the norm)
 	float4 xv[2];
-	xv[0] = ((const float4*)a.xin)[threadIdx.x];
-	xv[1] = ((const float4*)a.xin)[threadIdx.x + BLOCK];
+	if (a.chained == 2) {
+		// variant B: no acquire fence; the vector is read with system-scope (sc0 sc1) loads that bypass L1/L2
+		const unsigned long long* p = (const unsigned long long*)a.xin;
+		unsigned long long q0 = __hip_atomic_load(p + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		unsigned long long q1 = __hip_atomic_load(p + 2 * threadIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		unsigned long long q2 = __hip_atomic_load(p + 2 * (threadIdx.x + BLOCK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		unsigned long long q3 = __hip_atomic_load(p + 2 * (threadIdx.x + BLOCK) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+		xv[0] = make_float4(__uint_as_float((unsigned)q0), __uint_as_float((unsigned)(q0 >> 32)), __uint_as_float((unsigned)q1), __uint_as_float((unsigned)(q1 >> 32)));
+		xv[1] = make_float4(__uint_as_float((unsigned)q2), __uint_as_float((unsigned)(q2 >> 32)), __uint_as_float((unsigned)q3), __uint_as_float((unsigned)(q3 >> 32)));
+	} else {
+		xv[0] = ((const float4*)a.xin)[threadIdx.x];
+		xv[1] = ((const float4*)a.xin)[threadIdx.x + BLOCK];
+	}
 	float ss = xv[0].x * xv[0].x + xv[0].y * xv[0].y + xv[0].z * xv[0].z + xv[0].w * xv[0].w + xv[1].x * xv[1].x + xv[1].y * xv[1].y + xv[1].z * xv[1].z +
 	           xv[1].w * xv[1].w;
 	ss = wave_sum(ss);
@@ -128,10 +139,12 @@ __global__ __launch_bounds__(BLOCK) void k_stream(KArgs a) {
 			for (int u = 0; u < 8; ++u) {
 				tile[ph][u] = __builtin_nontemporal_load((gptr16)a.w + tl * 512 + u * 64 + lane);
 			}
-			float v = wave_sum((float)(acc & 0xffff) * (1.0f / 65536.0f)) * scale * xs[(t * 7) % VEC];
+			float v = wave_sum((float)((acc & 0xff) + 1) * (1.0f / 4096.0f)) * scale * xs[(t * 7) % VEC];
 			if (lane == 0 && t < VEC) { // one writer per slot: the result is independent of timing
 				float r = v + (float)(t % 13);
-				if (a.chained) {
+				if (a.chained == 2) {
+					__hip_atomic_store(a.xout + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // sc0 sc1
+				} else if (a.chained) {
 					__hip_atomic_store(a.xout + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // sc1 write-through
 				} else {
 					a.xout[t] = r;
@@ -236,7 +249,7 @@ extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, do
 		CK(hipMemcpyAsync(xbuf[0], x0.data(), VEC * 4, hipMemcpyHostToDevice, s[0]));
 		CK(hipMemsetAsync(done, 0, 4 * (total + 1), s[0]));
 		hipEvent_t fork, join;
-		if (mode == 1) {
+		if (mode >= 1) {
 			CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
 			CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
 			CK(hipEventRecord(fork, s[0]));
@@ -253,9 +266,9 @@ extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, do
 			a.done_me = done + i;
 			a.timeout = timeout;
 			a.chained = mode;
-			hipLaunchKernelGGL(k_stream, dim3(grid), dim3(BLOCK), 0, s[mode == 1 ? (i & 1) : 0], a);
+			hipLaunchKernelGGL(k_stream, dim3(grid), dim3(BLOCK), 0, s[mode >= 1 ? (i & 1) : 0], a);
 		}
-		if (mode == 1) {
+		if (mode >= 1) {
 			CK(hipEventRecord(join, s[1]));
 			CK(hipStreamWaitEvent(s[0], join, 0));
 		}

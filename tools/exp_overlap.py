@@ -18,9 +18,9 @@ lib.exp_chain.restype = C.c_double
 lib.exp_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
 lib.exp_concurrency(256)
 L = 8
-for grid in (256, 512):
-    for graph in (1, 0):
-        for mode in (0, 1):
-            cs = C.c_double(0)
-            us = lib.exp_chain(mode, graph, L, 6, C.byref(cs), grid)
-            print(f"grid={grid} graph={graph} mode={'chained' if mode else 'plain  '}: {us:7.2f} us/layer  ({218.1/us*1e3/1e3:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+names = {0: "plain", 1: "chained(acquire fence)", 2: "chained(system-scope loads)"}
+for grid in (128, 256):
+    for graph, mode in ((1, 0), (0, 0), (0, 1), (0, 2)):
+        cs = C.c_double(0)
+        us = lib.exp_chain(mode, graph, L, 6, C.byref(cs), grid)
+        print(f"grid={grid} graph={graph} mode={names[mode]:28s}: {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)

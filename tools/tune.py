@@ -28,7 +28,7 @@ for kv in (128, 256):
             us, b = be.stage_us(i, 6 if i != 5 else 2)
             row.append(f"{st} {us:6.2f}us {b/us/1e3:6.0f}GB/s")
         print(f"bpc={bpc}: " + " | ".join(row), flush=True)
-    lib.calm_hip_configure(b"bpc", 3)
+    lib.calm_hip_configure(b"bpc", 2)
 for graph in (1, 0):
     lib.calm_hip_configure(b"graph", graph)
     generate(be, model, [17], 16)
