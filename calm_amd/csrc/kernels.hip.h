@@ -725,8 +725,13 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	if (a.n_split == 1) {
 		load_round(tb);
 		// kv_len through the VECTOR memory pipe, issued behind the K/V loads: it returns in order with them,
-		// so waiting for it costs nothing extra (a scalar load would be waited for ahead of the K/V issue)
-		t1 = __builtin_amdgcn_readfirstlane(*(const volatile int*)&a.ts->kv_len);
+		// so waiting for it costs nothing extra (a scalar load would be waited for ahead of the K/V issue;
+		// a volatile load becomes an uncached system-scope flat load).  Load + wait in ONE asm statement
+		// (cdna_hip_programming.md 5.7 form (i)); the wait covers the K/V round as well, by design.
+		int kvl;
+		const int* kvp = &a.ts->kv_len;
+		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(kvl) : "v"(kvp) : "memory");
+		t1 = __builtin_amdgcn_readfirstlane(kvl);
 	} else {
 		const int kv_len = a.ts->kv_len;
 		const int chunk = (kv_len + a.n_split - 1) / a.n_split;
@@ -779,7 +784,9 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			}
 		}
 		const int tbn = tb + NW * RPW * UA;
-		load_round(tbn); // next round (clamped; dropped if past the end)
+		if (tbn < t1) { // workgroup-uniform; short contexts finish in the first round and issue nothing more
+			load_round(tbn);
+		}
 		float s[UA];
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {

@@ -14,6 +14,13 @@ if [ -f tools/exp_overlap.py ] && [ "${EXP:-1}" = "1" ]; then
 fi
 echo "== tune" | tee -a $OUT/summary.txt
 timeout 600 python tools/tune.py > $OUT/tune.txt 2>&1; cat $OUT/tune.txt >> $OUT/summary.txt
+if [ "${SHAPES:-0}" = "1" ]; then
+  echo "== other BASELINE shapes (layer-reduced)" | tee -a $OUT/summary.txt
+  for cfg in "llama-3-8b gf4 6" "tinyllama-1.1b fp16 12" "mixtral-8x7b fp8 2" "dbrx-132b fp8 1" "mistral-7b fp16 4" "mistral-7b gf4 8"; do
+    timeout 300 python tools/tune.py $cfg brief >> $OUT/shapes.txt 2>&1
+  done
+  cat $OUT/shapes.txt >> $OUT/summary.txt
+fi
 echo "== bench (no cpu leg)" | tee -a $OUT/summary.txt
 timeout 600 python bench.py --no-cpu > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
 tail -c 2500 $OUT/bench.json >> $OUT/summary.txt; tail -5 $OUT/bench.err >> $OUT/summary.txt
