@@ -146,23 +146,39 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 			acc = __builtin_elementwise_fma(bf8x2_hi(v[i]), x.hi, acc);
 		}
 	} else {
-		// gf4: word = 8-bit e5m2 scale + 8 x 3-bit codes, w_k = (q_k - 4) * scale / -4
-		// (src/infer.c:37-40).  Sum the integer-weighted activations per word, scale once.
+		// gf4: word = 8-bit e5m2 scale S + 8 x 3-bit codes, w_k = (q_k - 4) * S / -4   (src/infer.c:37-40)
+		//   sum_k w_k x_k = (-S/4) * sum_k q_k x_k + S * sum_k x_k
+		// The codes are never converted: a pair (q_a, q_b) is moved into the two halves of a dword
+		// (6-bit extract, multiply by 0x2001, mask) where, read as binary16, q is the SUBNORMAL q * 2^-24
+		// -- exact -- and v_fma_mix_f32 multiplies a half by an fp32 activation into an fp32 accumulator
+		// in one instruction.  2.5 VALU ops per weight instead of 5; the 2^24 folds into the scale.
+		typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			unsigned w = v[j];
-			f32x4 x0 = xp[(2 * j) * 64], x1 = xp[(2 * j + 1) * 64];
-			float s = bf8_byte0(w) * -0.25f;
-			f32x2 q0 = {(float)((int)((w >> 8) & 7) - 4), (float)((int)((w >> 11) & 7) - 4)};
-			f32x2 q1 = {(float)((int)((w >> 14) & 7) - 4), (float)((int)((w >> 17) & 7) - 4)};
-			f32x2 q2 = {(float)((int)((w >> 20) & 7) - 4), (float)((int)((w >> 23) & 7) - 4)};
-			f32x2 q3 = {(float)((int)((w >> 26) & 7) - 4), (float)((int)((w >> 29) & 7) - 4)};
-			f32x2 t = q0 * x0.lo;
-			t = __builtin_elementwise_fma(q1, x0.hi, t);
-			t = __builtin_elementwise_fma(q2, x1.lo, t);
-			t = __builtin_elementwise_fma(q3, x1.hi, t);
-			f32x2 s2 = {s, s};
-			acc = __builtin_elementwise_fma(s2, t, acc);
+			const unsigned w = v[j];
+			const f32x4 x0 = xp[(2 * j) * 64], x1 = xp[(2 * j + 1) * 64];
+			const float S = bf8_byte0(w);
+			const float xsum = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
+			auto pair = [&](int k) -> h16x2 { // codes k and k+1 as two subnormal halves
+				unsigned t = __builtin_amdgcn_ubfe(w, 8 + 3 * k, 6);
+				t = (t * 0x2001u) & 0x00070007u; // v_mul_u32_u24 (t < 64)
+				return __builtin_bit_cast(h16x2, t);
+			};
+			const h16x2 p0 = pair(0), p1 = pair(2), p2 = pair(4), p3 = pair(6);
+			// ONE dependent chain per word: with two chains the SLP vectoriser pairs them into v_pk_fma_f32
+			// and pays a v_cvt_f32_f16 per code again; the other words / rows of the tile provide the ILP
+			float t = 0.f;
+			t = fmaf((float)p0[0], x0[0], t);
+			t = fmaf((float)p0[1], x0[1], t);
+			t = fmaf((float)p1[0], x0[2], t);
+			t = fmaf((float)p1[1], x0[3], t);
+			t = fmaf((float)p2[0], x1[0], t);
+			t = fmaf((float)p2[1], x1[1], t);
+			t = fmaf((float)p3[0], x1[2], t);
+			t = fmaf((float)p3[1], x1[3], t);
+			// (-S/4) * 2^24 * t + S * xsum
+			acc[0] = fmaf(S * -4194304.0f, t, acc[0]);
+			acc[1] = fmaf(S, xsum, acc[1]);
 		}
 	}
 	return acc;
@@ -687,63 +703,16 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	const int r = lane % LPR, g = lane / LPR;
 	const bool dvalid = r * 8 < a.head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
-	constexpr int EB = KVB / 8; // bytes per element
-	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const size_t rstride = (size_t)a.head_dim * EB;
-
-	// One round = UA wave-loads of K and of V.  Loads are unconditional: rows are clamped to the cache
-	// extent (seq_len rows exist; rows past kv_len hold zeros or stale values) and masked afterwards.
-	u32x4 kw[UA], vw[UA];
-	auto load_round = [&](int tb) {
-#pragma unroll
-		for (int u = 0; u < UA; ++u) {
-			int t = min(tb + u * NW * RPW + g, a.seq_len - 1);
-			if constexpr (KVB == 16) {
-				kw[u] = *(const u32x4*)(kbase + (size_t)t * rstride);
-				vw[u] = *(const u32x4*)(vbase + (size_t)t * rstride);
-			} else {
-				u32x2 k2 = *(const u32x2*)(kbase + (size_t)t * rstride);
-				u32x2 v2 = *(const u32x2*)(vbase + (size_t)t * rstride);
-				kw[u] = (u32x4){k2[0], k2[1], 0u, 0u};
-				vw[u] = (u32x4){v2[0], v2[1], 0u, 0u};
-			}
-		}
-	};
-
-	// The first round goes out before kv_len (a scalar load of TokState) and q have arrived: ts, q, K
-	// and V are all in flight together, so the kernel's latency chain is one memory round trip, not
-	// three.  (With n_split > 1 the split's first row depends on kv_len; long contexts are
-	// bandwidth-bound and do not care.)
-	float qraw[8]; // issued first: plain loads, consumed after the K/V round is in flight
-#pragma unroll
-	for (int i = 0; i < 8; ++i) {
-		qraw[i] = a.q[h * a.head_dim + d0 + i];
-	}
-	int tb = wave * RPW;
-	int t1;
-	if (a.n_split == 1) {
-		load_round(tb);
-		// kv_len through the VECTOR memory pipe, issued behind the K/V loads: it returns in order with them,
-		// so waiting for it costs nothing extra (a scalar load would be waited for ahead of the K/V issue;
-		// a volatile load becomes an uncached system-scope flat load).  Load + wait in ONE asm statement
-		// (cdna_hip_programming.md 5.7 form (i)); the wait covers the K/V round as well, by design.
-		int kvl;
-		const int* kvp = &a.ts->kv_len;
-		asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(kvl) : "v"(kvp) : "memory");
-		t1 = __builtin_amdgcn_readfirstlane(kvl);
-	} else {
-		const int kv_len = a.ts->kv_len;
-		const int chunk = (kv_len + a.n_split - 1) / a.n_split;
-		tb += split * chunk;
-		t1 = min(kv_len, split * chunk + chunk);
-		load_round(tb);
-	}
+	const int kv_len = a.ts->kv_len;
+	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
+	const int t0 = split * chunk;
+	const int t1 = min(kv_len, t0 + chunk);
 
 	float qv[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		qv[i] = dvalid ? qraw[i] : 0.f;
+		float qi = a.q[h * a.head_dim + d0 + i];
+		qv[i] = dvalid ? qi : 0.f;
 	}
 	const float sqrt_hd = sqrtf((float)a.head_dim);
 
@@ -753,39 +722,42 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 		o[i] = 0.f;
 	}
 
-	for (;;) {
+	constexpr int EB = KVB / 8; // bytes per element
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const size_t rstride = (size_t)a.head_dim * EB;
+
+	for (int tb = t0 + wave * RPW; tb < t1; tb += NW * RPW * UA) {
 		float kf[UA][8], vf[UA][8];
 		bool valid[UA];
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {
-			valid[u] = tb + u * NW * RPW + g < t1;
-			if constexpr (KVB == 16) {
+			int t = tb + u * NW * RPW + g;
+			valid[u] = t < t1;
+			t = min(t, kv_len - 1); // always load (clamped); masked below -- keeps the vmcnt bookkeeping exact
+			{
+				if constexpr (KVB == 16) {
+					u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
+					u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
 #pragma unroll
-				for (int i = 0; i < 4; ++i) {
-					kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[u][i] & 0xffff));
-					kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[u][i] >> 16));
-					vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[u][i] & 0xffff));
-					vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[u][i] >> 16));
-				}
-			} else {
+					for (int i = 0; i < 4; ++i) {
+						kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[i] & 0xffff));
+						kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[i] >> 16));
+						vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[i] & 0xffff));
+						vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[i] >> 16));
+					}
+				} else {
+					u32x2 kw = *(const u32x2*)(kbase + (size_t)t * rstride);
+					u32x2 vw = *(const u32x2*)(vbase + (size_t)t * rstride);
 #pragma unroll
-				for (int i = 0; i < 2; ++i) {
-					f32x2 k0 = bf8x2_lo(kw[u][i]), k1 = bf8x2_hi(kw[u][i]);
-					f32x2 v0 = bf8x2_lo(vw[u][i]), v1 = bf8x2_hi(vw[u][i]);
-					kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
-					vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+					for (int i = 0; i < 2; ++i) {
+						f32x2 k0 = bf8x2_lo(kw[i]), k1 = bf8x2_hi(kw[i]);
+						f32x2 v0 = bf8x2_lo(vw[i]), v1 = bf8x2_hi(vw[i]);
+						kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
+						vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+					}
 				}
 			}
-			if (!valid[u]) { // stale rows may hold anything, including Inf/NaN patterns
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					kf[u][i] = 0.f, vf[u][i] = 0.f;
-				}
-			}
-		}
-		const int tbn = tb + NW * RPW * UA;
-		if (tbn < t1) { // workgroup-uniform; short contexts finish in the first round and issue nothing more
-			load_round(tbn);
 		}
 		float s[UA];
 #pragma unroll
@@ -824,10 +796,6 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			}
 			m = mn;
 		}
-		if (tbn >= t1) {
-			break;
-		}
-		tb = tbn;
 	}
 
 	// merge the RPW lane groups of the wave

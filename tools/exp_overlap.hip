@@ -163,6 +163,186 @@ finish:
 	}
 }
 
+// mode 3: ONE persistent launch walks all phases; between phases a counter barrier whose latency is
+// covered by the next phase's prefetched tiles (all blocks resident: grid <= CUs x blocks/CU).
+struct Phase {
+	const void* w;
+	size_t ntasks;
+};
+
+__global__ __launch_bounds__(BLOCK) void k_persist(const Phase* ph, int nphases, float* x0, float* x1, unsigned* done, unsigned* timeout, int variant) {
+	__shared__ float red[NW];
+	__shared__ float xs[VEC];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const size_t W = (size_t)gridDim.x * NW;
+	for (int p = 0; p < nphases; ++p) {
+		const void* w = ph[p].w;
+		const size_t ntasks = ph[p].ntasks;
+		const float* xin = (p & 1) ? x1 : x0;
+		float* xout = (p & 1) ? x0 : x1;
+		size_t t = (size_t)blockIdx.x * NW + wave;
+		u32x4 tile[2][8];
+		size_t t0 = t < ntasks ? t : 0, t1 = t + W < ntasks ? t + W : 0;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			tile[0][u] = __builtin_nontemporal_load((gptr16)w + t0 * 512 + u * 64 + lane);
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			tile[1][u] = __builtin_nontemporal_load((gptr16)w + t1 * 512 + u * 64 + lane);
+		}
+		if (p > 0) {
+			if (threadIdx.x == 0) {
+				unsigned spins = 0;
+				while (__hip_atomic_load(done + (p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+					__builtin_amdgcn_s_sleep(2);
+					if (++spins > (1u << 18)) {
+						*timeout = 1;
+						break;
+					}
+				}
+				if (variant == 0) {
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+				}
+			}
+			__syncthreads();
+		}
+		float4 xv[2];
+		if (variant == 1) {
+			const unsigned long long* q = (const unsigned long long*)xin;
+			unsigned long long q0 = __hip_atomic_load(q + 2 * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			unsigned long long q1 = __hip_atomic_load(q + 2 * threadIdx.x + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			unsigned long long q2 = __hip_atomic_load(q + 2 * (threadIdx.x + BLOCK), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			unsigned long long q3 = __hip_atomic_load(q + 2 * (threadIdx.x + BLOCK) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			xv[0] = make_float4(__uint_as_float((unsigned)q0), __uint_as_float((unsigned)(q0 >> 32)), __uint_as_float((unsigned)q1), __uint_as_float((unsigned)(q1 >> 32)));
+			xv[1] = make_float4(__uint_as_float((unsigned)q2), __uint_as_float((unsigned)(q2 >> 32)), __uint_as_float((unsigned)q3), __uint_as_float((unsigned)(q3 >> 32)));
+		} else {
+			xv[0] = ((const float4*)xin)[threadIdx.x];
+			xv[1] = ((const float4*)xin)[threadIdx.x + BLOCK];
+		}
+		float ss = xv[0].x * xv[0].x + xv[0].y * xv[0].y + xv[0].z * xv[0].z + xv[0].w * xv[0].w + xv[1].x * xv[1].x + xv[1].y * xv[1].y +
+		           xv[1].z * xv[1].z + xv[1].w * xv[1].w;
+		ss = wave_sum(ss);
+		__syncthreads(); // xs / red of the previous phase are no longer read
+		if (lane == 0) {
+			red[wave] = ss;
+		}
+		((float4*)xs)[threadIdx.x] = xv[0];
+		((float4*)xs)[threadIdx.x + BLOCK] = xv[1];
+		__syncthreads();
+		float tot = 0.f;
+#pragma unroll
+		for (int i = 0; i < NW; ++i) {
+			tot += red[i];
+		}
+		const float scale = 1.0f / sqrtf(tot / VEC + 1e-5f);
+		bool go = true;
+		while (go) {
+#pragma unroll
+			for (int h = 0; h < 2; ++h) {
+				if (t >= ntasks) {
+					go = false;
+					break;
+				}
+				unsigned acc = 0;
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					acc += (tile[h][u][0] ^ tile[h][u][1]) + (tile[h][u][2] ^ tile[h][u][3]);
+				}
+				size_t t2 = t + 2 * W;
+				size_t tl = t2 < ntasks ? t2 : 0;
+#pragma unroll
+				for (int u = 0; u < 8; ++u) {
+					tile[h][u] = __builtin_nontemporal_load((gptr16)w + tl * 512 + u * 64 + lane);
+				}
+				float v = wave_sum((float)((acc & 0xff) + 1) * (1.0f / 4096.0f)) * scale * xs[(t * 7) % VEC];
+				if (lane == 0 && t < VEC) {
+					float r = v + (float)(t % 13);
+					if (variant == 1) {
+						__hip_atomic_store(xout + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					} else {
+						__hip_atomic_store(xout + t, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+				t += W;
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__hip_atomic_fetch_add(done + p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+
+extern "C" double exp_persist(int variant, int n_layers, int iters, double* checksum, int grid) {
+	static const size_t sizes[4] = {25165824, 16777216, 117440512, 58720256};
+	const int NK = 4, total = n_layers * NK;
+	hipStream_t s;
+	CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	std::vector<void*> w(total);
+	std::vector<Phase> hp(total);
+	for (int i = 0; i < total; ++i) {
+		CK(hipMalloc(&w[i], sizes[i % NK] + 65536));
+		CK(hipMemset(w[i], 0x11 + i / NK + i % NK, sizes[i % NK] + 65536));
+		hp[i].w = w[i];
+		hp[i].ntasks = sizes[i % NK] / 8192;
+	}
+	Phase* dp;
+	CK(hipMalloc(&dp, sizeof(Phase) * total));
+	CK(hipMemcpy(dp, hp.data(), sizeof(Phase) * total, hipMemcpyHostToDevice));
+	float* xbuf[2];
+	CK(hipMalloc(&xbuf[0], VEC * 4 + 65536));
+	CK(hipMalloc(&xbuf[1], VEC * 4 + 65536));
+	std::vector<float> x0(VEC);
+	for (int i = 0; i < VEC; ++i) {
+		x0[i] = 0.001f * (i % 97) + 0.5f;
+	}
+	unsigned *done, *timeout;
+	CK(hipMalloc(&done, 4 * (total + 1)));
+	CK(hipMalloc(&timeout, 4));
+	CK(hipMemset(timeout, 0, 4));
+	auto run = [&]() {
+		CK(hipMemcpyAsync(xbuf[0], x0.data(), VEC * 4, hipMemcpyHostToDevice, s));
+		CK(hipMemsetAsync(done, 0, 4 * (total + 1), s));
+		hipLaunchKernelGGL(k_persist, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout, variant);
+	};
+	run();
+	CK(hipDeviceSynchronize());
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	CK(hipEventRecord(e0, s));
+	for (int i = 0; i < iters; ++i) {
+		run();
+	}
+	CK(hipEventRecord(e1, s));
+	CK(hipDeviceSynchronize());
+	float ms = 0;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	std::vector<float> xf(VEC);
+	CK(hipMemcpy(xf.data(), xbuf[total & 1], VEC * 4, hipMemcpyDeviceToHost));
+	double cs = 0;
+	for (int i = 0; i < VEC; ++i) {
+		cs += xf[i] * (1 + i % 5);
+	}
+	*checksum = cs;
+	unsigned to = 0;
+	CK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost));
+	if (to) {
+		printf("  !! a bounded spin timed out (persistent variant %d)\n", variant);
+	}
+	for (void* p : w) {
+		CK(hipFree(p));
+	}
+	CK(hipFree(dp));
+	CK(hipFree(xbuf[0]));
+	CK(hipFree(xbuf[1]));
+	CK(hipFree(done));
+	CK(hipFree(timeout));
+	return (double)ms * 1e3 / ((double)iters * n_layers);
+}
+
 // concurrency probe: do two kernels on two streams run at the same time?
 __global__ void k_wait_flag(unsigned* flag, unsigned* seen, unsigned long long* cycles) {
 	if (threadIdx.x == 0) {

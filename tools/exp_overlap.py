@@ -18,9 +18,16 @@ lib.exp_chain.restype = C.c_double
 lib.exp_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
 lib.exp_concurrency(256)
 L = 8
+lib.exp_persist.restype = C.c_double
+lib.exp_persist.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
+for grid in (256, 512):
+    for variant in (0, 1):
+        cs = C.c_double(0)
+        us = lib.exp_persist(variant, L, 6, C.byref(cs), grid)
+        print(f"grid={grid} persistent variant={'acquire-fence' if variant == 0 else 'system-scope'}: {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
 names = {0: "plain", 1: "chained(acquire fence)", 2: "chained(system-scope loads)"}
-for grid in (128, 256):
-    for graph, mode in ((1, 0), (0, 0), (0, 1), (0, 2)):
+for grid in (256,):
+    for graph, mode in ((1, 0),):
         cs = C.c_double(0)
         us = lib.exp_chain(mode, graph, L, 6, C.byref(cs), grid)
         print(f"grid={grid} graph={graph} mode={names[mode]:28s}: {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
