@@ -274,17 +274,35 @@ void launch_ffn_up(Ctx* c, int l) {
 	}
 }
 
+// rows of the FFN-down matrix that are a whole multiple of 7 KiB chunks take the 2 x 7 tile shape
+inline bool ffn_down_u7(int hidden, int dbits) {
+	int nl = hidden / (128 / dbits);
+	return nl % 64 == 0 && (nl / 64) % 7 == 0;
+}
+
 template <int DB>
 void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
-	int ntasks = c->dim / Shape<DB>::NR;
+	const bool u7 = ffn_down_u7(c->hidden, DB);
+	int ntasks = c->dim / (u7 ? 2 : Shape<DB>::NR);
+	dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
+	size_t lds = lds_bytes<DB>(c->hidden);
+	const void* w2 = c->t->weights.w2[l];
+#define FD(V, U7) hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, V, U7>), grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active)
 	if (stage_v4(c->hidden, BLOCK)) {
-		hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, 4>), dim3(pick_blocks(ntasks, BLOCK / 64)), dim3(BLOCK), lds_bytes<DB>(c->hidden), g_stream, c->x, c->he,
-		                   c->t->weights.w2[l], c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+		if (u7) {
+			FD(4, true);
+		} else {
+			FD(4, false);
+		}
 	} else {
-		hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, 8>), dim3(pick_blocks(ntasks, BLOCK / 64)), dim3(BLOCK), lds_bytes<DB>(c->hidden), g_stream, c->x, c->he,
-		                   c->t->weights.w2[l], c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+		if (u7) {
+			FD(8, true);
+		} else {
+			FD(8, false);
+		}
 	}
+#undef FD
 }
 
 template <int DB>
@@ -490,8 +508,10 @@ void set_lds_attrs(Ctx* c) {
 	allow_lds(k_attn_out<DB, 8>, lds_bytes<DB>(c->q_dim));
 	allow_lds(k_ffn_up<DB, 4>, lds_bytes<DB>(c->dim));
 	allow_lds(k_ffn_up<DB, 8>, lds_bytes<DB>(c->dim));
-	allow_lds(k_ffn_down<DB, 512, 4>, lds_bytes<DB>(c->hidden));
-	allow_lds(k_ffn_down<DB, 512, 8>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_ffn_down<DB, 512, 4, false>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_ffn_down<DB, 512, 8, false>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_ffn_down<DB, 512, 4, true>, lds_bytes<DB>(c->hidden));
+	allow_lds(k_ffn_down<DB, 512, 8, true>, lds_bytes<DB>(c->hidden));
 	allow_lds(k_output<DB, 4>, lds_bytes<DB>(c->dim));
 	allow_lds(k_output<DB, 8>, lds_bytes<DB>(c->dim));
 }

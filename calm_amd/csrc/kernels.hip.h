@@ -153,32 +153,38 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		// -- exact -- and v_fma_mix_f32 multiplies a half by an fp32 activation into an fp32 accumulator
 		// in one instruction.  2.5 VALU ops per weight instead of 5; the 2^24 folds into the scale.
 		typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+		h16x2 p[4][4];
+		f32x4 xv[4][2];
+		float t[4], S[4], xsum[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const unsigned w = v[j];
-			const f32x4 x0 = xp[(2 * j) * 64], x1 = xp[(2 * j + 1) * 64];
-			const float S = bf8_byte0(w);
-			const float xsum = ((x0[0] + x0[1]) + (x0[2] + x0[3])) + ((x1[0] + x1[1]) + (x1[2] + x1[3]));
-			auto pair = [&](int k) -> h16x2 { // codes k and k+1 as two subnormal halves
-				unsigned t = __builtin_amdgcn_ubfe(w, 8 + 3 * k, 6);
-				t = (t * 0x2001u) & 0x00070007u; // v_mul_u32_u24 (t < 64)
-				return __builtin_bit_cast(h16x2, t);
-			};
-			const h16x2 p0 = pair(0), p1 = pair(2), p2 = pair(4), p3 = pair(6);
-			// ONE dependent chain per word: with two chains the SLP vectoriser pairs them into v_pk_fma_f32
-			// and pays a v_cvt_f32_f16 per code again; the other words / rows of the tile provide the ILP
-			float t = 0.f;
-			t = fmaf((float)p0[0], x0[0], t);
-			t = fmaf((float)p0[1], x0[1], t);
-			t = fmaf((float)p1[0], x0[2], t);
-			t = fmaf((float)p1[1], x0[3], t);
-			t = fmaf((float)p2[0], x1[0], t);
-			t = fmaf((float)p2[1], x1[1], t);
-			t = fmaf((float)p3[0], x1[2], t);
-			t = fmaf((float)p3[1], x1[3], t);
+			xv[j][0] = xp[(2 * j) * 64];
+			xv[j][1] = xp[(2 * j + 1) * 64];
+			S[j] = bf8_byte0(w);
+			xsum[j] = ((xv[j][0][0] + xv[j][0][1]) + (xv[j][0][2] + xv[j][0][3])) + ((xv[j][1][0] + xv[j][1][1]) + (xv[j][1][2] + xv[j][1][3]));
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { // codes 2k and 2k+1 as two subnormal halves
+				unsigned q = __builtin_amdgcn_ubfe(w, 8 + 6 * k, 6);
+				q = (q * 0x2001u) & 0x00070007u; // v_mul_u32_u24 (q < 64)
+				p[j][k] = __builtin_bit_cast(h16x2, q);
+			}
+			t[j] = 0.f;
+		}
+		// one dependent chain per word (two chains per word get SLP-paired into v_pk_fma_f32 and pay a
+		// v_cvt_f32_f16 per code again); the four words' chains are interleaved code-major for ILP
+#pragma unroll
+		for (int k = 0; k < 8; ++k) {
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				t[j] = fmaf((float)p[j][k >> 1][k & 1], xv[j][k >> 2][k & 3], t[j]);
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
 			// (-S/4) * 2^24 * t + S * xsum
-			acc[0] = fmaf(S * -4194304.0f, t, acc[0]);
-			acc[1] = fmaf(S, xsum, acc[1]);
+			acc[0] = fmaf(S[j] * -4194304.0f, t[j], acc[0]);
+			acc[1] = fmaf(S[j], xsum[j], acc[1]);
 		}
 	}
 	return acc;
@@ -235,28 +241,32 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
 // a clamped index costs a 64-bit address per load.)  Every device buffer is therefore allocated
 // with DEV_PAD bytes of slack (infer_hip.hip).  Vectors longer than 4*V*BLOCK floats fall back to
 // re-reading global memory for the excess.
-template <int V>
+// NORM: the kernel may have a norm weight to apply (then its loads are issued here too; a null normw at
+// run time -- parallel-residual models -- re-reads src instead, unconditionally all the same).
+template <int V, bool NORM>
 struct StageRegs {
 	float4 v[V];
-	float4 g[V]; // norm weight (or a harmless second copy of src when there is no norm)
+	float4 g[NORM ? V : 1];
 };
 
-template <int BLOCK, int V>
-__device__ __forceinline__ void stage_load(StageRegs<V>& sr, const float* __restrict__ src, const float* __restrict__ normw) {
+template <int BLOCK, int V, bool NORM>
+__device__ __forceinline__ void stage_load(StageRegs<V, NORM>& sr, const float* __restrict__ src, const float* __restrict__ normw) {
 	const float4* src4 = (const float4*)src + threadIdx.x;
-	const float4* g4 = (const float4*)(normw ? normw : src) + threadIdx.x;
 #pragma unroll
 	for (int i = 0; i < V; ++i) {
 		sr.v[i] = src4[i * BLOCK];
 	}
+	if constexpr (NORM) {
+		const float4* g4 = (const float4*)(normw ? normw : src) + threadIdx.x;
 #pragma unroll
-	for (int i = 0; i < V; ++i) {
-		sr.g[i] = g4[i * BLOCK];
+		for (int i = 0; i < V; ++i) {
+			sr.g[i] = g4[i * BLOCK];
+		}
 	}
 }
 
-template <int DB, int BLOCK, int V>
-__device__ __forceinline__ void stage_finish(const StageRegs<V>& sr, float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
+template <int DB, int BLOCK, int V, bool NORM>
+__device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
                                              int n, float eps, bool ln, float* dump) {
 	constexpr int MAXV = V;
 	const int tid = threadIdx.x;
@@ -299,7 +309,6 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V>& sr, float4* xs4
 		scale = 1.0f / sqrtf(var + eps);
 	}
 
-	const float4(&g)[MAXV] = sr.g;
 	auto emit = [&](int p, float4 t, float4 gw) {
 		if (normw) {
 			t.x = (t.x - mean) * scale * gw.x;
@@ -316,7 +325,7 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V>& sr, float4* xs4
 	for (int i = 0; i < MAXV; ++i) {
 		int p = tid + i * BLOCK;
 		if (p < n4) {
-			emit(p, v[i], g[i]);
+			emit(p, v[i], sr.g[NORM ? i : 0]);
 		}
 	}
 	for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
@@ -602,7 +611,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 			rows[r] = row_ptr(t * NR + r);
 		}
 	};
-	StageRegs<V> sr;
+	StageRegs<V, true> sr;
 	auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
 	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 			rows[r] = (const unsigned char*)wo + (size_t)(t * NR + r) * row_bytes;
 		}
 	};
-	StageRegs<V> sr;
+	StageRegs<V, false> sr;
 	auto pre = [&]() { stage_load<256>(sr, att, nullptr); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
 	auto aux_of = [&](int t, float(&aux)[NR]) { // the residual values this task adds to
@@ -977,7 +986,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		}
 	};
 
-	StageRegs<V> sr;
+	StageRegs<V, true> sr;
 	if (!moe) {
 		auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
@@ -1048,11 +1057,14 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
 // Experts are added in rank order (k = 0, 1, ...) by the same lane, so the sum order is the
 // reference's and is deterministic (the CUDA path's atomicAdd, src/infer.cu:618, is not).
-template <int DB, int BLOCK, int V>
+// U7: rows of 7k KiB (hidden 14336 at fp8 = 14 chunks, fp16 = 28, gf4 = 7): tiles of 2 rows x 7 chunks, so a
+// wave's first two steps -- issued before the prologue -- already cover 28 KiB, the whole task at fp8;
+// the long prologue of this kernel (staging the hidden-sized vector) then hides behind the full stream.
+template <int DB, int BLOCK, int V, bool U7>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int NR = U7 ? 2 : Shape<DB>::NR, U = U7 ? 7 : Shape<DB>::U;
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(hidden));
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 				rows[r] = wbase + (size_t)(t * NR + r) * row_bytes;
 			}
 		};
-		StageRegs<V> sr;
+		StageRegs<V, false> sr;
 		auto pre = [&]() { stage_load<BLOCK>(sr, he + (size_t)k * hidden, nullptr); };
 		auto stage = [&]() {
 			if (k > 0) {
@@ -1111,7 +1123,7 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 			rows[r] = (const unsigned char*)wcls + (size_t)j * row_bytes;
 		}
 	};
-	StageRegs<V> sr;
+	StageRegs<V, true> sr;
 	auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
 	auto no_aux = [&](int, float(&)[NR]) {};

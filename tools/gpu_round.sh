@@ -34,8 +34,11 @@ timeout 600 python tools/tune.py > $OUT/tune.txt 2>&1; cat $OUT/tune.txt >> $OUT
 echo "== rocprof kernel trace of the bench command" | tee -a $OUT/summary.txt
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --no-cpu --no-device-greedy --steps 64 --warmup 8 > $OUT/prof_bench.log 2>&1
 echo "exit $?" >> $OUT/summary.txt
-find $OUT/prof -name "*stats*" | head >> $OUT/summary.txt
-for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -30 $f >> $OUT/summary.txt; cp $f $OUT/kernel_stats.csv; done
-# the raw trace is large: keep only the stats
-find $OUT/prof -name "*kernel_trace.csv" -size +20M -delete
+echo "== rocprof PMC pass (FETCH_SIZE), its own run" | tee -a $OUT/summary.txt
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc -o fetch -- python bench.py --no-cpu --no-device-greedy --steps 8 --warmup 2 > $OUT/prof_pmc.log 2>&1
+echo "exit $?" >> $OUT/summary.txt
+python tools/prof_summary.py $OUT/prof $OUT/pmc --tag $TAG >> $OUT/summary.txt 2>&1
+mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/ 2>/dev/null
+# the raw traces are large: keep only what the summary needs
+find $OUT/prof $OUT/pmc -type f -size +30M -delete 2>/dev/null
 cat $OUT/summary.txt

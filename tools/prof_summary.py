@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories into the small summaries committed under profiles/.
+
+    python tools/prof_summary.py <kernel-trace dir> [<pmc dir>] --tag r01
+
+* kernel trace (rocprofv3 --kernel-trace --stats): per-kernel calls / total / average / min duration.
+  Handles both output flavours of this rocprofv3: CSV (*kernel_trace.csv) and the rocpd SQLite database.
+* PMC pass (rocprofv3 --pmc FETCH_SIZE --kernel-trace): average FETCH_SIZE per launch per kernel, converted
+  to bytes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE is in KiB and reports exactly
+  half of a wide coalesced stream on gfx950: bytes = FETCH_SIZE * 1024 * 2).
+Writes profiles/<tag>_kernel_stats.md and profiles/<tag>_pmc.json.
+"""
+import csv
+import glob
+import json
+import os
+import sqlite3
+import statistics
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").replace("calm::", "")
+
+
+def kernel_durations(d):
+    durs = defaultdict(list)
+    dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+    csvs = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if csvs:
+        for f in csvs:
+            for row in csv.DictReader(open(f)):
+                durs[short(row["Kernel_Name"])].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    elif dbs:
+        for f in dbs:
+            cur = sqlite3.connect(f).cursor()
+            for name, start, end in cur.execute("select name, start, end from kernels"):
+                durs[short(name)].append((end - start) / 1e3)
+    return durs
+
+
+def pmc_fetch(d):
+    out = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == "FETCH_SIZE":
+                out[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
+        cur = sqlite3.connect(f).cursor()
+        try:
+            rows = cur.execute("select k.name, p.value from pmc_events p join kernels k on p.event_id = k.id where p.name = 'FETCH_SIZE'")
+            for name, v in rows:
+                out[short(name)].append(float(v))
+        except sqlite3.Error:
+            pass
+    return out
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r01"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
+    durs = kernel_durations(args[0])
+    total = sum(sum(v) for v in durs.values())
+    lines = [f"# rocprofv3 --kernel-trace summary ({tag}); durations in microseconds", "",
+             "| kernel | calls | total us | % | avg us | median us | min us |", "|---|---|---|---|---|---|---|"]
+    for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
+        lines.append(f"| `{k}` | {len(v)} | {sum(v):.0f} | {100*sum(v)/total:.1f} | {sum(v)/len(v):.2f} | {statistics.median(v):.2f} | {min(v):.2f} |")
+    open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    if len(args) > 1:
+        fetch = pmc_fetch(args[1])
+        res = {}
+        for k, v in fetch.items():
+            res[k] = {"launches": len(v), "FETCH_SIZE_KiB_avg": sum(v) / len(v), "hbm_read_bytes_per_launch_corrected": sum(v) / len(v) * 1024 * 2}
+        json.dump(res, open(os.path.join(root, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+        for k, r in sorted(res.items(), key=lambda kv: -kv[1]["hbm_read_bytes_per_launch_corrected"]):
+            print(f"{k:40s} FETCH_SIZE avg {r['FETCH_SIZE_KiB_avg']:12.1f} KiB  -> {r['hbm_read_bytes_per_launch_corrected']/1e6:9.2f} MB/launch (x2 gfx950 correction)")
+
+
+if __name__ == "__main__":
+    main()
