@@ -133,21 +133,24 @@ Ctx* ctx_of(struct Transformer* t) {
 	return it->second;
 }
 
-// choose a grid for `ntasks` wave-tasks at `wpb` waves per workgroup: everything resident if it fits,
-// else a whole number of workgroups per CU that wastes the fewest wave-slots (ties: more waves)
+// Choose a grid for `ntasks` wave-tasks at `wpb` waves per workgroup: everything resident if it fits,
+// else a whole number b of workgroups per CU.  Two costs pull against each other -- idle wave-slots
+// in the last round (rounds * waves / ntasks) and too few waves to keep HBM busy (a wave holds 16 KiB
+// in flight; 4 waves per CU measured latency-bound: gf4 FFN-up ran at 2.6 TB/s on a "perfectly
+// balanced" b = 1 grid) -- so the waste is weighted by (1 + 1/(2b)).
 int pick_blocks(int ntasks, int wpb) {
 	int need = (ntasks + wpb - 1) / wpb;
 	if (need <= g_ncu * g_bpc) {
 		return need > 0 ? need : 1;
 	}
 	int best_b = 1;
-	double best_waste = 1e30;
+	double best = 1e30;
 	for (int b = 1; b <= g_bpc; ++b) {
 		long waves = (long)g_ncu * b * wpb;
 		long rounds = (ntasks + waves - 1) / waves;
-		double waste = (double)(rounds * waves) / ntasks;
-		if (waste <= best_waste + 1e-9) {
-			best_waste = waste;
+		double cost = (double)(rounds * waves) / ntasks * (1.0 + 0.5 / b);
+		if (cost <= best + 1e-9) {
+			best = cost;
 			best_b = b;
 		}
 	}

@@ -128,7 +128,10 @@ __device__ __forceinline__ float decode_elem(const void* w, size_t idx) {
 // lane is at xp[i * 64].
 template <int DB>
 __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
+	// (fp16 / fp8: a second, call-local accumulator pair halves the length of the dependent v_pk_fma chain
+	// -- PMC showed 30-40 % of wave cycles in issue stalls with one chain per row)
 	if constexpr (DB == 16) {
+		f32x2 acc_b = {0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
 			f32x4 x = xp[i * 64];
@@ -136,15 +139,18 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 			f32x2 a = {half_bits_to_float((unsigned short)(w0 & 0xffff)), half_bits_to_float((unsigned short)(w0 >> 16))};
 			f32x2 b = {half_bits_to_float((unsigned short)(w1 & 0xffff)), half_bits_to_float((unsigned short)(w1 >> 16))};
 			acc = __builtin_elementwise_fma(a, x.lo, acc);
-			acc = __builtin_elementwise_fma(b, x.hi, acc);
+			acc_b = __builtin_elementwise_fma(b, x.hi, acc_b);
 		}
+		acc += acc_b;
 	} else if constexpr (DB == 8) {
+		f32x2 acc_b = {0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
 			f32x4 x = xp[i * 64];
 			acc = __builtin_elementwise_fma(bf8x2_lo(v[i]), x.lo, acc);
-			acc = __builtin_elementwise_fma(bf8x2_hi(v[i]), x.hi, acc);
+			acc_b = __builtin_elementwise_fma(bf8x2_hi(v[i]), x.hi, acc_b);
 		}
+		acc += acc_b;
 	} else {
 		// gf4: word = 8-bit e5m2 scale S + 8 x 3-bit codes, w_k = (q_k - 4) * S / -4   (src/infer.c:37-40)
 		//   sum_k w_k x_k = (-S/4) * sum_k q_k x_k + S * sum_k x_k
