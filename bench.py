@@ -149,6 +149,15 @@ def main():
         us, b = be.stage_us(i, 8 if i != 5 else 1)
         stage_report[name] = {"us": round(us, 2), "GBps": round(b / us / 1e3, 1) if us > 0 else None, "bytes": int(b)}
     dom = stage_report["ffn_up"]
+    # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own
+    # run, x1024 x2 per MI355X_MICROARCH.md; tools/prof_summary.py) -- only for the shape it was measured on
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
+    if os.path.exists(pmc_file) and args.model == "mistral-7b" and args.dtype == "fp8":
+        pmc = json.load(open(pmc_file))
+        for k, v in pmc.items():
+            if k.startswith("k_ffn_up<8"):
+                traffic = int(v["hbm_read_bytes_per_launch_corrected"])
     roofline = {
         "bound": "hbm",
         "kernel": "k_ffn_up",
@@ -156,7 +165,7 @@ def main():
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
         "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4),
-        "traffic": None,
+        "traffic": traffic,
         "bytes_per_launch": dom["bytes"],
         "us_per_launch": dom["us"],
     }
