@@ -49,7 +49,7 @@ def pmc_fetch(d):
     for f in glob.glob(os.path.join(d, "**", "*.db"), recursive=True):
         cur = sqlite3.connect(f).cursor()
         try:
-            rows = cur.execute("select k.name, p.value from pmc_events p join kernels k on p.event_id = k.id where p.name = 'FETCH_SIZE'")
+            rows = cur.execute("select name, counter_value from pmc_events where counter_name = 'FETCH_SIZE'")
             for name, v in rows:
                 out[short(name)].append(float(v))
         except sqlite3.Error:
