@@ -424,13 +424,14 @@ void* begin_func(Ctx* c) {
 	}
 }
 
-void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp) {
+void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool embed = true) {
 	struct Config* p = &c->t->config;
 	// rolling KV buffer with attention sinks (src/infer.c:329-332)
 	int kv_sink = pos >= p->seq_len ? CALM_KV_SINKS : 0;
 	int kv_pos = kv_sink + (pos - kv_sink) % (p->seq_len - kv_sink);
 	int kv_len = pos >= p->seq_len ? p->seq_len : pos + 1;
 	CALM_REQUIRE(tok_src || (token >= 0 && token < c->vocab), "token out of range");
+	CALM_REQUIRE(!embed || c->t->weights.token_embedding_table, "this stage has no embedding table");
 	CALM_REQUIRE(pos >= 0, "negative position");
 
 	sp.sink = kv_sink > 0;
@@ -441,6 +442,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp) {
 	sp.chained = tok_src != nullptr;
 
 	c->ba.token = token;
+	c->ba.embed = embed ? c->t->weights.token_embedding_table : nullptr;
 	c->ba.tok_src = tok_src;
 	c->ba.pos = pos;
 	c->ba.kv_sink = kv_sink;
@@ -767,6 +769,25 @@ extern "C" float* forward_hip(struct Transformer* t, int token, int pos, unsigne
 	}
 	HIP_CHECK(hipStreamSynchronize(g_stream));
 	return c->logits_h;
+}
+
+extern "C" float* forward_stage_hip(struct Transformer* t, int token, int pos, unsigned flags, unsigned stage_flags) {
+	Ctx* c = ctx_of(t);
+	const bool first = (stage_flags & CALM_STAGE_FIRST) != 0, last = (stage_flags & CALM_STAGE_LAST) != 0;
+	StepPlan sp = {};
+	sp.kv_only = !last || (flags & FF_UPDATE_KV_ONLY) != 0;
+	sp.argmax = false;
+	sp.copy_logits = !sp.kv_only;
+	CALM_REQUIRE(sp.kv_only || (t->weights.wcls && t->weights.rms_final_weight), "the last stage needs the final norm and the classifier");
+	run_step(c, token, nullptr, pos, sp, first);
+	HIP_CHECK(hipStreamSynchronize(g_stream)); // state.x is complete: the host may hand it to the next stage
+	return sp.kv_only ? NULL : c->logits_h;
+}
+
+extern "C" void copy_hip(void* dst, const void* src, size_t size) {
+	init_hip();
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyDefault));
 }
 
 extern "C" float* decode_greedy_hip(struct Transformer* t, int token, int pos, int n_steps, int* out_tokens) {

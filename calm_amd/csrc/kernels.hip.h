@@ -537,7 +537,7 @@ __global__ void k_begin_token(TokState* ts, int token, const int* tok_src, int p
 		ts->kv_pos = kv_pos;
 		ts->kv_len = kv_len;
 	}
-	if (i < dim) {
+	if (embed && i < dim) { // embed == nullptr: a later pipeline stage; x already holds the residual stream
 		x[i] = decode_elem<DB>(embed, (size_t)token * dim + i);
 	}
 	if (i < half_hd) {

@@ -48,6 +48,8 @@ def load_lib() -> C.CDLL:
         "release_hip": (None, [T]),
         "free_hip": (None, [C.c_void_p]),
         "decode_greedy_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "forward_stage_hip": (fp, [T, C.c_int, C.c_int, C.c_uint, C.c_uint]),
+        "copy_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "perf_stage_hip": (C.c_double, [T, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
         "calm_hip_test_matvec": (None, [C.c_int, C.c_void_p, fp, fp, C.c_int, C.c_int]),
         "calm_hip_test_norm_matvec": (None, [C.c_int, C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int]),
@@ -67,7 +69,7 @@ def load_lib() -> C.CDLL:
 
 EXPORTS = [
     "init_hip", "upload_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
-    "free_hip", "decode_greedy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
+    "free_hip", "decode_greedy_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
     "calm_hip_test_argmax", "download_hip", "calm_hip_read_kv", "calm_hip_membench",
 ]
 
@@ -136,7 +138,7 @@ class HostModel:
 
         n_bytes, n_params = count("model.")
         n_bw = n_bytes - count("model.embed.")[0]
-        if "model.output.weight" not in self.tensors:
+        if "model.output.weight" not in self.tensors and "model.embed.weight" in self.tensors:
             n_bw += self.tensors["model.embed.weight"].nbytes
         if self.config.n_experts:
             mlp = count("model.layers.", ".mlp.w")[0]
@@ -157,7 +159,8 @@ class HostModel:
         w.dbits = self.dbits
         cfg = self.config
         has = lambda n: n in self.tensors
-        w.token_embedding_table = addr("model.embed.weight")
+        if has("model.embed.weight"):  # absent on the later stages of a layer pipeline
+            w.token_embedding_table = addr("model.embed.weight")
         for l in range(cfg.n_layers):
             p = f"model.layers.{l}."
             w.rms_att_weight[l] = addr(p + "attn.norm.weight")
@@ -174,8 +177,9 @@ class HostModel:
             w.w1[l] = addr(p + "mlp.w1.weight")
             w.w2[l] = addr(p + "mlp.w2.weight")
             w.w3[l] = addr(p + "mlp.w3.weight")
-        w.rms_final_weight = addr("model.norm.weight")
-        w.wcls = addr("model.output.weight") if has("model.output.weight") else w.token_embedding_table
+        if has("model.norm.weight"):  # absent on all but the last stage of a layer pipeline
+            w.rms_final_weight = addr("model.norm.weight")
+            w.wcls = addr("model.output.weight") if has("model.output.weight") else w.token_embedding_table
         t.state.kvbits = kvbits
         t.n_params, t.n_bytes, t.n_bandwidth = self.accounting()
 
@@ -208,6 +212,19 @@ class HipBackend:
         if not p:
             return None
         return np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def forward_stage(self, token: int, pos: int, flags: int, stage_flags: int) -> Optional[np.ndarray]:
+        p = self.lib.forward_stage_hip(C.byref(self.t), token, pos, flags, stage_flags)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def export_x(self, dst_ptr: int) -> None:
+        """state.x -> a caller buffer (device or host pointer)"""
+        self.lib.copy_hip(dst_ptr, self.t.state.x, self.model.config.dim * 4)
+
+    def import_x(self, src_ptr: int) -> None:
+        self.lib.copy_hip(self.t.state.x, src_ptr, self.model.config.dim * 4)
 
     def decode_greedy(self, token: int, pos: int, n_steps: int):
         out = (C.c_int * n_steps)()

@@ -73,6 +73,24 @@ void free_hip(void* device);
  * token ids to out_tokens; returns state.logits of the last step. */
 float* decode_greedy_hip(struct Transformer* transformer, int token, int pos, int n_steps, int* out_tokens);
 
+/* Layer-pipeline stage (for models beyond one GPU's 288 GB): `transformer` describes
+ * only THIS stage's slice of the model -- config.n_layers = the stage's layer count, weights indexed from 0,
+ * token_embedding_table set on the first stage only, rms_final_weight / wcls on the last stage only.
+ *   CALM_STAGE_FIRST : embed `token` into state.x; otherwise state.x must already hold the residual stream
+ *                      received from the previous stage (copy it in with copy_hip).
+ *   CALM_STAGE_LAST  : final norm + classifier; returns state.logits.  Other stages return NULL.
+ * Always synchronises before returning, so state.x (dim floats, device memory) can be sent on.
+ * forward_hip(t, ...) == forward_stage_hip(t, ..., CALM_STAGE_FIRST | CALM_STAGE_LAST). */
+enum CalmHipStageFlags {
+	CALM_STAGE_FIRST = 1 << 0,
+	CALM_STAGE_LAST = 1 << 1,
+};
+float* forward_stage_hip(struct Transformer* transformer, int token, int pos, unsigned flags, unsigned stage_flags);
+
+/* synchronous copy between any two of {device, host} buffers (hipMemcpyDefault); used to move state.x in and
+ * out of the communication buffers of a pipeline */
+void copy_hip(void* dst, const void* src, size_t size);
+
 /* Stage timer for roofline reporting: launches the kernel of `stage` for every layer in turn
  * (so successive launches stream different weights and cannot hit the 256 MiB Infinity Cache),
  * `iters` sweeps, bracketed by hipEvents on the backend's own stream.

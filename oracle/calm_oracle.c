@@ -326,8 +326,11 @@ void oracle_release(struct Transformer* t) {
 	memset(s, 0, sizeof(*s));
 }
 
-/* One decode step; src/infer.c:311-472.  Weights are HOST pointers here. */
-float* oracle_forward(struct Transformer* t, int token, int pos, unsigned flags) {
+/* One decode step; src/infer.c:311-472.  Weights are HOST pointers here.
+ * stage_flags (bit 0 = first stage: embed the token, bit 1 = last stage: final norm + classifier) let the
+ * same walk serve as one stage of a layer pipeline whose `t` describes only that stage's layers; the
+ * reference has no such split -- with both bits set this IS its forward(). */
+float* oracle_forward_stage(struct Transformer* t, int token, int pos, unsigned flags, unsigned stage_flags) {
 	struct Config* p = &t->config;
 	struct Weights* w = &t->weights;
 	struct RunState* s = &t->state;
@@ -344,8 +347,10 @@ float* oracle_forward(struct Transformer* t, int token, int pos, unsigned flags)
 	oracle_kv_slots(pos, p->seq_len, &kv_sink, &kv_pos, &kv_len);
 
 	/* embedding row -> x; src/infer.c:334-347 */
-	for (int i = 0; i < dim; ++i) {
-		x[i] = oracle_decode_weight(w->token_embedding_table, dbits, (size_t)token * dim + i);
+	if (stage_flags & 1u) {
+		for (int i = 0; i < dim; ++i) {
+			x[i] = oracle_decode_weight(w->token_embedding_table, dbits, (size_t)token * dim + i);
+		}
 	}
 
 	for (int l = 0; l < p->n_layers; l++) {
@@ -436,13 +441,17 @@ float* oracle_forward(struct Transformer* t, int token, int pos, unsigned flags)
 		}
 	}
 
-	if (flags & FF_UPDATE_KV_ONLY) { /* :460-463 */
+	if ((flags & FF_UPDATE_KV_ONLY) || !(stage_flags & 2u)) { /* :460-463 */
 		return NULL;
 	}
 
 	oracle_norm(x, x, w->rms_final_weight, dim, p->norm_eps, p->norm_ln);    /* :466 */
 	oracle_matvec(s->logits, x, w->wcls, NULL, dim, p->vocab_size, dbits); /* :469 */
 	return s->logits;
+}
+
+float* oracle_forward(struct Transformer* t, int token, int pos, unsigned flags) {
+	return oracle_forward_stage(t, token, pos, flags, 3u);
 }
 
 /* greedy sampler: first index of the strict maximum; reference src/sampler.c:34-42 */

@@ -73,6 +73,8 @@ def lib() -> C.CDLL:
         L.oracle_release.argtypes = [_T]
         L.oracle_forward.restype = _fp
         L.oracle_forward.argtypes = [_T, C.c_int, C.c_int, C.c_uint]
+        L.oracle_forward_stage.restype = _fp
+        L.oracle_forward_stage.argtypes = [_T, C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.oracle_argmax.restype = C.c_int
         L.oracle_argmax.argtypes = [_fp, C.c_int]
         _lib = L
@@ -173,6 +175,19 @@ class OracleBackend(_CpuBackend):
     def __init__(self, model: HostModel):
         L = lib()
         super().__init__(model, L.oracle_prepare, L.oracle_forward, L.oracle_release)
+
+    # the pipeline-stage surface of calm_amd.host.HipBackend, on host memory (tests of the stage protocol)
+    def forward_stage(self, token: int, pos: int, flags: int, stage_flags: int):
+        p = lib().oracle_forward_stage(C.byref(self.t), token, pos, flags, stage_flags)
+        if not p:
+            return None
+        return np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def export_x(self, dst_ptr: int) -> None:
+        C.memmove(dst_ptr, self.t.state.x, self.model.config.dim * 4)
+
+    def import_x(self, src_ptr: int) -> None:
+        C.memmove(self.t.state.x, src_ptr, self.model.config.dim * 4)
 
 
 _ref = None

@@ -316,3 +316,30 @@ def test_fp8_kv_cache_tracks_the_fp16_cache(hiplib):
     finally:
         b16.close()
         b8.close()
+
+
+@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "bias_tied_gf4"])
+def test_pipeline_stages_on_one_gpu_equal_the_unsharded_step(hiplib, case):
+    """forward_stage_hip: the model cut into two layer stages (each its own struct Transformer with its own KV
+    slice), x handed from stage 0 to stage 1 through copy_hip -- the data path of calm_amd/pipeline.py without
+    the transport -- reproduces the reference logits"""
+    import ctypes
+
+    from calm_amd.pipeline import stage_model
+
+    model, z = load_golden(case)
+    (m0, f0), (m1, f1) = stage_model(model, 0, 2), stage_model(model, 1, 2)
+    b0, b1 = HipBackend(m0), HipBackend(m1)
+    try:
+        hand = np.zeros(model.config.dim, dtype=np.float32)  # a host buffer standing in for the RCCL message
+        worst = 0.0
+        for pos, tok in enumerate(z["tokens"][:12]):
+            assert b0.forward_stage(int(tok), pos, 0, f0) is None
+            b0.export_x(hand.ctypes.data)
+            b1.import_x(hand.ctypes.data)
+            lg = b1.forward_stage(int(tok), pos, 0, f1)
+            worst = max(worst, rel_err(lg, z["logits"][pos]))
+        assert worst < LOGIT_TOL, worst
+    finally:
+        b0.close()
+        b1.close()
