@@ -121,6 +121,16 @@ __device__ __forceinline__ float decode_elem(const void* w, size_t idx) {
 	}
 }
 
+// acc + (binary16 in the low / high half of h2) * x, fp32 result: one VALU instruction, no conversion
+__device__ __forceinline__ float fma_mix_lo(unsigned h2, float x, float acc) {
+	asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(x));
+	return acc;
+}
+__device__ __forceinline__ float fma_mix_hi(unsigned h2, float x, float acc) {
+	asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(x));
+	return acc;
+}
+
 // acc += dot(16-byte lane-load `v`, its G activations), as a 2-wide accumulator (even/odd columns)
 // so that every multiply-add is a v_pk_fma_f32 on register pairs that are already adjacent: the
 // converted weight pair, the activation pair from ds_read_b128, the accumulator pair.
@@ -158,8 +168,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		// (6-bit extract, multiply by 0x2001, mask) where, read as binary16, q is the SUBNORMAL q * 2^-24
 		// -- exact -- and v_fma_mix_f32 multiplies a half by an fp32 activation into an fp32 accumulator
 		// in one instruction.  2.5 VALU ops per weight instead of 5; the 2^24 folds into the scale.
-		typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-		h16x2 p[4][4];
+		unsigned p[4][4];
 		f32x4 xv[4][2];
 		float t[4], S[4], xsum[4];
 #pragma unroll
@@ -170,27 +179,26 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 			S[j] = bf8_byte0(w);
 			xsum[j] = ((xv[j][0][0] + xv[j][0][1]) + (xv[j][0][2] + xv[j][0][3])) + ((xv[j][1][0] + xv[j][1][1]) + (xv[j][1][2] + xv[j][1][3]));
 #pragma unroll
-			for (int k = 0; k < 4; ++k) { // codes 2k and 2k+1 as two subnormal halves
+			for (int k = 0; k < 4; ++k) { // codes 2k and 2k+1 as two subnormal halves of one dword
 				unsigned q = __builtin_amdgcn_ubfe(w, 8 + 6 * k, 6);
-				q = (q * 0x2001u) & 0x00070007u; // v_mul_u32_u24 (q < 64)
-				p[j][k] = __builtin_bit_cast(h16x2, q);
+				p[j][k] = (q * 0x2001u) & 0x00070007u; // v_mul_u32_u24 (q < 64)
 			}
 			t[j] = 0.f;
 		}
-		// one dependent chain per word (two chains per word get SLP-paired into v_pk_fma_f32 and pay a
-		// v_cvt_f32_f16 per code again); the four words' chains are interleaved code-major for ILP
+		// v_fma_mix_f32 is written as (pure, non-volatile) inline asm: left to itself the SLP vectoriser
+		// keeps re-pairing these chains into v_pk_fma_f32 and converts every code with v_cvt_f32_f16 again.
+		// One chain per word; the four words' chains are interleaved code-major for ILP.
 #pragma unroll
 		for (int k = 0; k < 8; ++k) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
-				t[j] = fmaf((float)p[j][k >> 1][k & 1], xv[j][k >> 2][k & 3], t[j]);
+				t[j] = (k & 1) ? fma_mix_hi(p[j][k >> 1], xv[j][k >> 2][k & 3], t[j]) : fma_mix_lo(p[j][k >> 1], xv[j][k >> 2][k & 3], t[j]);
 			}
 		}
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			// (-S/4) * 2^24 * t + S * xsum
-			acc[0] = fmaf(S[j] * -4194304.0f, t[j], acc[0]);
-			acc[1] = fmaf(S[j], xsum[j], acc[1]);
+			// (-S/4) * 2^24 * t + S * xsum  =  S * (xsum - 2^22 t): two fmas on one chain
+			acc[0] = fmaf(S[j], fmaf(t[j], -4194304.0f, xsum[j]), acc[0]);
 		}
 	}
 	return acc;

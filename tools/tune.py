@@ -30,6 +30,14 @@ for kv in ((256,) if brief else (128, 256)):
             row.append(f"{st} {us:6.2f}us {b/us/1e3:6.0f}GB/s")
         print(f"bpc={bpc}: " + " | ".join(row), flush=True)
     lib.calm_hip_configure(b"bpc", 2)
+if not brief or os.environ.get("LONGCTX"):
+    # long context: the last 32 positions of a 4096 window (the reference README's "last 32" column)
+    generate(be, model, [17], 8, pos_offset=4000)
+    t0 = time.perf_counter()
+    _, st = generate(be, model, [17], 32, pos_offset=4008)
+    dt = time.perf_counter() - t0
+    us, b = be.stage_us(1, 6)
+    print(f"last-32 @pos~4040: {32/dt:8.1f} tok/s ({dt/32*1e6:7.1f} us/token, L={L}); attn stage {us:6.2f}us {b/us/1e3:6.0f}GB/s")
 for graph in ((1,) if brief else (1, 0)):
     lib.calm_hip_configure(b"graph", graph)
     generate(be, model, [17], 16)
