@@ -35,14 +35,16 @@ def cpu_baseline(spec, dtype, seed, n_tokens, first_token):
     from calm_amd.host import HostModel
     from oracle import oracle  # test infrastructure used as the reported CPU baseline only
 
-    # thread count: the reference's own default (src/infer.c:171-176: half the logical CPUs) unless
-    # OMP_NUM_THREADS is already set by the caller
-    cores = int(os.environ.get("OMP_NUM_THREADS", max((os.cpu_count() or 2) // 2, 1)))
+    # thread count: the reference's own default is half the logical CPUs (src/infer.c:171-176); on the
+    # 256-thread GPU hosts that many threads over a 1-2 GB sample measured erratic (0.7-2.3 tok/s run to
+    # run: one OpenMP region per matmul, first-touch placement), so the sample is capped at 32 threads
+    # unless OMP_NUM_THREADS is set by the caller
+    cores = int(os.environ.get("OMP_NUM_THREADS", max(min((os.cpu_count() or 2) // 2, 32), 1)))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     kind = "reference" if oracle.have_ref() else "port"
     times = {}
     logits_ref = None
-    for L in (2, 6):
+    for L in (2, 6):  # sample sizes: 0.57 GB and 1.44 GB of weights per token
         tensors, md = cf.synth_model_big(spec, dtype, seed, n_layers=L)
         model = HostModel(tensors, md)
         be = oracle.RefBackend(model) if kind == "reference" else oracle.OracleBackend(model)
