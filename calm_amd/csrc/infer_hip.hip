@@ -53,7 +53,8 @@ int g_ncu = 256;
 int g_bpc = 2;       // cap on resident 256-thread workgroups per CU when sizing grids (measured: 2 beats 3 and 4)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
-int g_split_t = 1024; // kv positions per attention split
+int g_split_t = 128;   // kv positions per attention split (one round of the 8-wave GQA kernel)
+int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
 char g_devname[256] = "none";
 
 int env_int(const char* name, int dflt) {
@@ -221,10 +222,22 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.partial = c->partial;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
-	hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads * n_split), dim3(ATTN_BLOCK), 0, g_stream, a);
-	if (n_split > 1) {
-		hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	if (n_split == 1) {
+		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
+		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a);
+		return;
 	}
+	// long context: K/V rows loaded once per kv head for up to 4 query heads, kv range split, then merged
+	const int qh = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
+	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
+	if (qh == 4) {
+		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 4>), grid, block, 0, g_stream, a);
+	} else if (qh == 2) {
+		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 2>), grid, block, 0, g_stream, a);
+	} else {
+		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1>), grid, block, 0, g_stream, a);
+	}
+	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
 }
 
 template <int KVB>
@@ -325,6 +338,14 @@ void launch_output(Ctx* c) {
 
 void launch_argmax(Ctx* c) {
 	hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, g_stream, c->logits_d, c->vocab, c->next_tok, c->trace, c->trace_count);
+}
+
+int attn_splits(int kv_len) {
+	if (kv_len <= g_split_min) {
+		return 1;
+	}
+	int n = (kv_len + g_split_t - 1) / g_split_t;
+	return n > MAX_SPLIT ? MAX_SPLIT : n;
 }
 
 // algorithmic bytes per launch, the reference's accounting (src/infer.cu:685-699)
@@ -435,10 +456,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	CALM_REQUIRE(pos >= 0, "negative position");
 
 	sp.sink = kv_sink > 0;
-	sp.n_split = kv_len <= g_split_t ? 1 : (kv_len + g_split_t - 1) / g_split_t;
-	if (sp.n_split > MAX_SPLIT) {
-		sp.n_split = MAX_SPLIT;
-	}
+	sp.n_split = attn_splits(kv_len);
 	sp.chained = tok_src != nullptr;
 
 	c->ba.token = token;
@@ -551,6 +569,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_bpc;
 	} else if (!strcmp(key, "split_t")) {
 		slot = &g_split_t;
+	} else if (!strcmp(key, "split_min")) {
+		slot = &g_split_min;
 	} else {
 		return -1;
 	}
@@ -586,6 +606,7 @@ extern "C" void init_hip(void) {
 	g_use_graph = env_int("CALM_HIP_GRAPH", 1);
 	g_prof = env_int("CALM_HIP_PROF", 0);
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
+	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
 		printf("# HIP: %s (%s), %d CUs, %.1f GiB, device %d\n", prop.name, prop.gcnArchName, g_ncu, (double)prop.totalGlobalMem / (1024.0 * 1024 * 1024), dev);
 	}
@@ -840,7 +861,7 @@ extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, ui
 	if (bytes_per_launch) {
 		*bytes_per_launch = stage_bytes(c, stage, kv_len);
 	}
-	int n_split = kv_len <= g_split_t ? 1 : (kv_len + g_split_t - 1) / g_split_t;
+	int n_split = attn_splits(kv_len);
 	auto one = [&](int l) {
 #define ST(db, kvb)                                  \
 	if (c->dbits == db && c->kvbits == kvb) {        \

@@ -881,6 +881,190 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	}
 }
 
+// Long-context attention: one workgroup (8 waves) per (kv head, group of QH query heads, kv split).
+// The K/V rows of the split are loaded ONCE and used for all QH query heads that share the kv head
+// (GQA), so a 4096-position context is 8 kv heads x 32 splits = 256 workgroups whose every wave has its
+// whole share -- 4 K + 4 V wave-loads -- in flight at once: one memory round trip instead of the
+// per-head kernel's 4 serial rounds with 4x redundant reads.  Always writes split partials (o, m, l per
+// query head) for k_attn_merge.  Same arithmetic as k_attn.
+constexpr int ATTN_GQA_BLOCK = 512;
+
+template <int KVB, int LPR, int QH>
+__global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(AttnArgs a) {
+	constexpr int RPW = 64 / LPR;
+	constexpr int NW = ATTN_GQA_BLOCK / 64;
+	constexpr int UA = 4;
+	__shared__ float sm_m[QH][NW], sm_l[QH][NW];
+	__shared__ float sm_o[QH][NW][LPR * 8];
+
+	const int lane = lane_id(), wave = wave_id();
+	const int qgroups = a.kv_mul / QH;
+	const int split = blockIdx.x % a.n_split;
+	const int qg = (blockIdx.x / a.n_split) % qgroups;
+	const int kvh = blockIdx.x / (a.n_split * qgroups);
+	const int h0 = kvh * a.kv_mul + qg * QH; // first of this block's QH query heads
+	const int r = lane % LPR, g = lane / LPR;
+	const bool dvalid = r * 8 < a.head_dim;
+	const int d0 = dvalid ? r * 8 : 0;
+	const int kv_len = a.ts->kv_len;
+	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
+	const int t0 = split * chunk;
+	const int t1 = min(kv_len, t0 + chunk);
+
+	float qv[QH][8];
+#pragma unroll
+	for (int q = 0; q < QH; ++q) {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			float qi = a.q[(h0 + q) * a.head_dim + d0 + i];
+			qv[q][i] = dvalid ? qi : 0.f;
+		}
+	}
+	const float sqrt_hd = sqrtf((float)a.head_dim);
+	float m[QH], l[QH], o[QH][8];
+#pragma unroll
+	for (int q = 0; q < QH; ++q) {
+		m[q] = -INFINITY, l[q] = 0.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			o[q][i] = 0.f;
+		}
+	}
+
+	constexpr int EB = KVB / 8;
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const size_t rstride = (size_t)a.head_dim * EB;
+
+	for (int tb = t0 + wave * RPW; tb < t1; tb += NW * RPW * UA) {
+		float kf[UA][8], vf[UA][8];
+		bool valid[UA];
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			int t = tb + u * NW * RPW + g;
+			valid[u] = t < t1;
+			t = min(t, kv_len - 1); // always load (clamped), mask below
+			if constexpr (KVB == 16) {
+				u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
+				u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[i] & 0xffff));
+					kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[i] >> 16));
+					vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[i] & 0xffff));
+					vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[i] >> 16));
+				}
+			} else {
+				u32x2 kw = *(const u32x2*)(kbase + (size_t)t * rstride);
+				u32x2 vw = *(const u32x2*)(vbase + (size_t)t * rstride);
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					f32x2 k0 = bf8x2_lo(kw[i]), k1 = bf8x2_hi(kw[i]);
+					f32x2 v0 = bf8x2_lo(vw[i]), v1 = bf8x2_hi(vw[i]);
+					kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
+					vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+				}
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < QH; ++q) {
+			float sc[UA];
+#pragma unroll
+			for (int u = 0; u < UA; ++u) {
+				float d = 0.f;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					d = fmaf(qv[q][i], kf[u][i], d);
+				}
+#pragma unroll
+				for (int ofs = LPR / 2; ofs > 0; ofs >>= 1) {
+					d += __shfl_xor(d, ofs);
+				}
+				sc[u] = valid[u] ? d / sqrt_hd : -INFINITY;
+			}
+			float mn = m[q];
+#pragma unroll
+			for (int u = 0; u < UA; ++u) {
+				mn = fmaxf(mn, sc[u]);
+			}
+			if (mn != -INFINITY) {
+				float c = (m[q] == -INFINITY) ? 0.f : __expf(m[q] - mn);
+				l[q] *= c;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					o[q][i] *= c;
+				}
+#pragma unroll
+				for (int u = 0; u < UA; ++u) {
+					float p = valid[u] ? __expf(sc[u] - mn) : 0.f;
+					l[q] += p;
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						o[q][i] = fmaf(p, vf[u][i], o[q][i]);
+					}
+				}
+				m[q] = mn;
+			}
+		}
+	}
+
+	// merge lane groups, then waves, per query head
+#pragma unroll
+	for (int q = 0; q < QH; ++q) {
+#pragma unroll
+		for (int ofs = LPR; ofs < 64; ofs <<= 1) {
+			float m2 = __shfl_xor(m[q], ofs), l2 = __shfl_xor(l[q], ofs), o2[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				o2[i] = __shfl_xor(o[q][i], ofs);
+			}
+			sm_merge(m[q], l[q], o[q], m2, l2, o2);
+		}
+		if (g == 0) {
+			if (r == 0) {
+				sm_m[q][wave] = m[q];
+				sm_l[q][wave] = l[q];
+			}
+			if (dvalid) {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					sm_o[q][wave][d0 + i] = o[q][i];
+				}
+			}
+		}
+	}
+	__syncthreads();
+	// wave q (q < QH) finishes query head q
+	if (wave < QH && g == 0) {
+		const int q = wave;
+		float mm = sm_m[q][0], ll = sm_l[q][0], oo[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			oo[i] = sm_o[q][0][d0 + i];
+		}
+#pragma unroll
+		for (int w = 1; w < NW; ++w) {
+			float o2[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				o2[i] = sm_o[q][w][d0 + i];
+			}
+			sm_merge(mm, ll, oo, sm_m[q][w], sm_l[q][w], o2);
+		}
+		if (dvalid) {
+			float* p = a.partial + ((size_t)(h0 + q) * a.n_split + split) * (a.head_dim + 2);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				p[d0 + i] = oo[i];
+			}
+			if (r == 0) {
+				p[a.head_dim] = mm;
+				p[a.head_dim + 1] = ll;
+			}
+		}
+	}
+}
+
 // merge the kv splits of every head: grid = n_heads, block = 64 (dims strided over lanes)
 __global__ void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
 	const int h = blockIdx.x;

@@ -114,7 +114,8 @@ const char* calm_hip_device_name(void);
  *   "graph"   1 = replay each step from a hipGraph (default), 0 = eager launches
  *   "prof"    1 = eager launches bracketed by per-stage events, reported by perf_hip
  *   "bpc"     cap on resident 256-thread workgroups per CU when sizing grids (default 4)
- *   "split_t" cached positions per attention KV split (default 1024)
+ *   "split_t" cached positions per attention KV split (default 128)
+ *   "split_min" contexts up to this many positions are not split (default 384)
  * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.
  * Changing "bpc"/"split_t" only affects graphs captured afterwards. */
 int calm_hip_configure(const char* key, int value);

@@ -227,6 +227,7 @@ def test_attention_split_path_inside_forward(hiplib):
     model, z = load_golden("tiny_fp16")
     toks = [int(t) for t in z["tokens"]]
     old = hiplib.calm_hip_configure(b"split_t", 4)
+    old_min = hiplib.calm_hip_configure(b"split_min", 2)  # split from the third position on
     b = HipBackend(model)
     try:
         for pos, tok in enumerate(toks):
@@ -235,6 +236,7 @@ def test_attention_split_path_inside_forward(hiplib):
     finally:
         b.close()
         hiplib.calm_hip_configure(b"split_t", old)
+        hiplib.calm_hip_configure(b"split_min", old_min)
 
 
 @pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 1), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1), ("dbrx-132b", "fp8", 1)])

@@ -38,7 +38,7 @@ if not brief or os.environ.get("LONGCTX"):
     dt = time.perf_counter() - t0
     us, b = be.stage_us(1, 6)
     print(f"last-32 @pos~4040: {32/dt:8.1f} tok/s ({dt/32*1e6:7.1f} us/token, L={L}); attn stage {us:6.2f}us {b/us/1e3:6.0f}GB/s")
-    for st_ in (512, 256, 128, 64):
+    for st_ in (512, 256, 64):
         old = lib.calm_hip_configure(b"split_t", st_)
         us, b = be.stage_us(1, 6)
         t0 = time.perf_counter()
