@@ -237,7 +237,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	} else {
 		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1>), grid, block, 0, g_stream, a);
 	}
-	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(256), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
 }
 
 template <int KVB>

@@ -1065,26 +1065,50 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(AttnArgs a) {
 	}
 }
 
-// merge the kv splits of every head: grid = n_heads, block = 64 (dims strided over lanes)
-__global__ void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
+// merge the kv splits of every head: grid = n_heads, block = 256; n_split <= 64.
+// Wave 0 fetches all (m, l) pairs at once (one lane per split) and turns them into weights; then one
+// thread per output dim sums the split partials with 8 independent loads in flight (a serial loop of
+// dependent L2 round trips made this kernel cost 1 us PER SPLIT).
+__global__ __launch_bounds__(256) void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
+	__shared__ float wgt[64];
+	__shared__ float inv_l;
 	const int h = blockIdx.x;
-	const float* p = partial + (size_t)h * n_split * (head_dim + 2);
-	float M = -INFINITY;
-	for (int s = 0; s < n_split; ++s) {
-		M = fmaxf(M, p[s * (head_dim + 2) + head_dim]);
-	}
-	float L = 0.f;
-	for (int s = 0; s < n_split; ++s) {
-		float ms = p[s * (head_dim + 2) + head_dim];
-		L += (ms == -INFINITY) ? 0.f : p[s * (head_dim + 2) + head_dim + 1] * __expf(ms - M);
-	}
-	for (int d = threadIdx.x; d < head_dim; d += blockDim.x) {
-		float acc = 0.f;
-		for (int s = 0; s < n_split; ++s) {
-			float ms = p[s * (head_dim + 2) + head_dim];
-			acc += (ms == -INFINITY) ? 0.f : p[s * (head_dim + 2) + d] * __expf(ms - M);
+	const int stride = head_dim + 2;
+	const float* p = partial + (size_t)h * n_split * stride;
+	if (threadIdx.x < 64) {
+		const int s = threadIdx.x;
+		float ms = -INFINITY, ls = 0.f;
+		if (s < n_split) {
+			ms = p[s * stride + head_dim];
+			ls = p[s * stride + head_dim + 1];
 		}
-		out[h * head_dim + d] = acc / L;
+		const float M = wave_max(ms);
+		const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+		const float L = wave_sum(ls * w);
+		wgt[s] = w;
+		if (s == 0) {
+			inv_l = 1.0f / L;
+		}
+	}
+	__syncthreads();
+	for (int d = threadIdx.x; d < head_dim; d += 256) {
+		float acc = 0.f;
+		int s = 0;
+		for (; s + 8 <= n_split; s += 8) {
+			float v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				v[u] = p[(s + u) * stride + d];
+			}
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				acc = fmaf(v[u], wgt[s + u], acc);
+			}
+		}
+		for (; s < n_split; ++s) {
+			acc = fmaf(p[s * stride + d], wgt[s], acc);
+		}
+		out[h * head_dim + d] = acc * inv_l;
 	}
 }
 
