@@ -72,6 +72,22 @@ void* dev_alloc(size_t size) {
 	return p;
 }
 
+// compile-time dispatch on a run-time bool: f(std::true_type) / f(std::false_type)
+template <class F>
+inline void by_bool(bool b, F f) {
+	if (b) {
+		f(std::true_type());
+	} else {
+		f(std::false_type());
+	}
+}
+
+// rows of n weights at DB bits are whole 1-KiB wave-loads (the kernels' FULL variant)
+template <int DB>
+inline bool rows_full(int n) {
+	return (n / (128 / DB)) % 64 == 0;
+}
+
 // float4 registers per thread the staging prologue needs for an n-float vector at `block` threads
 inline bool stage_v4(int n, int block) {
 	return n <= 4 * 4 * block;
@@ -205,11 +221,13 @@ void launch_qkv(Ctx* c, int l) {
 	a.dim = c->dim, a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len;
 	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
 	int ntasks = (c->q_dim + 2 * c->kv_dim) / Shape<DB>::NR;
-	if (stage_v4(c->dim, 256)) {
-		hipLaunchKernelGGL((k_qkv<DB, KVB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
-	} else {
-		hipLaunchKernelGGL((k_qkv<DB, KVB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
-	}
+	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	size_t lds = lds_bytes<DB>(c->dim);
+	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
+		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
+			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a);
+		});
+	});
 }
 
 template <int KVB, int LPR>
@@ -261,13 +279,14 @@ void launch_attn(Ctx* c, int l, int n_split) {
 template <int DB>
 void launch_attn_out(Ctx* c, int l) {
 	int ntasks = c->dim / Shape<DB>::NR;
-	if (stage_v4(c->q_dim, 256)) {
-		hipLaunchKernelGGL((k_attn_out<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->q_dim), g_stream, c->x, c->att, c->t->weights.wo[l],
-		                   c->dim, c->q_dim);
-	} else {
-		hipLaunchKernelGGL((k_attn_out<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->q_dim), g_stream, c->x, c->att, c->t->weights.wo[l],
-		                   c->dim, c->q_dim);
-	}
+	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	size_t lds = lds_bytes<DB>(c->q_dim);
+	const void* wo = c->t->weights.wo[l];
+	by_bool(stage_v4(c->q_dim, 256), [&](auto V4) {
+		by_bool(rows_full<DB>(c->q_dim), [&](auto FULL) {
+			hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim);
+		});
+	});
 }
 
 template <int DB>
@@ -283,11 +302,15 @@ void launch_ffn_up(Ctx* c, int l) {
 	a.eps = p->norm_eps, a.ln = p->norm_ln, a.gelu = p->act_gelu;
 	int nact = c->n_active > 0 ? c->n_active : 1;
 	int ntasks = nact * (c->hidden / (Shape<DB>::NR / 2));
-	if (stage_v4(c->dim, 256)) {
-		hipLaunchKernelGGL((k_ffn_up<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
-	} else {
-		hipLaunchKernelGGL((k_ffn_up<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, a);
-	}
+	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	size_t lds = lds_bytes<DB>(c->dim);
+	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
+		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
+			by_bool(c->n_experts > 0, [&](auto MOE) {
+				hipLaunchKernelGGL((k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(MOE)::value>), grid, block, lds, g_stream, a);
+			});
+		});
+	});
 }
 
 // gf4 rows of exactly 7 KiB chunks (hidden 14336) take the 2 x 7 tile shape: one exact step per task instead
@@ -306,34 +329,28 @@ void launch_ffn_down(Ctx* c, int l) {
 	dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 	size_t lds = lds_bytes<DB>(c->hidden);
 	const void* w2 = c->t->weights.w2[l];
-#define FD(V, U7) hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, V, U7>), grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active)
-	if (stage_v4(c->hidden, BLOCK)) {
-		if (u7) {
-			FD(4, true);
-		} else {
-			FD(4, false);
-		}
-	} else {
-		if (u7) {
-			FD(8, true);
-		} else {
-			FD(8, false);
-		}
-	}
-#undef FD
+	by_bool(stage_v4(c->hidden, BLOCK), [&](auto V4) {
+		by_bool(u7, [&](auto U7) {
+			by_bool(rows_full<DB>(c->hidden), [&](auto FULL) {
+				hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->he, w2,
+				                   c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+			});
+		});
+	});
 }
 
 template <int DB>
 void launch_output(Ctx* c) {
 	struct Config* p = &c->t->config;
 	int ntasks = (c->vocab + Shape<DB>::NR - 1) / Shape<DB>::NR;
-	if (stage_v4(c->dim, 256)) {
-		hipLaunchKernelGGL((k_output<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, c->logits_d, c->x,
-		                   c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
-	} else {
-		hipLaunchKernelGGL((k_output<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(c->dim), g_stream, c->logits_d, c->x,
-		                   c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
-	}
+	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	size_t lds = lds_bytes<DB>(c->dim);
+	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
+		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
+			hipLaunchKernelGGL((k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
+			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
+		});
+	});
 }
 
 void launch_argmax(Ctx* c) {
@@ -525,20 +542,24 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 template <int DB>
 void set_lds_attrs(Ctx* c) {
-	allow_lds(k_qkv<DB, 16, 4>, lds_bytes<DB>(c->dim));
-	allow_lds(k_qkv<DB, 16, 8>, lds_bytes<DB>(c->dim));
-	allow_lds(k_qkv<DB, 8, 4>, lds_bytes<DB>(c->dim));
-	allow_lds(k_qkv<DB, 8, 8>, lds_bytes<DB>(c->dim));
-	allow_lds(k_attn_out<DB, 4>, lds_bytes<DB>(c->q_dim));
-	allow_lds(k_attn_out<DB, 8>, lds_bytes<DB>(c->q_dim));
-	allow_lds(k_ffn_up<DB, 4>, lds_bytes<DB>(c->dim));
-	allow_lds(k_ffn_up<DB, 8>, lds_bytes<DB>(c->dim));
-	allow_lds(k_ffn_down<DB, 512, 4, false>, lds_bytes<DB>(c->hidden));
-	allow_lds(k_ffn_down<DB, 512, 8, false>, lds_bytes<DB>(c->hidden));
-	allow_lds(k_ffn_down<DB, 512, 4, true>, lds_bytes<DB>(c->hidden));
-	allow_lds(k_ffn_down<DB, 512, 8, true>, lds_bytes<DB>(c->hidden));
-	allow_lds(k_output<DB, 4>, lds_bytes<DB>(c->dim));
-	allow_lds(k_output<DB, 8>, lds_bytes<DB>(c->dim));
+	// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
+	// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
+	by_bool(true, [&](auto) {
+		size_t big = lds_bytes<DB>(c->hidden);
+		allow_lds(k_ffn_down<DB, 512, 4, false, false>, big);
+		allow_lds(k_ffn_down<DB, 512, 4, false, true>, big);
+		allow_lds(k_ffn_down<DB, 512, 4, true, true>, big);
+		allow_lds(k_ffn_down<DB, 512, 8, false, false>, big);
+		allow_lds(k_ffn_down<DB, 512, 8, false, true>, big);
+		allow_lds(k_ffn_down<DB, 512, 8, true, true>, big);
+		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
+		if (d > 48 * 1024) {
+			allow_lds(k_qkv<DB, 16, 8, true>, d), allow_lds(k_qkv<DB, 16, 8, false>, d), allow_lds(k_qkv<DB, 8, 8, true>, d), allow_lds(k_qkv<DB, 8, 8, false>, d);
+			allow_lds(k_attn_out<DB, 8, true>, d), allow_lds(k_attn_out<DB, 8, false>, d);
+			allow_lds(k_ffn_up<DB, 8, true, true>, d), allow_lds(k_ffn_up<DB, 8, true, false>, d), allow_lds(k_ffn_up<DB, 8, false, true>, d), allow_lds(k_ffn_up<DB, 8, false, false>, d);
+			allow_lds(k_output<DB, 8, true>, d), allow_lds(k_output<DB, 8, false>, d);
+		}
+	});
 }
 
 } // namespace
@@ -944,13 +965,13 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 	HIP_CHECK(hipMemset(dout, 0, d * sizeof(float)));
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		if (stage_v4(n, 256)) {
-			allow_lds(k_attn_out<DB, 4>, lds_bytes<DB>(n));
-			hipLaunchKernelGGL((k_attn_out<DB, 4>), dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
-		} else {
-			allow_lds(k_attn_out<DB, 8>, lds_bytes<DB>(n));
-			hipLaunchKernelGGL((k_attn_out<DB, 8>), dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
-		}
+		by_bool(stage_v4(n, 256), [&](auto V4) {
+			by_bool(rows_full<DB>(n), [&](auto FULL) {
+				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
+				allow_lds(k, lds_bytes<DB>(n));
+				hipLaunchKernelGGL(k, dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+			});
+		});
 	});
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, dout, d * sizeof(float));
@@ -968,13 +989,13 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
 		int ntasks = (d + Shape<DB>::NR - 1) / Shape<DB>::NR;
-		if (stage_v4(n, 256)) {
-			allow_lds(k_output<DB, 4>, lds_bytes<DB>(n));
-			hipLaunchKernelGGL((k_output<DB, 4>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
-		} else {
-			allow_lds(k_output<DB, 8>, lds_bytes<DB>(n));
-			hipLaunchKernelGGL((k_output<DB, 8>), dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
-		}
+		by_bool(stage_v4(n, 256), [&](auto V4) {
+			by_bool(rows_full<DB>(n), [&](auto FULL) {
+				auto k = k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
+				allow_lds(k, lds_bytes<DB>(n));
+				hipLaunchKernelGGL(k, dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+			});
+		});
 	});
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, dout, d * sizeof(float));

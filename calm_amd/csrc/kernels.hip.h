@@ -506,14 +506,13 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	}
 }
 
-template <int DB, int NR, int U, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+// FULL (rows are whole KiB chunks) is a KERNEL template parameter picked by the host: carrying both variants
+// in one kernel doubled its code size for a branch that never changes (kernels this short feel their
+// instruction-cache warm-up).
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                          StageFn stage, AuxFn aux_of, EpiFn epi) {
-	if ((n / Fmt<DB>::G) % 64 == 0) { // workgroup-uniform
-		run_rows_impl<DB, NR, U, true>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
-	} else {
-		run_rows_impl<DB, NR, U, false>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
-	}
+	run_rows_impl<DB, NR, U, FULL>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
 // rows per task / tile depth per weight format: 8 x 1 KiB loads in flight per wave in all cases
@@ -599,7 +598,7 @@ struct QkvArgs {
 
 // attention norm + fused q/k/v matvec + bias + clip + RoPE + KV append   (src/infer.c:352-381)
 // task = NR consecutive rows of the concatenated [wq; wk; wv]; rows come in RoPE pairs (2i, 2i+1).
-template <int DB, int KVB, int V>
+template <int DB, int KVB, int V, bool FULL>
 __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 			}
 		}
 	};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -1113,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_attn_merge(const float* partial, float*
 }
 
 // ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
-template <int DB, int V>
+template <int DB, int V, bool FULL>
 __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -1144,7 +1143,7 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 			}
 		}
 	};
-	run_rows<DB, NR, U>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
@@ -1169,7 +1168,7 @@ __device__ __forceinline__ float act_gelu(float x) {
 }
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
-template <int DB, int V>
+template <int DB, int V, bool FULL, bool MOE>
 __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -1184,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 	const int nact = a.n_active > 0 ? a.n_active : 1;
 	const int per_expert = a.hidden / JP;
 	const int ntasks = nact * per_expert;
-	const bool moe = a.n_experts > 0;
+	constexpr bool moe = MOE;
 
 	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
 		int k = t / per_expert, j = (t % per_expert) * JP;
@@ -1209,10 +1208,10 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 	};
 
 	StageRegs<V, true> sr;
-	if (!moe) {
+	if constexpr (!MOE) {
 		auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, no_aux, epi);
+		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -1273,7 +1272,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		__syncthreads();
 	}
 	auto nothing = [&]() {};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, nothing, nothing, no_aux, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, nothing, nothing, no_aux, epi);
 }
 
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
@@ -1282,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 // U7: rows of 7k KiB (hidden 14336 at fp8 = 14 chunks, fp16 = 28, gf4 = 7): tiles of 2 rows x 7 chunks, so a
 // wave's first two steps -- issued before the prologue -- already cover 28 KiB, the whole task at fp8;
 // the long prologue of this kernel (staging the hidden-sized vector) then hides behind the full stream.
-template <int DB, int BLOCK, int V, bool U7>
+template <int DB, int BLOCK, int V, bool U7, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1324,12 +1323,12 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 				}
 			}
 		};
-		run_rows<DB, NR, U>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, aux_of, epi);
+		run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, aux_of, epi);
 	}
 }
 
 // ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
-template <int DB, int V>
+template <int DB, int V, bool FULL>
 __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -1359,7 +1358,7 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 			}
 		}
 	};
-	run_rows<DB, NR, U>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
