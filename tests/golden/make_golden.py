@@ -10,7 +10,8 @@ where /root/reference exists (the build container); its outputs are committed:
     <case>.npz    tokens[T]  -- greedy token stream of the reference (teacher-forcing input)
                   logits[T, vocab] -- the reference's logits at every step
                   k_last / v_last  -- layer-0 KV cache rows after the last step (fp16 bits)
-    cli_tiny_fp16.txt -- stdout+stderr throughput-line hash of the reference CLI (run_cpu) on one case
+    cli_tiny_fp16.txt -- text decoded by the reference CLI (run_cpu) on one case
+    cli_tiny_fp16_perplexity.txt -- its perplexity line for sample.txt (-x mode)
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -76,6 +77,13 @@ def main():
     with open(os.path.join(HERE, "cli_tiny_fp16.txt"), "w") as f:
         f.write(r.stdout.splitlines()[1] + "\n")  # line 0 is the model banner (path dependent), line 1 the decoded text
     print("cli:", r.stdout.splitlines()[1][:80])
+
+    # perplexity mode (study(), src/run.c:258-316): positions wrap (pos = i % steps), every step wants logits
+    r = subprocess.run([oracle.RUN_CPU, os.path.join(HERE, "tiny_fp16.calm"), "-x", os.path.join(HERE, "sample.txt"), "-n", "48"], env=env, capture_output=True, text=True, check=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("# perplexity:")][0]
+    with open(os.path.join(HERE, "cli_tiny_fp16_perplexity.txt"), "w") as f:
+        f.write(line.split("(")[0].strip() + "\n")
+    print("pplx:", line)
 
 
 if __name__ == "__main__":

@@ -345,3 +345,24 @@ def test_pipeline_stages_on_one_gpu_equal_the_unsharded_step(hiplib, case):
     finally:
         b0.close()
         b1.close()
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip not built")
+def test_reference_cli_perplexity_mode_on_the_hip_backend():
+    """`run -x file` (study(), src/run.c:258-316) through the unmodified reference CLI on the HIP backend:
+    every step returns logits, positions wrap around (pos = i % steps), the host computes log-probs from
+    them; the perplexity must equal the reference CPU backend's (golden) to 4 significant digits"""
+    import re
+    import subprocess
+
+    from conftest import GOLDEN
+
+    env = dict(os.environ)
+    env.pop("CALM_CPU", None)
+    r = subprocess.run([oracle.RUN_HIP, os.path.join(GOLDEN, "tiny_fp16.calm"), "-x", os.path.join(GOLDEN, "sample.txt"), "-n", "48"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = [l for l in r.stdout.splitlines() if l.startswith("# perplexity:")][0]
+    want = open(os.path.join(GOLDEN, "cli_tiny_fp16_perplexity.txt")).read()
+    g = [float(x) for x in re.findall(r"[0-9]+\\.[0-9]+", got)[:2]]
+    w = [float(x) for x in re.findall(r"[0-9]+\\.[0-9]+", want)[:2]]
+    assert abs(g[0] - w[0]) <= 5e-4 * w[0] and abs(g[1] - w[1]) <= 5e-3 * max(w[1], 1.0), (got, want)
