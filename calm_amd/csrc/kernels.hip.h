@@ -164,25 +164,18 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 	} else {
 		// gf4: word = 8-bit e5m2 scale S + 8 x 3-bit codes, w_k = (q_k - 4) * S / -4   (src/infer.c:37-40)
 		//   sum_k w_k x_k = (-S/4) * sum_k q_k x_k + S * sum_k x_k
-		// The codes are never converted: a pair (q_a, q_b) is moved into the two halves of a dword
-		// (6-bit extract, multiply by 0x2001, mask) where, read as binary16, q is the SUBNORMAL q * 2^-24
-		// -- exact -- and v_fma_mix_f32 multiplies a half by an fp32 activation into an fp32 accumulator
-		// in one instruction.  2.5 VALU ops per weight instead of 5; the 2^24 folds into the scale.
-		unsigned p[4][4];
+		// The codes are never converted: each is extracted (one v_bfe_u32) into the low bits of a dword
+		// where, read as binary16, q is the SUBNORMAL q * 2^-24 -- exact -- and v_fma_mix_f32 multiplies
+		// that half by an fp32 activation into an fp32 accumulator in one instruction.  2 VALU ops per
+		// weight (+ scale and activation sum per word); the 2^24 folds into the scale.
 		f32x4 xv[4][2];
 		float t[4], S[4], xsum[4];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			const unsigned w = v[j];
 			xv[j][0] = xp[(2 * j) * 64];
 			xv[j][1] = xp[(2 * j + 1) * 64];
-			S[j] = bf8_byte0(w);
+			S[j] = bf8_byte0(v[j]);
 			xsum[j] = ((xv[j][0][0] + xv[j][0][1]) + (xv[j][0][2] + xv[j][0][3])) + ((xv[j][1][0] + xv[j][1][1]) + (xv[j][1][2] + xv[j][1][3]));
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { // codes 2k and 2k+1 as two subnormal halves of one dword
-				unsigned q = __builtin_amdgcn_ubfe(w, 8 + 6 * k, 6);
-				p[j][k] = (q * 0x2001u) & 0x00070007u; // v_mul_u32_u24 (q < 64)
-			}
 			t[j] = 0.f;
 		}
 		// v_fma_mix_f32 is written as (pure, non-volatile) inline asm: left to itself the SLP vectoriser
@@ -192,7 +185,8 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		for (int k = 0; k < 8; ++k) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
-				t[j] = (k & 1) ? fma_mix_hi(p[j][k >> 1], xv[j][k >> 2][k & 3], t[j]) : fma_mix_lo(p[j][k >> 1], xv[j][k >> 2][k & 3], t[j]);
+				unsigned q = k == 7 ? v[j] >> 29 : __builtin_amdgcn_ubfe(v[j], 8 + 3 * k, 3);
+				t[j] = fma_mix_lo(q, xv[j][k >> 2][k & 3], t[j]);
 			}
 		}
 #pragma unroll

@@ -363,6 +363,6 @@ def test_reference_cli_perplexity_mode_on_the_hip_backend():
     assert r.returncode == 0, r.stderr[-2000:]
     got = [l for l in r.stdout.splitlines() if l.startswith("# perplexity:")][0]
     want = open(os.path.join(GOLDEN, "cli_tiny_fp16_perplexity.txt")).read()
-    g = [float(x) for x in re.findall(r"[0-9]+\\.[0-9]+", got)[:2]]
-    w = [float(x) for x in re.findall(r"[0-9]+\\.[0-9]+", want)[:2]]
+    g = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", got)[:2]]
+    w = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", want)[:2]]
     assert abs(g[0] - w[0]) <= 5e-4 * w[0] and abs(g[1] - w[1]) <= 5e-3 * max(w[1], 1.0), (got, want)
