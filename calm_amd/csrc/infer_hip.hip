@@ -21,6 +21,7 @@
 #include "../../include/calm_hip.h"
 #include "../../include/calm_hip_test.h"
 #include "kernels.hip.h"
+#include "prefill.hip.h"
 
 using namespace calm;
 
@@ -120,6 +121,10 @@ struct Ctx {
 	size_t kv_layer_bytes = 0;
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
+	// batched prompt ingestion (allocated on first use): token-major [PF_NT][...] activations of one chunk
+	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
+	float2* pf_rope = nullptr;
+	int* pf_tok = nullptr;
 	// graph cache: (n_split, kv_only, sink, chained, argmax)
 	std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
 	// argument block of the begin-token kernel (patched per replay)
@@ -240,6 +245,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.partial = c->partial;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
+	a.pf_kv0 = 0, a.pf_stride = 0;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
 		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a);
@@ -540,6 +546,109 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	HIP_CHECK(hipGraphLaunch(ge.exec, g_stream));
 }
 
+// ---------------------------------------------------------------- batched prompt ingestion -----
+
+void pf_alloc(Ctx* c) {
+	if (c->pf_x) {
+		return;
+	}
+	const int wide = c->dim > c->q_dim ? c->dim : c->q_dim;
+	c->pf_x = (float*)dev_alloc((size_t)PF_NT * c->dim * sizeof(float));
+	c->pf_xn = (float*)dev_alloc((size_t)PF_NT * wide * sizeof(float));
+	c->pf_q = (float*)dev_alloc((size_t)PF_NT * c->q_dim * sizeof(float));
+	c->pf_att = (float*)dev_alloc((size_t)PF_NT * c->q_dim * sizeof(float));
+	c->pf_h = (float*)dev_alloc((size_t)PF_NT * c->hidden * sizeof(float));
+	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
+	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
+}
+
+template <int KVB, int LPR>
+void launch_pf_attn_lpr(Ctx* c, int l, int nb, int pos0) {
+	AttnArgs a;
+	a.q = c->pf_q;
+	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
+	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+	a.out = c->pf_att;
+	a.partial = nullptr;
+	a.ts = c->ts;
+	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
+	a.pf_kv0 = pos0, a.pf_stride = c->q_dim;
+	hipLaunchKernelGGL((k_attn<KVB, LPR, true>), dim3(c->n_heads, nb), dim3(ATTN_BLOCK), 0, g_stream, a);
+}
+
+template <int KVB>
+void launch_pf_attn(Ctx* c, int l, int nb, int pos0) {
+	switch (c->lpr) {
+	case 4:
+		return launch_pf_attn_lpr<KVB, 4>(c, l, nb, pos0);
+	case 8:
+		return launch_pf_attn_lpr<KVB, 8>(c, l, nb, pos0);
+	case 16:
+		return launch_pf_attn_lpr<KVB, 16>(c, l, nb, pos0);
+	case 32:
+		return launch_pf_attn_lpr<KVB, 32>(c, l, nb, pos0);
+	default:
+		return launch_pf_attn_lpr<KVB, 64>(c, l, nb, pos0);
+	}
+}
+
+// one chunk of nb <= PF_NT tokens at positions pos0 .. pos0 + nb - 1 (no wrap of the rolling buffer):
+// the layer loop of src/infer.c:349-458 with a token dimension
+template <int DB, int KVB>
+void prefill_chunk(Ctx* c, int nb, int pos0) {
+	struct Config* p = &c->t->config;
+	struct Weights* w = &c->t->weights;
+	const int half_hd = c->head_dim / 2;
+	const int n0 = c->dim > half_hd ? c->dim : half_hd;
+	hipLaunchKernelGGL((k_pf_begin<DB>), dim3((n0 + 255) / 256, PF_NT), dim3(256), 0, g_stream, c->pf_tok, nb, pos0, c->pf_x, w->token_embedding_table, c->dim,
+	                   c->rope_freq, c->pf_rope, half_hd);
+	const dim3 block(256);
+	const int ct = (nb + 31) / 32;
+	PfGemmArgs a;
+	memset(&a, 0, sizeof(a));
+	a.nb = nb;
+	a.bqkv = nullptr, a.rope = c->pf_rope;
+	a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len, a.kv_pos0 = pos0;
+	a.clip = p->qkv_clip, a.gelu = p->act_gelu;
+	for (int l = 0; l < c->n_layers; ++l) {
+		// attention norm; q / k / v + bias + clip + RoPE + KV append   (src/infer.c:352-381)
+		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, c->pf_xn, c->pf_x, w->rms_att_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
+		a.xin = c->pf_xn, a.K = c->dim, a.M = c->q_dim + 2 * c->kv_dim;
+		a.w0 = w->wq[l], a.w1 = w->wk[l], a.w2 = w->wv[l], a.bqkv = w->bqkv[l];
+		a.out = c->pf_q;
+		a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes, a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_QKV>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+		// causal attention of every token of the chunk over the cache (its own row included)
+		launch_pf_attn<KVB>(c, l, nb, pos0);
+		// x += wo . att   (src/infer.c:408-415)
+		a.xin = c->pf_att, a.K = c->q_dim, a.M = c->dim, a.w0 = w->wo[l], a.out = c->pf_x;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_RESID>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+		// FFN   (src/infer.c:417-457); parallel-residual models reuse the attention norm's output
+		if (!p->norm_par) {
+			hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
+		}
+		a.xin = c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_FFN_UP>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+		a.xin = c->pf_h, a.K = c->hidden, a.M = c->dim, a.w0 = w->w2[l], a.out = c->pf_x;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_RESID>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+	}
+	HIP_CHECK(hipGetLastError());
+}
+
+void dispatch_prefill_chunk(Ctx* c, int nb, int pos0) {
+#define CASE(db, kvb)                       \
+	if (c->dbits == db && c->kvbits == kvb) \
+	return prefill_chunk<db, kvb>(c, nb, pos0)
+	CASE(16, 16);
+	CASE(8, 16);
+	CASE(4, 16);
+	CASE(16, 8);
+	CASE(8, 8);
+	CASE(4, 8);
+#undef CASE
+	CALM_REQUIRE(false, "unsupported dbits/kvbits combination");
+}
+
 template <int DB>
 void set_lds_attrs(Ctx* c) {
 	// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
@@ -789,6 +898,12 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}
+	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok};
+	for (void* b : pf_bufs) {
+		if (b) {
+			HIP_CHECK(hipFree(b));
+		}
+	}
 	HIP_CHECK(hipHostFree(c->logits_h));
 	if (g_prof_ctx == c) {
 		g_prof_ctx = nullptr;
@@ -830,6 +945,36 @@ extern "C" void copy_hip(void* dst, const void* src, size_t size) {
 	init_hip();
 	HIP_CHECK(hipStreamSynchronize(g_stream));
 	HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyDefault));
+}
+
+extern "C" void prefill_hip(struct Transformer* t, const int* tokens, int n, int pos) {
+	Ctx* c = ctx_of(t);
+	CALM_REQUIRE(n >= 0 && pos >= 0, "negative token count / position");
+	for (int i = 0; i < n; ++i) {
+		CALM_REQUIRE(tokens[i] >= 0 && tokens[i] < c->vocab, "token out of range");
+	}
+	// The batched path covers dense models while the rolling buffer has not wrapped; everything else --
+	// mixture-of-experts routing (per-token expert sets), positions at or past seq_len (sink rotation
+	// between tokens) -- goes through the decode path one token at a time, still on the device.
+	int done = 0;
+	if (c->n_experts == 0 && c->t->weights.token_embedding_table) {
+		pf_alloc(c);
+		while (done < n && pos + done < c->seq_len) {
+			int nb = n - done < PF_NT ? n - done : PF_NT;
+			if (pos + done + nb > c->seq_len) {
+				nb = c->seq_len - (pos + done);
+			}
+			HIP_CHECK(hipMemcpyAsync(c->pf_tok, tokens + done, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
+			dispatch_prefill_chunk(c, nb, pos + done);
+			done += nb;
+		}
+	}
+	for (; done < n; ++done) {
+		StepPlan sp = {};
+		sp.kv_only = true;
+		run_step(c, tokens[done], nullptr, pos + done, sp);
+	}
+	HIP_CHECK(hipStreamSynchronize(g_stream)); // `tokens` may be reused by the caller; KV rows are complete
 }
 
 extern "C" float* decode_greedy_hip(struct Transformer* t, int token, int pos, int n_steps, int* out_tokens) {

@@ -126,6 +126,11 @@ __device__ __forceinline__ float fma_mix_lo(unsigned h2, float x, float acc) {
 	asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(x));
 	return acc;
 }
+__device__ __forceinline__ float mul_mix_lo(unsigned h2, float x) {
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(x));
+	return r;
+}
 __device__ __forceinline__ float fma_mix_hi(unsigned h2, float x, float acc) {
 	asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(x));
 	return acc;
@@ -175,8 +180,8 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 			xv[j][0] = xp[(2 * j) * 64];
 			xv[j][1] = xp[(2 * j + 1) * 64];
 			S[j] = bf8_byte0(v[j]);
-			xsum[j] = ((xv[j][0][0] + xv[j][0][1]) + (xv[j][0][2] + xv[j][0][3])) + ((xv[j][1][0] + xv[j][1][1]) + (xv[j][1][2] + xv[j][1][3]));
-			t[j] = 0.f;
+			f32x2 s2 = (xv[j][0].lo + xv[j][0].hi) + (xv[j][1].lo + xv[j][1].hi); // v_pk_add_f32 on the pairs as loaded
+			xsum[j] = s2[0] + s2[1];
 		}
 		// v_fma_mix_f32 is written as (pure, non-volatile) inline asm: left to itself the SLP vectoriser
 		// keeps re-pairing these chains into v_pk_fma_f32 and converts every code with v_cvt_f32_f16 again.
@@ -186,7 +191,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
 				unsigned q = k == 7 ? v[j] >> 29 : __builtin_amdgcn_ubfe(v[j], 8 + 3 * k, 3);
-				t[j] = fma_mix_lo(q, xv[j][k >> 2][k & 3], t[j]);
+				t[j] = k == 0 ? mul_mix_lo(q, xv[j][0][0]) : fma_mix_lo(q, xv[j][k >> 2][k & 3], t[j]);
 			}
 		}
 #pragma unroll
@@ -683,6 +688,9 @@ struct AttnArgs {
 	float* partial;      // (n_heads, n_split, head_dim + 2) when n_split > 1: o[head_dim], m, l
 	const TokState* ts;
 	int head_dim, kv_mul, seq_len, n_split;
+	// batched prompt ingestion (k_attn<.., PF = true>, grid.y = token of the chunk): token b reads q + b * pf_stride,
+	// attends to cache rows [0, pf_kv0 + b] and writes out + b * pf_stride
+	int pf_kv0, pf_stride;
 };
 
 // merge two online-softmax states (m, l, o[8])
@@ -705,7 +713,7 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // tiles of positions.  Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are
 // computed in one pass with running (max, sum, out) per lane group -- algebraically the same
 // result as the reference's three loops.
-template <int KVB, int LPR>
+template <int KVB, int LPR, bool PF = false>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
 	constexpr int NW = ATTN_BLOCK / 64;
@@ -719,15 +727,17 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	const int r = lane % LPR, g = lane / LPR;
 	const bool dvalid = r * 8 < a.head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
-	const int kv_len = a.ts->kv_len;
+	const int kv_len = PF ? a.pf_kv0 + (int)blockIdx.y + 1 : a.ts->kv_len;
 	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
+	const float* qsrc = PF ? a.q + (size_t)blockIdx.y * a.pf_stride : a.q;
+	float* odst = PF ? a.out + (size_t)blockIdx.y * a.pf_stride : a.out;
 
 	float qv[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		float qi = a.q[h * a.head_dim + d0 + i];
+		float qi = qsrc[h * a.head_dim + d0 + i];
 		qv[i] = dvalid ? qi : 0.f;
 	}
 	const float sqrt_hd = sqrtf((float)a.head_dim);
@@ -857,7 +867,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			if (a.n_split == 1) {
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
-					a.out[h * a.head_dim + d0 + i] = o[i] / l;
+					odst[h * a.head_dim + d0 + i] = o[i] / l;
 				}
 			} else {
 				float* p = a.partial + ((size_t)h * a.n_split + split) * (a.head_dim + 2);

@@ -48,6 +48,7 @@ def load_lib() -> C.CDLL:
         "release_hip": (None, [T]),
         "free_hip": (None, [C.c_void_p]),
         "decode_greedy_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "prefill_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int]),
         "forward_stage_hip": (fp, [T, C.c_int, C.c_int, C.c_uint, C.c_uint]),
         "copy_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "perf_stage_hip": (C.c_double, [T, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
@@ -69,7 +70,7 @@ def load_lib() -> C.CDLL:
 
 EXPORTS = [
     "init_hip", "upload_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
-    "free_hip", "decode_greedy_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
+    "free_hip", "decode_greedy_hip", "prefill_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
     "calm_hip_test_argmax", "download_hip", "calm_hip_read_kv", "calm_hip_membench",
 ]
 
@@ -230,6 +231,11 @@ class HipBackend:
         out = (C.c_int * n_steps)()
         p = self.lib.decode_greedy_hip(C.byref(self.t), token, pos, n_steps, out)
         return np.array(out[:], dtype=np.int64), np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def prefill(self, tokens, pos: int) -> None:
+        """KV-cache effect of forward(tokens[i], pos + i, FF_UPDATE_KV_ONLY) for every i, batched (prefill_hip)"""
+        arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
+        self.lib.prefill_hip(C.byref(self.t), arr, len(tokens), pos)
 
     def stage_us(self, stage: int, iters: int = 4):
         b = C.c_uint64(0)

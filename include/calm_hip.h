@@ -73,6 +73,16 @@ void free_hip(void* device);
  * token ids to out_tokens; returns state.logits of the last step. */
 float* decode_greedy_hip(struct Transformer* transformer, int token, int pos, int n_steps, int* out_tokens);
 
+/* Batched prompt ingestion: the KV-cache effect of
+ *     for (i = 0; i < n; ++i) forward_hip(transformer, tokens[i], pos + i, FF_UPDATE_KV_ONLY);
+ * i.e. of the reference's serial prompt loop (src/run.c:208,216-218; README.md:80 "prompt processing is
+ * serial"), computed 64 tokens at a time: weights are streamed once per chunk and the multiply-adds run on
+ * the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32), so the cache rows agree with the serial path to
+ * fp32 rounding.  Returns after the work is complete (`tokens` is host memory and may be reused).
+ * Mixture-of-experts models and positions at or beyond seq_len (rolling buffer) are processed through the
+ * decode path one token at a time inside the call -- same result, no speed-up. */
+void prefill_hip(struct Transformer* transformer, const int* tokens, int n, int pos);
+
 /* Layer-pipeline stage (for models beyond one GPU's 288 GB): `transformer` describes
  * only THIS stage's slice of the model -- config.n_layers = the stage's layer count, weights indexed from 0,
  * token_embedding_table set on the first stage only, rms_final_weight / wcls on the last stage only.

@@ -366,3 +366,103 @@ def test_reference_cli_perplexity_mode_on_the_hip_backend():
     g = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", got)[:2]]
     w = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", want)[:2]]
     assert abs(g[0] - w[0]) <= 5e-4 * w[0] and abs(g[1] - w[1]) <= 5e-3 * max(w[1], 1.0), (got, want)
+
+
+# ---------------------------------------------------------------- batched prompt ingestion ------
+
+def _kv_floats(hiplib, b, kvbits):
+    """the whole K and V cache of a backend (private device layout) as float32"""
+    c = b.model.config
+    nbytes = c.n_layers * c.seq_len * c.head_dim * c.n_kv_heads * (kvbits // 8)
+    out = []
+    for ptr in (b.t.state.key_cache, b.t.state.value_cache):
+        raw = np.empty(nbytes, dtype=np.uint8)
+        hiplib.download_hip(raw.ctypes.data, ptr, nbytes)
+        if kvbits == 16:
+            out.append(raw.view(np.float16).astype(np.float32))
+        else:
+            out.append((raw.astype(np.uint16) << 8).view(np.float16).astype(np.float32))  # e5m2 = top byte of fp16
+    return out
+
+
+@pytest.mark.parametrize("kvbits", [16, 8])
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_prefill_equals_the_serial_prompt_loop(hiplib, case, kvbits):
+    """prefill_hip(tokens[0:T-1]) then one decode step == the reference's logits at step T-1 (teacher-forced
+    golden stream), == T-1 serial FF_UPDATE_KV_ONLY steps on the same backend; the cache rows it leaves behind
+    are the serial path's.  Covers every golden shape: ragged rows, bias, clip, layernorm, parallel residual,
+    MoE (serial inside the call) and the wrapping rolling buffer of sink_fp16 (serial past seq_len)."""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    T = len(toks)
+    serial = HipBackend(model, kvbits=kvbits)
+    batched = HipBackend(model, kvbits=kvbits)
+    try:
+        for pos, tok in enumerate(toks[: T - 1]):
+            serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        ls = serial.forward(toks[T - 1], T - 1, 0).copy()
+        batched.prefill(toks[: T - 1], 0)
+        lb = batched.forward(toks[T - 1], T - 1, 0).copy()
+        # (an e5m2 cache amplifies last-bit differences of the fp32 sums into whole rounding steps of a cached element)
+        assert rel_err(lb, ls) < (2e-4 if kvbits == 16 else 3e-2), rel_err(lb, ls)
+        if kvbits == 16:
+            assert rel_err(lb, z["logits"][T - 1]) < LOGIT_TOL
+        for ks, kb in zip(_kv_floats(hiplib, serial, kvbits), _kv_floats(hiplib, batched, kvbits)):
+            # the same values up to one rounding step of the cache format (fp32 sums differ in their last bits)
+            assert np.abs(ks - kb).max() <= (2e-3 if kvbits == 16 else 0.26) * max(np.abs(ks).max(), 1e-6)
+    finally:
+        serial.close()
+        batched.close()
+
+
+def test_prefill_in_two_calls_and_odd_chunks(hiplib):
+    """a prompt longer than one 64-token chunk, split at awkward places, with the second call starting at pos > 0"""
+    spec = cf.tiny_spec("pf", max_seq_len=256, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=500)
+    tensors, md = cf.synth_model(spec, "fp8", seed=21)
+    model = HostModel(tensors, md)
+    rng = np.random.default_rng(4)
+    toks = [int(t) for t in rng.integers(0, 500, size=150)]
+    o = oracle.OracleBackend(model)
+    b = HipBackend(model)
+    try:
+        for pos, tok in enumerate(toks[:-1]):
+            o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        lo = o.forward(toks[-1], len(toks) - 1, 0).copy()
+        b.prefill(toks[:97], 0)     # chunks of 64 + 33
+        b.prefill(toks[97:149], 97)  # one chunk of 52 that attends to the 97 rows before it
+        lb = b.forward(toks[-1], len(toks) - 1, 0)
+        assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
+        b.prefill([], 0)  # empty prompt: no-op
+    finally:
+        b.close()
+        o.close()
+
+
+@pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16")])
+def test_prefill_full_width_matches_serial(hiplib, name, dtype):
+    """BASELINE shapes at full width (2 layers): 100-token prompt, batched vs serial ingestion on the GPU, and
+    the oracle's logits after a 12-token prompt"""
+    spec = cf.SPECS[name]
+    tensors, md = cf.synth_model_big(spec, dtype, seed=9, n_layers=2)
+    model = HostModel(tensors, md, context=128)
+    rng = np.random.default_rng(8)
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, size=101)]
+    o = oracle.OracleBackend(model)
+    serial = HipBackend(model)
+    batched = HipBackend(model)
+    try:
+        for pos, tok in enumerate(toks[:12]):
+            o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        lo = o.forward(toks[12], 12, 0).copy()
+        batched.prefill(toks[:12], 0)
+        assert rel_err(batched.forward(toks[12], 12, 0), lo) < LOGIT_TOL
+        for pos, tok in enumerate(toks[:100]):
+            serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        ls = serial.forward(toks[100], 100, 0).copy()
+        batched.prefill(toks[:100], 0)
+        lb = batched.forward(toks[100], 100, 0)
+        assert rel_err(lb, ls) < 2e-4, rel_err(lb, ls)
+    finally:
+        serial.close()
+        batched.close()
+        o.close()
