@@ -11,9 +11,9 @@
 // that costs 3e-4..2e-3 per matvec and breaks the 1e-3 logits parity with the CPU path.
 //
 // A workgroup (4 waves) owns one tile of 32 output units x 32 tokens; its waves split the reduction
-// dimension (wave w takes every 4th 16-byte piece pair of the rows) and add their partial tiles through
-// LDS in a fixed order.  Operands go global -> registers directly: A = this lane's 16 bytes of its weight
-// row (lane = unit i, k-half kk), decoded to f32 in registers; B = the matching G activations of token j
+// dimension (wave w takes every 4th step of 64 weights per row) and add their partial tiles through LDS in
+// a fixed order.  Operands go global -> registers directly: A = 32 consecutive weights of this lane's row
+// (lane = unit i, k-half kk), decoded to f32 in registers; B = the matching 32 activations of token j
 // (lane = token j, k-half kk), contiguous in the token-major activation matrix (L2 resident: 64 x dim x 4 B).
 // The k order inside the dot product is permuted (both operands agree), which fp32 addition does not mind
 // beyond rounding.
@@ -113,14 +113,15 @@ template <int DB, int KVB, int EPI>
 __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	constexpr int G = Fmt<DB>::G;
 	constexpr int NMAT = EPI == PF_EPI_FFN_UP ? 2 : 1;
+	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and step
 	__shared__ float part[3][NMAT * 16][64]; // partial tiles of waves 1..3
 
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
 	const int unit0 = blockIdx.x * 32, tok0 = blockIdx.y * 32;
 	const size_t row_bytes = (size_t)a.K * DB / 8;
-	const int npieces = a.K / G;              // 16-byte pieces per row
-	const int nsteps = (npieces + 1) >> 1;    // a step = one piece per k-half
+	const int npieces = a.K / G;                   // 16-byte pieces per row
+	const int nsteps = (npieces + 2 * P - 1) / (2 * P); // a step = P pieces (32 weights) per k-half: 32 MFMAs per matrix
 
 	// A: this lane's weight row(s); B: this lane's token row.  Indices are clamped, never branched on:
 	// surplus lanes read real data and their results are dropped in the epilogue.
@@ -140,19 +141,23 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	const float* xrow = a.xin + (size_t)min(tok0 + j, a.nb - 1) * a.K;
 
 	struct Frag {
-		u32x4 w[NMAT];
-		f32x4 x[G / 4];
+		u32x4 w[NMAT][P];
+		f32x4 x[8];
 	};
 	auto load = [&](Frag& f, int s) {
-		const int piece = min(2 * min(s, nsteps - 1) + kk, npieces - 1);
+		const int p0 = (2 * min(s, nsteps - 1) + kk) * P;
 #pragma unroll
-		for (int m = 0; m < NMAT; ++m) {
-			f.w[m] = __builtin_nontemporal_load((gptr16)rowp[m] + piece);
-		}
-		const f32x4* xp = (const f32x4*)(xrow + (size_t)piece * G);
+		for (int i = 0; i < P; ++i) {
+			const int piece = min(p0 + i, npieces - 1);
 #pragma unroll
-		for (int q = 0; q < G / 4; ++q) {
-			f.x[q] = xp[q];
+			for (int m = 0; m < NMAT; ++m) {
+				f.w[m][i] = __builtin_nontemporal_load((gptr16)rowp[m] + piece);
+			}
+			const f32x4* xp = (const f32x4*)(xrow + (size_t)piece * G);
+#pragma unroll
+			for (int q = 0; q < G / 4; ++q) {
+				f.x[i * (G / 4) + q] = xp[q];
+			}
 		}
 	};
 
@@ -165,37 +170,51 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 		}
 	}
 	auto compute = [&](const Frag& f, int s) {
-		const bool valid = 2 * s + kk < npieces; // odd piece count: the last step's upper k-half is past the row
-		float wf[NMAT][G];
+		const int p0 = (2 * s + kk) * P;
 #pragma unroll
-		for (int m = 0; m < NMAT; ++m) {
-			u32x4 v = f.w[m];
-			if (!valid) {
-				v = (u32x4){0u, 0u, 0u, 0u}; // decodes to zeros in every format
+		for (int i = 0; i < P; ++i) {
+			const bool valid = p0 + i < npieces; // ragged rows: pieces past the row's end multiply as zeros
+			float wf[NMAT][G];
+#pragma unroll
+			for (int m = 0; m < NMAT; ++m) {
+				u32x4 v = f.w[m][i];
+				if (!valid) {
+					v = (u32x4){0u, 0u, 0u, 0u}; // decodes to zeros in every format
+				}
+				pf_decode<DB>(v, wf[m]);
 			}
-			pf_decode<DB>(v, wf[m]);
-		}
 #pragma unroll
-		for (int q = 0; q < G / 4; ++q) {
-#pragma unroll
-			for (int e = 0; e < 4; ++e) {
+			for (int e = 0; e < G; ++e) {
 #pragma unroll
 				for (int m = 0; m < NMAT; ++m) {
-					acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[m][4 * q + e], f.x[q][e], acc[m], 0, 0, 0);
+					acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[m][e], f.x[(i * G + e) / 4][(i * G + e) % 4], acc[m], 0, 0, 0);
 				}
 			}
 		}
 	};
 
-	// wave w takes steps w, w+4, ...; two steps of operands in flight ahead of the one being multiplied
+	// wave w takes steps w, w+4, ...; two steps of operands stay in flight ahead of the one being multiplied.
+	// The loop is unrolled by three so the three fragment buffers rotate by name (no register copies, which
+	// would wait for the loads just issued), and a scheduling barrier after each load block keeps the
+	// compiler from sinking the loads down to their first use (it did: 33 % of the f32 MFMA peak, vmcnt(0)
+	// in front of every other MFMA).  Loads are clamped, never skipped, so s_waitcnt stays counted.
 	Frag f0, f1, f2;
 	load(f0, wave);
 	load(f1, wave + 4);
-	for (int s = wave; s < nsteps; s += 4) {
+	for (int s = wave; s < nsteps; s += 12) {
 		load(f2, s + 8);
+		__builtin_amdgcn_sched_barrier(0);
 		compute(f0, s);
-		f0 = f1;
-		f1 = f2;
+		load(f0, s + 12);
+		__builtin_amdgcn_sched_barrier(0);
+		if (s + 4 < nsteps) {
+			compute(f1, s + 4);
+		}
+		load(f1, s + 16);
+		__builtin_amdgcn_sched_barrier(0);
+		if (s + 8 < nsteps) {
+			compute(f2, s + 8);
+		}
 	}
 
 	// add the four waves' partial tiles in wave order (deterministic)

@@ -12,6 +12,10 @@ import sys
 import numpy as np
 import pytest
 
+# the CPU checkers (oracle/liboracle.so, oracle/_ref) are OpenMP code with tiny parallel regions: on a many-core
+# box the default team size makes every region a scheduling storm (a 150-token tiny-model run took 290 s)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
