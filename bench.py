@@ -181,6 +181,22 @@ def main():
         dev_elapsed = time.perf_counter() - t0
         device_greedy = {"tok_s": round(args.steps / dev_elapsed, 2), "same_tokens": bool([int(t) for t in dev_toks] == toks)}
 
+    # prompt ingestion (prefill_hip, the next scope row after the decode step): extra, not `value`.
+    # MFMA-bound on the f32 matrix cores (v_mfma_f32_32x32x2_f32: 157.3 TF dense peak, MI355X_MICROARCH.md)
+    prefill = None
+    if spec.n_experts == 0 and not args.no_device_greedy:
+        n_pf = min(512, model.config.seq_len - 1)
+        prompt = [int(t) for t in np.random.default_rng(args.seed).integers(0, spec.vocab_size, size=n_pf)]
+        be.prefill(prompt[:64], 0)
+        t0 = time.perf_counter()
+        be.prefill(prompt, 0)
+        pf_elapsed = time.perf_counter() - t0
+        q_dim, kv_dim = spec.n_heads * spec.head_dim, spec.n_kv_heads * spec.head_dim
+        flop = 2.0 * n_pf * n_layers * (spec.dim * (2 * q_dim + 2 * kv_dim) + 3 * spec.dim * spec.hidden_dim)
+        prefill = {"tokens": n_pf, "tok_s": round(n_pf / pf_elapsed, 1), "vs_serial_decode": round(n_pf / pf_elapsed / tok_s, 2),
+                   "roofline": {"bound": "mfma", "achieved": round(flop / pf_elapsed / 1e12, 1), "peak": 157.3, "unit": "TFLOP/s",
+                                "frac": round(flop / pf_elapsed / 1e12 / 157.3, 4), "dtype": "f32 in / f32 accumulate"}}
+
     cpu = None
     parity = None
     if not args.no_cpu:
@@ -226,6 +242,7 @@ def main():
         "roofline": roofline,
         "stages": stage_report,
         "device_greedy": device_greedy,
+        "prefill": prefill,
         "cpu_baseline": cpu,
         "parity": parity,
         "load_seconds": round(load_s, 1),

@@ -552,12 +552,19 @@ void pf_alloc(Ctx* c) {
 	if (c->pf_x) {
 		return;
 	}
-	const int wide = c->dim > c->q_dim ? c->dim : c->q_dim;
+	// fragment-major matrices (prefill.hip.h: pf_idx) are sized in whole 64-column steps and zeroed once:
+	// their padding is read as a multiplicand of zero weights and must stay finite
+	auto frag = [&](int n) {
+		size_t bytes = (size_t)PF_NT * pf_steps(n) * 64 * sizeof(float);
+		float* p = (float*)dev_alloc(bytes);
+		HIP_CHECK(hipMemset(p, 0, bytes));
+		return p;
+	};
 	c->pf_x = (float*)dev_alloc((size_t)PF_NT * c->dim * sizeof(float));
-	c->pf_xn = (float*)dev_alloc((size_t)PF_NT * wide * sizeof(float));
+	c->pf_xn = frag(c->dim);
 	c->pf_q = (float*)dev_alloc((size_t)PF_NT * c->q_dim * sizeof(float));
-	c->pf_att = (float*)dev_alloc((size_t)PF_NT * c->q_dim * sizeof(float));
-	c->pf_h = (float*)dev_alloc((size_t)PF_NT * c->hidden * sizeof(float));
+	c->pf_att = frag(c->q_dim);
+	c->pf_h = frag(c->hidden);
 	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
 	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
 }
@@ -600,37 +607,51 @@ void prefill_chunk(Ctx* c, int nb, int pos0) {
 	struct Weights* w = &c->t->weights;
 	const int half_hd = c->head_dim / 2;
 	const int n0 = c->dim > half_hd ? c->dim : half_hd;
-	hipLaunchKernelGGL((k_pf_begin<DB>), dim3((n0 + 255) / 256, PF_NT), dim3(256), 0, g_stream, c->pf_tok, nb, pos0, c->pf_x, w->token_embedding_table, c->dim,
-	                   c->rope_freq, c->pf_rope, half_hd);
+	hipLaunchKernelGGL((k_pf_begin<DB>), dim3((n0 + 255) / 256, nb), dim3(256), 0, g_stream, c->pf_tok, pos0, c->pf_x, w->token_embedding_table, c->dim, c->rope_freq,
+	                   c->pf_rope, half_hd);
 	const dim3 block(256);
-	const int ct = (nb + 31) / 32;
+	const int cols = (nb + 63) / 64;
+	// two unit strips per wave (operands reused twice) as long as that leaves a workgroup for every CU
+	auto gemm = [&](const PfGemmArgs& a, auto EPI) {
+		constexpr int epi = decltype(EPI)::value;
+		if constexpr (epi == PF_EPI_FFN_UP) {
+			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
+		} else if ((a.M + 63) / 64 * cols >= g_ncu) {
+			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 2>), dim3((a.M + 63) / 64, cols), block, 0, g_stream, a);
+		} else {
+			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
+		}
+	};
+	using EpiQkv = std::integral_constant<int, PF_EPI_QKV>;
+	using EpiResid = std::integral_constant<int, PF_EPI_RESID>;
+	using EpiUp = std::integral_constant<int, PF_EPI_FFN_UP>;
 	PfGemmArgs a;
 	memset(&a, 0, sizeof(a));
 	a.nb = nb;
-	a.bqkv = nullptr, a.rope = c->pf_rope;
+	a.rope = c->pf_rope;
 	a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len, a.kv_pos0 = pos0;
 	a.clip = p->qkv_clip, a.gelu = p->act_gelu;
 	for (int l = 0; l < c->n_layers; ++l) {
 		// attention norm; q / k / v + bias + clip + RoPE + KV append   (src/infer.c:352-381)
-		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, c->pf_xn, c->pf_x, w->rms_att_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
-		a.xin = c->pf_xn, a.K = c->dim, a.M = c->q_dim + 2 * c->kv_dim;
+		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_att_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
+		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->q_dim + 2 * c->kv_dim;
 		a.w0 = w->wq[l], a.w1 = w->wk[l], a.w2 = w->wv[l], a.bqkv = w->bqkv[l];
 		a.out = c->pf_q;
 		a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes, a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_QKV>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+		gemm(a, EpiQkv());
 		// causal attention of every token of the chunk over the cache (its own row included)
 		launch_pf_attn<KVB>(c, l, nb, pos0);
 		// x += wo . att   (src/infer.c:408-415)
-		a.xin = c->pf_att, a.K = c->q_dim, a.M = c->dim, a.w0 = w->wo[l], a.out = c->pf_x;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_RESID>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+		a.xin = (const float4*)c->pf_att, a.K = c->q_dim, a.M = c->dim, a.w0 = w->wo[l], a.out = c->pf_x;
+		gemm(a, EpiResid());
 		// FFN   (src/infer.c:417-457); parallel-residual models reuse the attention norm's output
 		if (!p->norm_par) {
-			hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
+			hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
 		}
-		a.xin = c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_FFN_UP>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
-		a.xin = c->pf_h, a.K = c->hidden, a.M = c->dim, a.w0 = w->w2[l], a.out = c->pf_x;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_RESID>), dim3((a.M + 31) / 32, ct), block, 0, g_stream, a);
+		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
+		gemm(a, EpiUp());
+		a.xin = (const float4*)c->pf_h, a.K = c->hidden, a.M = c->dim, a.w0 = w->w2[l], a.out = c->pf_x;
+		gemm(a, EpiResid());
 	}
 	HIP_CHECK(hipGetLastError());
 }

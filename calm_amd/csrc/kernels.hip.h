@@ -689,7 +689,7 @@ struct AttnArgs {
 	const TokState* ts;
 	int head_dim, kv_mul, seq_len, n_split;
 	// batched prompt ingestion (k_attn<.., PF = true>, grid.y = token of the chunk): token b reads q + b * pf_stride,
-	// attends to cache rows [0, pf_kv0 + b] and writes out + b * pf_stride
+	// attends to cache rows [0, pf_kv0 + b] and writes row b of the fragment-major matrix `out`
 	int pf_kv0, pf_stride;
 };
 
@@ -732,7 +732,6 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
 	const float* qsrc = PF ? a.q + (size_t)blockIdx.y * a.pf_stride : a.q;
-	float* odst = PF ? a.out + (size_t)blockIdx.y * a.pf_stride : a.out;
 
 	float qv[8];
 #pragma unroll
@@ -864,10 +863,19 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			sm_merge(m, l, o, sm_m[w], sm_l[w], o2);
 		}
 		if (dvalid) {
-			if (a.n_split == 1) {
+			if constexpr (PF) {
+				// fragment-major rows of pf_stride floats (prefill.hip.h: pf_idx), the next GEMM's B operand
+				const int k = h * a.head_dim + d0, ns = (a.pf_stride + 63) >> 6, t = (int)blockIdx.y;
+#pragma unroll
+				for (int half = 0; half < 2; ++half) {
+					const int kh = k + 4 * half;
+					const size_t idx = ((((size_t)(t >> 5) * ns + (kh >> 6)) * 8 + ((kh & 31) >> 2)) << 6) + (((kh >> 5) & 1) << 5) + (t & 31);
+					((float4*)a.out)[idx] = make_float4(o[4 * half] / l, o[4 * half + 1] / l, o[4 * half + 2] / l, o[4 * half + 3] / l);
+				}
+			} else if (a.n_split == 1) {
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
-					odst[h * a.head_dim + d0 + i] = o[i] / l;
+					a.out[h * a.head_dim + d0 + i] = o[i] / l;
 				}
 			} else {
 				float* p = a.partial + ((size_t)h * a.n_split + split) * (a.head_dim + 2);

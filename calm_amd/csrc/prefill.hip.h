@@ -2,7 +2,7 @@
 //
 // The reference feeds a prompt one token at a time through forward(token, pos, FF_UPDATE_KV_ONLY)
 // (src/run.c:208,216-218; "prompt processing is serial", README.md:80).  prefill_hip does the same work
-// -- the KV cache rows of n consecutive positions -- PF_NT tokens at a time, so that every weight byte
+// -- the KV cache rows of n consecutive positions -- up to PF_NT tokens at a time, so that every weight byte
 // is streamed once per chunk instead of once per token, and the multiply-adds move to the matrix cores.
 //
 // Numerics stay those of the decode path: fp32 activations, exactly decoded weights, fp32 accumulation.
@@ -10,31 +10,49 @@
 // on this chip); the activations are NOT narrowed to fp16 / bf16 to reach the 16x faster MFMA forms --
 // that costs 3e-4..2e-3 per matvec and breaks the 1e-3 logits parity with the CPU path.
 //
-// A workgroup (4 waves) owns one tile of 32 output units x 32 tokens; its waves split the reduction
-// dimension (wave w takes every 4th step of 64 weights per row) and add their partial tiles through LDS in
-// a fixed order.  Operands go global -> registers directly: A = 32 consecutive weights of this lane's row
-// (lane = unit i, k-half kk), decoded to f32 in registers; B = the matching 32 activations of token j
-// (lane = token j, k-half kk), contiguous in the token-major activation matrix (L2 resident: 64 x dim x 4 B).
+// GEMM structure (k_pf_gemm).  A wave owns NA x 2 accumulator tiles of 32 units x 32 tokens: NA = 2 unit
+// strips (QKV, residual GEMMs) or the w1 / w3 pair of one strip (FFN-up), times two token tiles -- so every
+// decoded weight feeds two MFMAs and every activation fragment feeds two, which halves the operand traffic
+// per MFMA (one strip x one token tile measured 40 % of the MFMA peak with the operand fetch in the way).
+// The four waves of a workgroup split the reduction dimension (wave w takes every 4th step of 64 weights
+// per row) and add their partial tiles through LDS in a fixed order.  Operands go global -> registers:
+//   A  32 consecutive weights of this lane's row per step (lane = unit i, k-half kk), decoded to f32;
+//   B  the matching 32 activations of token j (lane = token j, k-half kk) from a FRAGMENT-MAJOR activation
+//      matrix (pf_idx below): a wave's 16-byte loads are 1 KiB contiguous, and the matrix is L2 resident.
 // The k order inside the dot product is permuted (both operands agree), which fp32 addition does not mind
-// beyond rounding.
+// beyond rounding.  Operands of the next step are loaded (double buffer, scheduling barrier) before the
+// current step's 128 MFMAs (8192 cycles) are issued.
 #pragma once
 
 namespace calm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PF_NT = 64; // tokens per chunk (two 32-token MFMA column tiles)
+constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
 
 enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2 };
 
+// Fragment-major activation matrix of n-float rows (GEMM B operand).  The float4 holding columns k..k+3
+// (k % 4 == 0) of token t lives at float4 index
+//     ((t / 32 * nsteps + k / 64) * 8 + k % 32 / 4) * 64 + (k % 64 / 32) * 32 + t % 32,   nsteps = ceil(n / 64)
+// i.e. [token group of 32][step of 64 columns][float4 q of the lane's 32 columns][lane = (k-half, token)]:
+// exactly the order in which a wave's lanes consume it.  Rows are padded to whole steps; the padding is
+// never written and stays zero from the allocation.
+__device__ __forceinline__ size_t pf_idx(int t, int k, int nsteps) {
+	return ((((size_t)(t >> 5) * nsteps + (k >> 6)) * 8 + ((k & 31) >> 2)) << 6) + (((k >> 5) & 1) << 5) + (t & 31);
+}
+__host__ __device__ inline int pf_steps(int n) {
+	return (n + 63) >> 6;
+}
+
 // embedding rows + RoPE table of a chunk of tokens   (src/infer.c:334-347, :223-236)
-// grid = (ceil(max(dim, head_dim/2) / 256), PF_NT); rows of tokens b >= nb are zeroed
+// grid = (ceil(max(dim, head_dim/2) / 256), nb)
 template <int DB>
-__global__ void k_pf_begin(const int* tokens, int nb, int pos0, float* X, const void* embed, int dim, const float* rope_freq, float2* rope, int half_hd) {
+__global__ void k_pf_begin(const int* tokens, int pos0, float* X, const void* embed, int dim, const float* rope_freq, float2* rope, int half_hd) {
 	const int b = blockIdx.y;
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
 	if (i < dim) {
-		X[(size_t)b * dim + i] = b < nb ? decode_elem<DB>(embed, (size_t)tokens[b] * dim + i) : 0.f;
+		X[(size_t)b * dim + i] = decode_elem<DB>(embed, (size_t)tokens[b] * dim + i);
 	}
 	if (i < half_hd) {
 		float val = (float)(pos0 + b) * rope_freq[i]; // src/infer.c:227-229
@@ -42,38 +60,48 @@ __global__ void k_pf_begin(const int* tokens, int nb, int pos0, float* X, const 
 	}
 }
 
-// out[b][:] = norm(X[b][:]) * normw, one workgroup per token   (src/infer.c:183-207)
-__global__ __launch_bounds__(256) void k_pf_norm(float* out, const float* X, const float* normw, int n, float eps, int ln) {
+// out (fragment-major) = norm(X[b][:]) * normw, one workgroup per token   (src/infer.c:183-207)
+__global__ __launch_bounds__(256) void k_pf_norm(float4* out, const float* X, const float* normw, int n, float eps, int ln) {
 	__shared__ float red[16];
-	const float* x = X + (size_t)blockIdx.x * n;
-	float* o = out + (size_t)blockIdx.x * n;
+	const int b = blockIdx.x;
+	const float4* x4 = (const float4*)(X + (size_t)b * n);
+	const float4* w4 = (const float4*)normw;
+	const int n4 = n >> 2;
 	float mean = 0.f;
 	if (ln) {
 		float s = 0.f;
-		for (int i = threadIdx.x; i < n; i += 256) {
-			s += x[i];
+		for (int i = threadIdx.x; i < n4; i += 256) {
+			float4 t = x4[i];
+			s += (t.x + t.y) + (t.z + t.w);
 		}
 		mean = block_sum<256>(s, red) / (float)n;
 	}
 	float ss = 0.f;
-	for (int i = threadIdx.x; i < n; i += 256) {
-		float d = x[i] - mean;
-		ss += d * d;
+	for (int i = threadIdx.x; i < n4; i += 256) {
+		float4 t = x4[i];
+		float a = t.x - mean, c = t.y - mean, d = t.z - mean, e = t.w - mean;
+		ss += (a * a + c * c) + (d * d + e * e);
 	}
 	float var = block_sum<256>(ss, red) / (float)n;
 	float scale = 1.0f / sqrtf(var + eps);
-	for (int i = threadIdx.x; i < n; i += 256) {
-		o[i] = (x[i] - mean) * scale * normw[i];
+	const int nsteps = pf_steps(n);
+	for (int i = threadIdx.x; i < n4; i += 256) {
+		float4 t = x4[i], g = w4[i];
+		t.x = (t.x - mean) * scale * g.x;
+		t.y = (t.y - mean) * scale * g.y;
+		t.z = (t.z - mean) * scale * g.z;
+		t.w = (t.w - mean) * scale * g.w;
+		out[pf_idx(b, 4 * i, nsteps)] = t;
 	}
 }
 
 struct PfGemmArgs {
-	const float* xin;    // [PF_NT][K] activations, token-major
+	const float4* xin;   // fragment-major activations (pf_idx), rows of K floats
 	const void *w0, *w1, *w2; // QKV: wq, wk, wv;  FFN_UP: w1, w3;  RESID: the matrix
 	int K, M, nb;        // reduction length, output units, valid tokens
-	float* out;          // QKV: Q [PF_NT][q_dim];  RESID: X [PF_NT][M] (accumulated into);  FFN_UP: H [PF_NT][M]
+	float* out;          // QKV: Q [token][q_dim];  RESID: X [token][M] (accumulated into);  FFN_UP: H, fragment-major rows of M
 	const float* bqkv;
-	const float2* rope;  // [PF_NT][head_dim / 2]
+	const float2* rope;  // [token][head_dim / 2]
 	void *kc, *vc;       // this layer's caches, [kv_head][seq_len][head_dim]
 	int q_dim, kv_dim, head_dim, seq_len, kv_pos0;
 	float clip;
@@ -108,65 +136,83 @@ __device__ __forceinline__ void pf_decode(u32x4 v, float (&wf)[Fmt<DB>::G]) {
 	}
 }
 
-// grid = (ceil(M / 32), ceil(nb / 32)), 256 threads
-template <int DB, int KVB, int EPI>
+// Weight streams per wave: S strips of 32 units (S = 2 when the grid still fills the chip, else 1), except
+// FFN-up whose two streams are w1 and w3 of ONE strip.
+template <int EPI, int S>
+struct PfTile {
+	static constexpr int NA = EPI == PF_EPI_FFN_UP ? 2 : S;
+	static constexpr int UNITS = EPI == PF_EPI_FFN_UP ? 32 : 32 * S; // output units per workgroup
+};
+
+// grid = (ceil(M / UNITS), ceil(nb / 64)), 256 threads
+template <int DB, int KVB, int EPI, int S>
 __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	constexpr int G = Fmt<DB>::G;
-	constexpr int NMAT = EPI == PF_EPI_FFN_UP ? 2 : 1;
-	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and step
-	__shared__ float part[3][NMAT * 16][64]; // partial tiles of waves 1..3
+	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and step (32 weights per k-half)
+	constexpr int NA = PfTile<EPI, S>::NA, NC = 2;
+	__shared__ float part[3][NA * NC * 16][64]; // partial tiles of waves 1..3 (24 / 48 KiB)
 
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
-	const int unit0 = blockIdx.x * 32, tok0 = blockIdx.y * 32;
+	const int unit0 = blockIdx.x * PfTile<EPI, S>::UNITS, tok0 = blockIdx.y * 64;
 	const size_t row_bytes = (size_t)a.K * DB / 8;
-	const int npieces = a.K / G;                   // 16-byte pieces per row
-	const int nsteps = (npieces + 2 * P - 1) / (2 * P); // a step = P pieces (32 weights) per k-half: 32 MFMAs per matrix
+	const int npieces = a.K / G;      // 16-byte pieces per row
+	const int nsteps = pf_steps(a.K); // a step = 64 weights of a row = 32 MFMAs per accumulator tile
 
-	// A: this lane's weight row(s); B: this lane's token row.  Indices are clamped, never branched on:
-	// surplus lanes read real data and their results are dropped in the epilogue.
-	const int u = min(unit0 + j, a.M - 1);
-	const unsigned char* rowp[NMAT];
-	if constexpr (EPI == PF_EPI_QKV) {
-		const bool is_q = u < a.q_dim, is_k = u < a.q_dim + a.kv_dim;
-		const unsigned char* base = (const unsigned char*)(is_q ? a.w0 : (is_k ? a.w1 : a.w2));
-		const int ul = u - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
-		rowp[0] = base + (size_t)ul * row_bytes;
-	} else if constexpr (EPI == PF_EPI_FFN_UP) {
-		rowp[0] = (const unsigned char*)a.w0 + (size_t)u * row_bytes;
-		rowp[1] = (const unsigned char*)a.w1 + (size_t)u * row_bytes;
-	} else {
-		rowp[0] = (const unsigned char*)a.w0 + (size_t)u * row_bytes;
+	// A: this lane's weight rows.  Row indices are clamped, never branched on: surplus lanes read real data
+	// and their results are dropped in the epilogue.
+	const unsigned char* rowp[NA];
+#pragma unroll
+	for (int s = 0; s < NA; ++s) {
+		if constexpr (EPI == PF_EPI_QKV) {
+			const int u = min(unit0 + 32 * s + j, a.M - 1);
+			const bool is_q = u < a.q_dim, is_k = u < a.q_dim + a.kv_dim;
+			const unsigned char* base = (const unsigned char*)(is_q ? a.w0 : (is_k ? a.w1 : a.w2));
+			const int ul = u - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
+			rowp[s] = base + (size_t)ul * row_bytes;
+		} else if constexpr (EPI == PF_EPI_FFN_UP) {
+			rowp[s] = (const unsigned char*)(s ? a.w1 : a.w0) + (size_t)min(unit0 + j, a.M - 1) * row_bytes;
+		} else {
+			rowp[s] = (const unsigned char*)a.w0 + (size_t)min(unit0 + 32 * s + j, a.M - 1) * row_bytes;
+		}
 	}
-	const float* xrow = a.xin + (size_t)min(tok0 + j, a.nb - 1) * a.K;
+	// B: the two 32-token groups of this workgroup (the matrix is allocated for whole groups of 64 tokens)
+	const float4* xg = a.xin + (size_t)(tok0 >> 5) * nsteps * 512 + lane;
 
 	struct Frag {
-		u32x4 w[NMAT][P];
-		f32x4 x[8];
+		u32x4 w[NA][P];
+		f32x4 x[NC][8];
 	};
 	auto load = [&](Frag& f, int s) {
-		const int p0 = (2 * min(s, nsteps - 1) + kk) * P;
+		const int sc = min(s, nsteps - 1);
+		const int p0 = (2 * sc + kk) * P;
 #pragma unroll
 		for (int i = 0; i < P; ++i) {
 			const int piece = min(p0 + i, npieces - 1);
 #pragma unroll
-			for (int m = 0; m < NMAT; ++m) {
-				f.w[m][i] = __builtin_nontemporal_load((gptr16)rowp[m] + piece);
+			for (int n = 0; n < NA; ++n) {
+				f.w[n][i] = __builtin_nontemporal_load((gptr16)rowp[n] + piece);
 			}
-			const f32x4* xp = (const f32x4*)(xrow + (size_t)piece * G);
+		}
 #pragma unroll
-			for (int q = 0; q < G / 4; ++q) {
-				f.x[i * (G / 4) + q] = xp[q];
+		for (int c = 0; c < NC; ++c) {
+			const f32x4* xp = (const f32x4*)(xg + ((size_t)c * nsteps + sc) * 512);
+#pragma unroll
+			for (int q = 0; q < 8; ++q) {
+				f.x[c][q] = xp[q * 64];
 			}
 		}
 	};
 
-	f32x16 acc[NMAT];
+	f32x16 acc[NA][NC];
 #pragma unroll
-	for (int m = 0; m < NMAT; ++m) {
+	for (int n = 0; n < NA; ++n) {
 #pragma unroll
-		for (int r = 0; r < 16; ++r) {
-			acc[m][r] = 0.f;
+		for (int c = 0; c < NC; ++c) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				acc[n][c][r] = 0.f;
+			}
 		}
 	}
 	auto compute = [&](const Frag& f, int s) {
@@ -174,56 +220,55 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 #pragma unroll
 		for (int i = 0; i < P; ++i) {
 			const bool valid = p0 + i < npieces; // ragged rows: pieces past the row's end multiply as zeros
-			float wf[NMAT][G];
+			float wf[NA][G];
 #pragma unroll
-			for (int m = 0; m < NMAT; ++m) {
-				u32x4 v = f.w[m][i];
+			for (int n = 0; n < NA; ++n) {
+				u32x4 v = f.w[n][i];
 				if (!valid) {
 					v = (u32x4){0u, 0u, 0u, 0u}; // decodes to zeros in every format
 				}
-				pf_decode<DB>(v, wf[m]);
+				pf_decode<DB>(v, wf[n]);
 			}
 #pragma unroll
 			for (int e = 0; e < G; ++e) {
 #pragma unroll
-				for (int m = 0; m < NMAT; ++m) {
-					acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[m][e], f.x[(i * G + e) / 4][(i * G + e) % 4], acc[m], 0, 0, 0);
+				for (int n = 0; n < NA; ++n) {
+#pragma unroll
+					for (int c = 0; c < NC; ++c) {
+						acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[n][e], f.x[c][(i * G + e) / 4][(i * G + e) % 4], acc[n][c], 0, 0, 0);
+					}
 				}
 			}
 		}
 	};
 
-	// wave w takes steps w, w+4, ...; two steps of operands stay in flight ahead of the one being multiplied.
-	// The loop is unrolled by three so the three fragment buffers rotate by name (no register copies, which
-	// would wait for the loads just issued), and a scheduling barrier after each load block keeps the
-	// compiler from sinking the loads down to their first use (it did: 33 % of the f32 MFMA peak, vmcnt(0)
-	// in front of every other MFMA).  Loads are clamped, never skipped, so s_waitcnt stays counted.
-	Frag f0, f1, f2;
+	// wave w takes steps w, w+4, ...  The loop is unrolled by two so the two operand buffers alternate by name
+	// (no register copies, which would wait for the loads just issued), and a scheduling barrier after each
+	// load block keeps the compiler from sinking the loads down to their first use (it did: vmcnt(0) in front
+	// of every other MFMA).  Loads are clamped, never skipped, so s_waitcnt stays counted.
+	Frag f0, f1;
 	load(f0, wave);
-	load(f1, wave + 4);
-	for (int s = wave; s < nsteps; s += 12) {
-		load(f2, s + 8);
+	for (int s = wave; s < nsteps; s += 8) {
+		load(f1, s + 4);
 		__builtin_amdgcn_sched_barrier(0);
 		compute(f0, s);
-		load(f0, s + 12);
+		load(f0, s + 8);
 		__builtin_amdgcn_sched_barrier(0);
 		if (s + 4 < nsteps) {
 			compute(f1, s + 4);
-		}
-		load(f1, s + 16);
-		__builtin_amdgcn_sched_barrier(0);
-		if (s + 8 < nsteps) {
-			compute(f2, s + 8);
 		}
 	}
 
 	// add the four waves' partial tiles in wave order (deterministic)
 	if (wave > 0) {
 #pragma unroll
-		for (int m = 0; m < NMAT; ++m) {
+		for (int n = 0; n < NA; ++n) {
 #pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				part[wave - 1][m * 16 + r][lane] = acc[m][r];
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					part[wave - 1][(n * NC + c) * 16 + r][lane] = acc[n][c][r];
+				}
 			}
 		}
 	}
@@ -234,69 +279,78 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 #pragma unroll
 	for (int w = 0; w < 3; ++w) {
 #pragma unroll
-		for (int m = 0; m < NMAT; ++m) {
+		for (int n = 0; n < NA; ++n) {
 #pragma unroll
-			for (int r = 0; r < 16; ++r) {
-				acc[m][r] += part[w][m * 16 + r][lane];
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					acc[n][c][r] += part[w][(n * NC + c) * 16 + r][lane];
+				}
 			}
 		}
 	}
 
 	// C layout: column (token) = lane & 31, row (unit) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-	const int token = tok0 + j;
-	if (token >= a.nb) {
-		return;
-	}
 #pragma unroll
-	for (int g = 0; g < 4; ++g) {
-		const int ub = unit0 + 8 * g + 4 * kk; // four consecutive units; M is a multiple of 4
-		if (ub >= a.M) {
+	for (int c = 0; c < NC; ++c) {
+		const int token = tok0 + 32 * c + j;
+		if (token >= a.nb) {
 			continue;
 		}
-		if constexpr (EPI == PF_EPI_RESID) {
-			float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
-			float4 t = *p;
-			t.x += acc[0][4 * g], t.y += acc[0][4 * g + 1], t.z += acc[0][4 * g + 2], t.w += acc[0][4 * g + 3];
-			*p = t;
-		} else if constexpr (EPI == PF_EPI_FFN_UP) {
-			float h[4];
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				float up = acc[0][4 * g + e], gt = acc[1][4 * g + e];
-				h[e] = (a.gelu ? act_gelu(up) : act_silu(up)) * gt; // src/infer.c:440-450
-			}
-			*(float4*)(a.out + (size_t)token * a.M + ub) = make_float4(h[0], h[1], h[2], h[3]);
-		} else {
+		for (int n = 0; n < (EPI == PF_EPI_FFN_UP ? 1 : NA); ++n) {
 #pragma unroll
-			for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
-				const int uu = ub + 2 * pr;
-				float v0 = acc[0][4 * g + 2 * pr], v1 = acc[0][4 * g + 2 * pr + 1];
-				if (a.bqkv) {
-					v0 += a.bqkv[uu];
-					v1 += a.bqkv[uu + 1];
+			for (int g = 0; g < 4; ++g) {
+				const int ub = unit0 + 32 * n + 8 * g + 4 * kk; // four consecutive units; M is a multiple of 4
+				if (ub >= a.M) {
+					continue;
 				}
-				v0 = clipf(v0, a.clip);
-				v1 = clipf(v1, a.clip);
-				if (uu < a.q_dim + a.kv_dim) { // src/infer.c:223-236
-					const int ul = uu < a.q_dim ? uu : uu - a.q_dim;
-					const float2 cs = a.rope[(size_t)token * (a.head_dim >> 1) + ((ul % a.head_dim) >> 1)];
-					const float r0 = v0 * cs.x - v1 * cs.y, r1 = v0 * cs.y + v1 * cs.x;
-					v0 = r0, v1 = r1;
-				}
-				if (uu < a.q_dim) {
-					*(float2*)(a.out + (size_t)token * a.q_dim + uu) = make_float2(v0, v1);
-				} else {
-					int jl = uu - a.q_dim;
-					void* cache = a.kc;
-					if (jl >= a.kv_dim) {
-						jl -= a.kv_dim;
-						cache = a.vc;
+				if constexpr (EPI == PF_EPI_RESID) {
+					float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
+					float4 t = *p;
+					t.x += acc[n][c][4 * g], t.y += acc[n][c][4 * g + 1], t.z += acc[n][c][4 * g + 2], t.w += acc[n][c][4 * g + 3];
+					*p = t;
+				} else if constexpr (EPI == PF_EPI_FFN_UP) {
+					float h[4];
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						float up = acc[0][c][4 * g + e], gt = acc[1][c][4 * g + e];
+						h[e] = (a.gelu ? act_gelu(up) : act_silu(up)) * gt; // src/infer.c:440-450
 					}
-					const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
-					if constexpr (KVB == 16) {
-						*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // src/infer.c:378-381
-					} else {
-						*(unsigned short*)((unsigned char*)cache + off) = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff);
+					((float4*)a.out)[pf_idx(token, ub, pf_steps(a.M))] = make_float4(h[0], h[1], h[2], h[3]);
+				} else {
+#pragma unroll
+					for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
+						const int uu = ub + 2 * pr;
+						float v0 = acc[n][c][4 * g + 2 * pr], v1 = acc[n][c][4 * g + 2 * pr + 1];
+						if (a.bqkv) {
+							v0 += a.bqkv[uu];
+							v1 += a.bqkv[uu + 1];
+						}
+						v0 = clipf(v0, a.clip);
+						v1 = clipf(v1, a.clip);
+						if (uu < a.q_dim + a.kv_dim) { // src/infer.c:223-236
+							const int ul = uu < a.q_dim ? uu : uu - a.q_dim;
+							const float2 cs = a.rope[(size_t)token * (a.head_dim >> 1) + ((ul % a.head_dim) >> 1)];
+							const float r0 = v0 * cs.x - v1 * cs.y, r1 = v0 * cs.y + v1 * cs.x;
+							v0 = r0, v1 = r1;
+						}
+						if (uu < a.q_dim) {
+							*(float2*)(a.out + (size_t)token * a.q_dim + uu) = make_float2(v0, v1);
+						} else {
+							int jl = uu - a.q_dim;
+							void* cache = a.kc;
+							if (jl >= a.kv_dim) {
+								jl -= a.kv_dim;
+								cache = a.vc;
+							}
+							const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
+							if constexpr (KVB == 16) {
+								*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // src/infer.c:378-381
+							} else {
+								*(unsigned short*)((unsigned char*)cache + off) = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff);
+							}
+						}
 					}
 				}
 			}
