@@ -416,20 +416,20 @@ def test_prefill_equals_the_serial_prompt_loop(hiplib, case, kvbits):
 
 
 def test_prefill_in_two_calls_and_odd_chunks(hiplib):
-    """a prompt longer than one 64-token chunk, split at awkward places, with the second call starting at pos > 0"""
-    spec = cf.tiny_spec("pf", max_seq_len=256, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=500)
+    """a prompt longer than one 256-token chunk, split at awkward places, with the second call starting at pos > 0"""
+    spec = cf.tiny_spec("pf", max_seq_len=512, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=500)
     tensors, md = cf.synth_model(spec, "fp8", seed=21)
     model = HostModel(tensors, md)
     rng = np.random.default_rng(4)
-    toks = [int(t) for t in rng.integers(0, 500, size=150)]
+    toks = [int(t) for t in rng.integers(0, 500, size=400)]
     o = oracle.OracleBackend(model)
     b = HipBackend(model)
     try:
         for pos, tok in enumerate(toks[:-1]):
             o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         lo = o.forward(toks[-1], len(toks) - 1, 0).copy()
-        b.prefill(toks[:97], 0)     # chunks of 64 + 33
-        b.prefill(toks[97:149], 97)  # one chunk of 52 that attends to the 97 rows before it
+        b.prefill(toks[:297], 0)       # chunks of 256 + 41
+        b.prefill(toks[297:399], 297)  # one chunk of 102 (64 + 38) that attends to the 297 rows before it
         lb = b.forward(toks[-1], len(toks) - 1, 0)
         assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
         b.prefill([], 0)  # empty prompt: no-op
