@@ -125,6 +125,9 @@ struct Ctx {
 	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
 	float2* pf_rope = nullptr;
 	int* pf_tok = nullptr;
+	// ... of a mixture-of-experts model: gate logits, per-expert row lists, one expert's gathered rows
+	float *pf_gate = nullptr, *pf_listw = nullptr, *pf_xe = nullptr;
+	int *pf_list = nullptr, *pf_count = nullptr;
 	// graph cache: (n_split, kv_only, sink, chained, argmax)
 	std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
 	// argument block of the begin-token kernel (patched per replay)
@@ -567,6 +570,13 @@ void pf_alloc(Ctx* c) {
 	c->pf_h = frag(c->hidden);
 	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
 	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
+	if (c->n_experts > 0) {
+		c->pf_gate = (float*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(float));
+		c->pf_list = (int*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(int));
+		c->pf_listw = (float*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(float));
+		c->pf_count = (int*)dev_alloc(c->n_experts * sizeof(int));
+		c->pf_xe = frag(c->dim);
+	}
 }
 
 template <int KVB, int LPR>
@@ -648,10 +658,31 @@ void prefill_chunk(Ctx* c, int nb, int pos0) {
 		if (!p->norm_par) {
 			hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
 		}
-		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
-		gemm(a, EpiUp());
-		a.xin = (const float4*)c->pf_h, a.K = c->hidden, a.M = c->dim, a.w0 = w->w2[l], a.out = c->pf_x;
-		gemm(a, EpiResid());
+		if (c->n_experts == 0) {
+			a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
+			gemm(a, EpiUp());
+			a.xin = (const float4*)c->pf_h, a.K = c->hidden, a.M = c->dim, a.w0 = w->w2[l], a.out = c->pf_x;
+			gemm(a, EpiResid());
+			continue;
+		}
+		// mixture of experts (src/infer.c:422-457): gate logits of every token, routing, then per expert its
+		// rows are gathered, pushed through w1/w3 and w2, and scattered back weighted.  Experts run one after
+		// the other on the stream, so a token's contributions are added in expert order -- deterministic.
+		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->n_experts, a.w0 = w->moegate[l], a.out = c->pf_gate;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_STORE, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
+		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, c->pf_list, c->pf_listw, c->pf_count);
+		const size_t up_bytes = (size_t)c->hidden * c->dim * DB / 8;
+		for (int e = 0; e < c->n_experts; ++e) {
+			hipLaunchKernelGGL(k_pf_gather, dim3(nb), block, 0, g_stream, (float4*)c->pf_xe, (const float4*)c->pf_xn, c->pf_list + (size_t)e * PF_NT, c->pf_count + e, c->dim);
+			PfGemmArgs m = a;
+			m.nb_dev = c->pf_count + e;
+			m.xin = (const float4*)c->pf_xe, m.K = c->dim, m.M = c->hidden;
+			m.w0 = (const char*)w->w1[l] + e * up_bytes, m.w1 = (const char*)w->w3[l] + e * up_bytes, m.out = c->pf_h;
+			gemm(m, EpiUp());
+			m.xin = (const float4*)c->pf_h, m.K = c->hidden, m.M = c->dim, m.w0 = (const char*)w->w2[l] + e * up_bytes, m.out = c->pf_x;
+			m.rows = c->pf_list + (size_t)e * PF_NT, m.roww = c->pf_listw + (size_t)e * PF_NT;
+			gemm(m, std::integral_constant<int, PF_EPI_SCATTER>());
+		}
 	}
 	HIP_CHECK(hipGetLastError());
 }
@@ -919,7 +950,7 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}
-	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok};
+	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_listw, c->pf_xe, c->pf_list, c->pf_count};
 	for (void* b : pf_bufs) {
 		if (b) {
 			HIP_CHECK(hipFree(b));
@@ -974,11 +1005,10 @@ extern "C" void prefill_hip(struct Transformer* t, const int* tokens, int n, int
 	for (int i = 0; i < n; ++i) {
 		CALM_REQUIRE(tokens[i] >= 0 && tokens[i] < c->vocab, "token out of range");
 	}
-	// The batched path covers dense models while the rolling buffer has not wrapped; everything else --
-	// mixture-of-experts routing (per-token expert sets), positions at or past seq_len (sink rotation
-	// between tokens) -- goes through the decode path one token at a time, still on the device.
+	// The batched path covers the positions before the rolling buffer wraps; positions at or past seq_len
+	// (sink rotation between tokens) go through the decode path one token at a time, still on the device.
 	int done = 0;
-	if (c->n_experts == 0 && c->t->weights.token_embedding_table) {
+	if ((c->n_experts == 0 || c->n_active <= PF_MAX_ACTIVE) && c->t->weights.token_embedding_table) {
 		pf_alloc(c);
 		while (done < n && pos + done < c->seq_len) {
 			int nb = n - done < PF_NT ? n - done : PF_NT;

@@ -30,7 +30,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
 
-enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2 };
+enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3, PF_EPI_SCATTER = 4 };
+constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
 
 // Fragment-major activation matrix of n-float rows (GEMM B operand).  The float4 holding columns k..k+3
 // (k % 4 == 0) of token t lives at float4 index
@@ -95,6 +96,64 @@ __global__ __launch_bounds__(256) void k_pf_norm(float4* out, const float* X, co
 	}
 }
 
+// Mixture-of-experts routing of a chunk (src/infer.c:277-305 per token): top-k by logit, first maximum wins
+// ties, weights = softmax over the selected logits; then one list of (token, weight) rows per expert, in
+// token order (deterministic).  One workgroup of PF_NT threads.
+__global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int* list, float* listw, int* count) {
+	__shared__ int se[PF_NT * PF_MAX_ACTIVE];
+	__shared__ float sw[PF_NT * PF_MAX_ACTIVE];
+	const int t = threadIdx.x;
+	if (t < nb) {
+		const float* g = gate + (size_t)t * n_experts;
+		float max_val = -3.402823466e+38f;
+		for (int j = 0; j < n_experts; ++j) {
+			max_val = max_val < g[j] ? g[j] : max_val;
+		}
+		unsigned long long mask = 0;
+		float wsum = 0.f;
+		for (int k = 0; k < n_active; ++k) {
+			int best = -1;
+			for (int j = 0; j < n_experts; ++j) {
+				if ((mask & (1ull << j)) == 0 && (best == -1 || g[j] > g[best])) {
+					best = j;
+				}
+			}
+			se[t * n_active + k] = best;
+			wsum += expf(g[best] - max_val);
+			mask |= 1ull << best;
+		}
+		for (int k = 0; k < n_active; ++k) {
+			sw[t * n_active + k] = expf(g[se[t * n_active + k]] - max_val) / wsum;
+		}
+	}
+	__syncthreads();
+	if (t < n_experts) {
+		int c = 0;
+		for (int tok = 0; tok < nb; ++tok) {
+			for (int k = 0; k < n_active; ++k) {
+				if (se[tok * n_active + k] == t) {
+					list[t * PF_NT + c] = tok;
+					listw[t * PF_NT + c] = sw[tok * n_active + k];
+					++c;
+				}
+			}
+		}
+		count[t] = c;
+	}
+}
+
+// rows of one expert: dst row i (fragment-major) = src row list[i]; grid = PF_NT workgroups
+__global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* src, const int* list, const int* count, int n) {
+	const int i = blockIdx.x;
+	if (i >= *count) {
+		return;
+	}
+	const int t = list[i], nsteps = pf_steps(n);
+	for (int k4 = threadIdx.x; k4 < (n >> 2); k4 += 256) {
+		dst[pf_idx(i, 4 * k4, nsteps)] = src[pf_idx(t, 4 * k4, nsteps)];
+	}
+}
+
 struct PfGemmArgs {
 	const float4* xin;   // fragment-major activations (pf_idx), rows of K floats
 	const void *w0, *w1, *w2; // QKV: wq, wk, wv;  FFN_UP: w1, w3;  RESID: the matrix
@@ -106,6 +165,10 @@ struct PfGemmArgs {
 	int q_dim, kv_dim, head_dim, seq_len, kv_pos0;
 	float clip;
 	int gelu;
+	// mixture of experts: the GEMM runs over the rows gathered for ONE expert
+	const int* nb_dev;   // != nullptr: the number of valid rows is read from device memory (the routing decided it)
+	const int* rows;     // SCATTER: token of each gathered row
+	const float* roww;   // SCATTER: routing weight of each gathered row
 };
 
 // one 16-byte piece of a weight row -> its G weights as f32 (exact in all three formats)
@@ -155,6 +218,10 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
 	const int unit0 = blockIdx.x * PfTile<EPI, S>::UNITS, tok0 = blockIdx.y * 64;
+	const int nb = a.nb_dev ? *a.nb_dev : a.nb;
+	if (tok0 >= nb) {
+		return; // an expert that received fewer rows than the grid was sized for
+	}
 	const size_t row_bytes = (size_t)a.K * DB / 8;
 	const int npieces = a.K / G;      // 16-byte pieces per row
 	const int nsteps = pf_steps(a.K); // a step = 64 weights of a row = 32 MFMAs per accumulator tile
@@ -294,7 +361,7 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 #pragma unroll
 	for (int c = 0; c < NC; ++c) {
 		const int token = tok0 + 32 * c + j;
-		if (token >= a.nb) {
+		if (token >= nb) {
 			continue;
 		}
 #pragma unroll
@@ -309,6 +376,14 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 					float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
 					float4 t = *p;
 					t.x += acc[n][c][4 * g], t.y += acc[n][c][4 * g + 1], t.z += acc[n][c][4 * g + 2], t.w += acc[n][c][4 * g + 3];
+					*p = t;
+				} else if constexpr (EPI == PF_EPI_STORE) {
+					*(float4*)(a.out + (size_t)token * a.M + ub) = make_float4(acc[n][c][4 * g], acc[n][c][4 * g + 1], acc[n][c][4 * g + 2], acc[n][c][4 * g + 3]);
+				} else if constexpr (EPI == PF_EPI_SCATTER) { // x[token of the row] += routing weight * (w2_e . h)   (src/infer.c:452-456)
+					const float wgt = a.roww[token];
+					float4* p = (float4*)(a.out + (size_t)a.rows[token] * a.M + ub);
+					float4 t = *p;
+					t.x += wgt * acc[n][c][4 * g], t.y += wgt * acc[n][c][4 * g + 1], t.z += wgt * acc[n][c][4 * g + 2], t.w += wgt * acc[n][c][4 * g + 3];
 					*p = t;
 				} else if constexpr (EPI == PF_EPI_FFN_UP) {
 					float h[4];

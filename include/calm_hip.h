@@ -79,8 +79,9 @@ float* decode_greedy_hip(struct Transformer* transformer, int token, int pos, in
  * serial"), computed 64 tokens at a time: weights are streamed once per chunk and the multiply-adds run on
  * the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32), so the cache rows agree with the serial path to
  * fp32 rounding.  Returns after the work is complete (`tokens` is host memory and may be reused).
- * Mixture-of-experts models and positions at or beyond seq_len (rolling buffer) are processed through the
- * decode path one token at a time inside the call -- same result, no speed-up. */
+ * Mixture-of-experts models are routed per token on the device and each expert runs one GEMM over the rows
+ * routed to it.  Positions at or beyond seq_len (rolling buffer, sink rotation between tokens) are processed
+ * through the decode path one token at a time inside the call -- same result, no speed-up. */
 void prefill_hip(struct Transformer* transformer, const int* tokens, int n, int pos);
 
 /* Layer-pipeline stage (for models beyond one GPU's 288 GB): `transformer` describes

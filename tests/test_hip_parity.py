@@ -438,12 +438,12 @@ def test_prefill_in_two_calls_and_odd_chunks(hiplib):
         o.close()
 
 
-@pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16")])
-def test_prefill_full_width_matches_serial(hiplib, name, dtype):
-    """BASELINE shapes at full width (2 layers): 100-token prompt, batched vs serial ingestion on the GPU, and
+@pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 2), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1), ("dbrx-132b", "fp8", 1)])
+def test_prefill_full_width_matches_serial(hiplib, name, dtype, layers):
+    """BASELINE shapes at full width (1-2 layers): 100-token prompt, batched vs serial ingestion on the GPU, and
     the oracle's logits after a 12-token prompt"""
     spec = cf.SPECS[name]
-    tensors, md = cf.synth_model_big(spec, dtype, seed=9, n_layers=2)
+    tensors, md = cf.synth_model_big(spec, dtype, seed=9, n_layers=layers)
     model = HostModel(tensors, md, context=128)
     rng = np.random.default_rng(8)
     toks = [int(t) for t in rng.integers(0, spec.vocab_size, size=101)]
