@@ -30,7 +30,8 @@ for n in (64, N):
     t0 = time.perf_counter()
     be.prefill(toks[:n], 0)
     dt = time.perf_counter() - t0
-    flop = 2.0 * n * L * (spec.dim * (spec.n_heads * spec.head_dim * 2 + 2 * spec.n_kv_heads * spec.head_dim) + 3 * spec.dim * spec.hidden_dim)
+    act = spec.n_experts_active if spec.n_experts else 1
+    flop = 2.0 * n * L * (spec.dim * (spec.n_heads * spec.head_dim * 2 + 2 * spec.n_kv_heads * spec.head_dim) + 3 * act * spec.dim * spec.hidden_dim)
     print(f"prefill {n:5d} tokens, L={L}: {dt*1e3:8.2f} ms = {n/dt:9.0f} tok/s ({dt/n/L*1e6:7.2f} us/token/layer, {flop/dt/1e12:6.1f} TFLOP/s f32); "
           f"full depth ({spec.n_layers} layers): {n/dt*L/spec.n_layers:8.0f} tok/s")
 lg_b = be.forward(toks[N - 1], N - 1, 0).copy()
