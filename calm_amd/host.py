@@ -273,11 +273,13 @@ def argmax_first(logits: np.ndarray) -> int:
     return int(np.argmax(logits))
 
 
-def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int, pos_offset: int = 0, kvbits: int = 16):
+def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int, pos_offset: int = 0, kvbits: int = 16, batched_prompt: bool = False):
     """greedy decode loop of src/run.c:167-256 (temperature 0): returns (tokens, stats).
 
     The first len(prompt)-1 positions are KV-only prompt steps; timing covers the whole loop, and
     tok/s = positions / elapsed with prompt positions included, like the reference (run.c:249-253).
+    batched_prompt: hand those positions to prefill_hip in one call instead (INTEGRATION.md section E);
+    same tokens out.
     """
     FF = abi.FF_UPDATE_KV_ONLY
     n_prompt = len(prompt_tokens)
@@ -287,6 +289,13 @@ def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int
     read_bytes = 0
     _, _, n_bw = model.accounting()
     t0 = time.perf_counter()
+    if batched_prompt and n_prompt > 1 and steps >= n_prompt:
+        backend.prefill(prompt_tokens[: n_prompt - 1], pos_offset)
+        for p in range(n_prompt - 1):
+            read_bytes += n_bw + model.kv_bandwidth(kvbits, p + pos_offset)
+        out.extend(int(t) for t in prompt_tokens[1:])
+        pos = n_prompt - 1
+        token = int(prompt_tokens[pos])
     while pos < steps:
         flags = FF if pos < n_prompt - 1 else 0
         logits = backend.forward(token, pos + pos_offset, flags)

@@ -152,6 +152,11 @@ class _CpuBackend:
             return None
         return np.ctypeslib.as_array(p, shape=(self.vocab,))
 
+    def prefill(self, tokens, pos: int) -> None:
+        """the reference's serial prompt loop (src/run.c:204-218): what prefill_hip must be equivalent to"""
+        for i, tok in enumerate(tokens):
+            self._forward(C.byref(self.t), int(tok), pos + i, abi.FF_UPDATE_KV_ONLY)
+
     def kv(self, layer: int, which: int) -> np.ndarray:
         c = self.model.config
         kv_dim = c.head_dim * c.n_kv_heads

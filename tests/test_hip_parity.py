@@ -466,3 +466,17 @@ def test_prefill_full_width_matches_serial(hiplib, name, dtype, layers):
         serial.close()
         batched.close()
         o.close()
+
+
+@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "bias_tied_gf4"])
+def test_generate_with_a_batched_prompt_continues_the_reference_stream(hiplib, case):
+    """the host loop with the prompt handed to prefill_hip: a 9-token prompt taken from the reference's greedy
+    stream must be continued by exactly the tokens the reference produced next"""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    b = HipBackend(model)
+    try:
+        out, _ = generate(b, model, toks[:9], len(toks), batched_prompt=True)
+        assert out[:-1] == toks[1:]
+    finally:
+        b.close()

@@ -55,3 +55,20 @@ def test_generate_prompt_positions_are_kv_only():
     assert calls == [(7, 0, 1), (8, 1, 1), (9, 2, 0), (1, 3, 0), (1, 4, 0)]
     assert out == [8, 9, 1, 1, 1]
     assert argmax_first(np.array([1.0, 5.0, 5.0])) == 1
+
+
+def test_generate_with_batched_prompt_is_the_same_loop():
+    """batched_prompt=True hands the prompt positions to backend.prefill in ONE call and must yield the same
+    tokens and the same byte accounting as the serial prompt loop"""
+    model, z = load_golden("tiny_fp16")
+    toks = [int(t) for t in z["tokens"]]
+    a, b = oracle.OracleBackend(model), oracle.OracleBackend(model)
+    calls = []
+    real = b.prefill
+    b.prefill = lambda tokens, pos: (calls.append((list(tokens), pos)), real(tokens, pos))[1]
+    out_a, st_a = generate(a, model, toks[:7], len(toks))
+    out_b, st_b = generate(b, model, toks[:7], len(toks), batched_prompt=True)
+    assert out_a == out_b and out_a[:-1] == toks[1:]
+    assert calls == [(toks[:6], 0)]
+    assert st_a["read_bytes"] == st_b["read_bytes"] and st_a["tokens"] == st_b["tokens"]
+    a.close(), b.close()
