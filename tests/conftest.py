@@ -72,3 +72,23 @@ def load_golden(name):
     model = HostModel.from_file(os.path.join(GOLDEN, name + ".calm"))
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     return model, z
+
+
+def run_torchrun(script, world: int, env: dict, attempts: int = 3):
+    """launch `script` under torch.distributed.run on 127.0.0.1 with a free port; a rendezvous that loses the race for
+    its port (the probe socket is closed before torchrun binds it) is retried on a fresh port"""
+    import socket
+    import subprocess
+
+    r = None
+    for _ in range(attempts):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        r = subprocess.run(
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
+            env=env, capture_output=True, text=True, timeout=300)
+        if r.returncode == 0:
+            break
+    return r

@@ -15,7 +15,7 @@ import pytest
 from calm_amd import calmfile as cf
 from calm_amd.host import HostModel
 from calm_amd.pipeline import layer_split, stage_model, stage_tensors
-from conftest import GOLDEN, ROOT, load_golden
+from conftest import GOLDEN, ROOT, load_golden, run_torchrun
 
 WORKER = textwrap.dedent(
     """
@@ -59,16 +59,10 @@ def test_stage_tensors_renumber_and_boundaries():
 def test_pipeline_matches_unsharded_greedy_stream(tmp_path, case, world):
     model, z = load_golden(case)
     want = [int(t) for t in z["tokens"][1:13]]
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, CALM_ROOT=ROOT, CALM_MODEL=os.path.join(GOLDEN, case + ".calm"), CALM_FIRST=str(int(z["tokens"][0])), CALM_STEPS="12", OMP_NUM_THREADS="1")
-    r = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-        env=env, capture_output=True, text=True, timeout=300)
+    r = run_torchrun(script, world, env)
     assert r.returncode == 0, r.stderr[-3000:]
     outs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(outs) == world and sum(o["layers"] for o in outs) == model.config.n_layers

@@ -7,7 +7,7 @@ import subprocess
 import sys
 import textwrap
 
-from conftest import ROOT
+from conftest import ROOT, run_torchrun
 
 WORKER = textwrap.dedent(
     """
@@ -28,16 +28,10 @@ WORKER = textwrap.dedent(
 
 
 def test_two_rank_replica_aggregation(tmp_path):
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, CALM_ROOT=ROOT)
-    r = subprocess.run(
-        [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
-        env=env, capture_output=True, text=True, timeout=300)
+    r = run_torchrun(script, 2, env)
     assert r.returncode == 0, r.stderr[-3000:]
     import json
 
