@@ -621,15 +621,30 @@ void prefill_chunk(Ctx* c, int nb, int pos0) {
 	                   c->pf_rope, half_hd);
 	const dim3 block(256);
 	const int cols = (nb + 63) / 64;
-	// two unit strips per wave (operands reused twice) as long as that leaves a workgroup for every CU
+	// S unit strips per wave (operands reused S times): the S whose grid costs the fewest workgroup rounds
+	// (one workgroup per CU at a time, a round takes S units of time); ties go to the larger S
 	auto gemm = [&](const PfGemmArgs& a, auto EPI) {
 		constexpr int epi = decltype(EPI)::value;
 		if constexpr (epi == PF_EPI_FFN_UP) {
 			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
-		} else if ((a.M + 63) / 64 * cols >= g_ncu) {
-			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 2>), dim3((a.M + 63) / 64, cols), block, 0, g_stream, a);
 		} else {
-			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
+			int best = 1;
+			long best_cost = 0;
+			for (int S = 1; S <= 3; ++S) {
+				long wgs = (long)((a.M + 32 * S - 1) / (32 * S)) * cols;
+				long cost = (wgs + g_ncu - 1) / g_ncu * S;
+				if (S == 1 || cost <= best_cost) {
+					best = S, best_cost = cost;
+				}
+			}
+			const dim3 grid((a.M + 32 * best - 1) / (32 * best), cols);
+			if (best == 3) {
+				hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 3>), grid, block, 0, g_stream, a);
+			} else if (best == 2) {
+				hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 2>), grid, block, 0, g_stream, a);
+			} else {
+				hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), grid, block, 0, g_stream, a);
+			}
 		}
 	};
 	using EpiQkv = std::integral_constant<int, PF_EPI_QKV>;

@@ -199,7 +199,7 @@ __device__ __forceinline__ void pf_decode(u32x4 v, float (&wf)[Fmt<DB>::G]) {
 	}
 }
 
-// Weight streams per wave: S strips of 32 units (S = 2 when the grid still fills the chip, else 1), except
+// Weight streams per wave: S strips of 32 units (S = 1..3, whichever wastes the fewest workgroup rounds), except
 // FFN-up whose two streams are w1 and w3 of ONE strip.
 template <int EPI, int S>
 struct PfTile {
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	constexpr int G = Fmt<DB>::G;
 	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and step (32 weights per k-half)
 	constexpr int NA = PfTile<EPI, S>::NA, NC = 2;
-	__shared__ float part[3][NA * NC * 16][64]; // partial tiles of waves 1..3 (24 / 48 KiB)
+	__shared__ float part[2][NA * NC * 16][64]; // partial tiles in flight during the two-round reduction (16 KiB per stream)
 
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
@@ -326,36 +326,48 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 		}
 	}
 
-	// add the four waves' partial tiles in wave order (deterministic)
-	if (wave > 0) {
+	// add the four waves' partial tiles, (w0 + w2) + (w1 + w3): a fixed order, two rounds through LDS
+	auto put = [&](int slot) {
 #pragma unroll
 		for (int n = 0; n < NA; ++n) {
 #pragma unroll
 			for (int c = 0; c < NC; ++c) {
 #pragma unroll
 				for (int r = 0; r < 16; ++r) {
-					part[wave - 1][(n * NC + c) * 16 + r][lane] = acc[n][c][r];
+					part[slot][(n * NC + c) * 16 + r][lane] = acc[n][c][r];
 				}
 			}
 		}
+	};
+	auto add = [&](int slot) {
+#pragma unroll
+		for (int n = 0; n < NA; ++n) {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					acc[n][c][r] += part[slot][(n * NC + c) * 16 + r][lane];
+				}
+			}
+		}
+	};
+	if (wave >= 2) {
+		put(wave - 2);
 	}
 	__syncthreads();
-	if (wave > 0) {
+	if (wave >= 2) {
 		return;
 	}
-#pragma unroll
-	for (int w = 0; w < 3; ++w) {
-#pragma unroll
-		for (int n = 0; n < NA; ++n) {
-#pragma unroll
-			for (int c = 0; c < NC; ++c) {
-#pragma unroll
-				for (int r = 0; r < 16; ++r) {
-					acc[n][c][r] += part[w][(n * NC + c) * 16 + r][lane];
-				}
-			}
-		}
+	add(wave);
+	__syncthreads(); // uniform for the two remaining waves: both slots have been read
+	if (wave == 1) {
+		put(0);
 	}
+	__syncthreads();
+	if (wave == 1) {
+		return;
+	}
+	add(0);
 
 	// C layout: column (token) = lane & 31, row (unit) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 #pragma unroll
