@@ -248,7 +248,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.partial = c->partial;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
-	a.pf_kv0 = 0, a.pf_stride = 0;
+	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
 		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a);
@@ -589,8 +589,9 @@ void launch_pf_attn_lpr(Ctx* c, int l, int nb, int pos0) {
 	a.partial = nullptr;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
-	a.pf_kv0 = pos0, a.pf_stride = c->q_dim;
-	hipLaunchKernelGGL((k_attn<KVB, LPR, true>), dim3(c->n_heads, nb), dim3(ATTN_BLOCK), 0, g_stream, a);
+	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
+	constexpr int TQ = PfAttn<LPR>::TQ;
+	hipLaunchKernelGGL((k_pf_attn<KVB, LPR>), dim3(c->n_heads, (nb + TQ - 1) / TQ), dim3(PF_ATTN_BLOCK), 0, g_stream, a);
 }
 
 template <int KVB>

@@ -688,9 +688,9 @@ struct AttnArgs {
 	float* partial;      // (n_heads, n_split, head_dim + 2) when n_split > 1: o[head_dim], m, l
 	const TokState* ts;
 	int head_dim, kv_mul, seq_len, n_split;
-	// batched prompt ingestion (k_attn<.., PF = true>, grid.y = token of the chunk): token b reads q + b * pf_stride,
-	// attends to cache rows [0, pf_kv0 + b] and writes row b of the fragment-major matrix `out`
-	int pf_kv0, pf_stride;
+	// batched prompt ingestion (prefill.hip.h: k_pf_attn): token b of the chunk reads q + b * pf_stride, attends to
+	// cache rows [0, pf_kv0 + b] and writes row b of the fragment-major matrix `out`; pf_nb tokens in the chunk
+	int pf_kv0, pf_stride, pf_nb;
 };
 
 // merge two online-softmax states (m, l, o[8])
@@ -713,7 +713,7 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // tiles of positions.  Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are
 // computed in one pass with running (max, sum, out) per lane group -- algebraically the same
 // result as the reference's three loops.
-template <int KVB, int LPR, bool PF = false>
+template <int KVB, int LPR>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
 	constexpr int NW = ATTN_BLOCK / 64;
@@ -727,16 +727,15 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	const int r = lane % LPR, g = lane / LPR;
 	const bool dvalid = r * 8 < a.head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
-	const int kv_len = PF ? a.pf_kv0 + (int)blockIdx.y + 1 : a.ts->kv_len;
+	const int kv_len = a.ts->kv_len;
 	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
-	const float* qsrc = PF ? a.q + (size_t)blockIdx.y * a.pf_stride : a.q;
 
 	float qv[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		float qi = qsrc[h * a.head_dim + d0 + i];
+		float qi = a.q[h * a.head_dim + d0 + i];
 		qv[i] = dvalid ? qi : 0.f;
 	}
 	const float sqrt_hd = sqrtf((float)a.head_dim);
@@ -863,16 +862,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			sm_merge(m, l, o, sm_m[w], sm_l[w], o2);
 		}
 		if (dvalid) {
-			if constexpr (PF) {
-				// fragment-major rows of pf_stride floats (prefill.hip.h: pf_idx), the next GEMM's B operand
-				const int k = h * a.head_dim + d0, ns = (a.pf_stride + 63) >> 6, t = (int)blockIdx.y;
-#pragma unroll
-				for (int half = 0; half < 2; ++half) {
-					const int kh = k + 4 * half;
-					const size_t idx = ((((size_t)(t >> 5) * ns + (kh >> 6)) * 8 + ((kh & 31) >> 2)) << 6) + (((kh >> 5) & 1) << 5) + (t & 31);
-					((float4*)a.out)[idx] = make_float4(o[4 * half] / l, o[4 * half + 1] / l, o[4 * half + 2] / l, o[4 * half + 3] / l);
-				}
-			} else if (a.n_split == 1) {
+			if (a.n_split == 1) {
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
 					a.out[h * a.head_dim + d0 + i] = o[i] / l;

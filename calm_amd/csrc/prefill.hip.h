@@ -154,6 +154,185 @@ __global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* sr
 	}
 }
 
+// ---- causal attention of a chunk of tokens over the cache   (src/infer.c:238-267,397-406 per token) ----------
+// The decode kernel k_attn with a query dimension: one workgroup per (head, group of TQ consecutive tokens).
+// Every cached K / V row is loaded once and used for all TQ queries (per-token launches of k_attn were bound
+// by L2 bandwidth: 256 tokens x 32 heads each streaming the whole context).  Query b attends to rows
+// [0, pf_kv0 + b]; rows past a query's own position are masked.  Output: fragment-major rows (pf_idx).
+constexpr int PF_ATTN_BLOCK = 512; // 8 waves: 256 VGPRs per lane for the TQ query states (16 waves spill)
+template <int LPR>
+struct PfAttn {
+	static constexpr int TQ = LPR <= 16 ? 4 : (LPR == 32 ? 2 : 1); // bounded by the LDS merge buffer (TQ x 8 waves x head_dim floats)
+};
+
+template <int KVB, int LPR>
+__global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
+	constexpr int RPW = 64 / LPR; // positions per wave-load
+	constexpr int NW = PF_ATTN_BLOCK / 64;
+	constexpr int UA = 4; // tiles in flight per wave
+	constexpr int TQ = PfAttn<LPR>::TQ;
+	__shared__ float sm_m[TQ][NW], sm_l[TQ][NW];
+	__shared__ float sm_o[TQ][NW][LPR * 8];
+
+	const int lane = lane_id(), wave = wave_id();
+	const int h = blockIdx.x, b0 = blockIdx.y * TQ;
+	const int kvh = h / a.kv_mul;
+	const int r = lane % LPR, g = lane / LPR;
+	const bool dvalid = r * 8 < a.head_dim;
+	const int d0 = dvalid ? r * 8 : 0;
+	const int nq = min(TQ, a.pf_nb - b0);      // queries of this group that exist
+	const int kv_max = a.pf_kv0 + b0 + nq;     // rows the last of them attends to
+
+	float qv[TQ][8];
+#pragma unroll
+	for (int q = 0; q < TQ; ++q) {
+		const float* qsrc = a.q + (size_t)min(b0 + q, a.pf_nb - 1) * a.pf_stride + h * a.head_dim + d0;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			float qi = qsrc[i];
+			qv[q][i] = dvalid ? qi : 0.f;
+		}
+	}
+	const float sqrt_hd = sqrtf((float)a.head_dim);
+
+	float m[TQ], l[TQ], o[TQ][8];
+#pragma unroll
+	for (int q = 0; q < TQ; ++q) {
+		m[q] = -INFINITY, l[q] = 0.f;
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			o[q][i] = 0.f;
+		}
+	}
+
+	constexpr int EB = KVB / 8;
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const size_t rstride = (size_t)a.head_dim * EB;
+
+	for (int tb = wave * RPW; tb < kv_max; tb += NW * RPW * UA) {
+		float kf[UA][8], vf[UA][8];
+		int trow[UA];
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			trow[u] = tb + u * NW * RPW + g;
+			const int t = min(trow[u], kv_max - 1); // always load (clamped); masked below
+			if constexpr (KVB == 16) {
+				u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
+				u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
+#pragma unroll
+				for (int i = 0; i < 4; ++i) {
+					kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[i] & 0xffff));
+					kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[i] >> 16));
+					vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[i] & 0xffff));
+					vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[i] >> 16));
+				}
+			} else {
+				u32x2 kw = *(const u32x2*)(kbase + (size_t)t * rstride);
+				u32x2 vw = *(const u32x2*)(vbase + (size_t)t * rstride);
+#pragma unroll
+				for (int i = 0; i < 2; ++i) {
+					f32x2 k0 = bf8x2_lo(kw[i]), k1 = bf8x2_hi(kw[i]);
+					f32x2 v0 = bf8x2_lo(vw[i]), v1 = bf8x2_hi(vw[i]);
+					kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
+					vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+				}
+			}
+		}
+#pragma unroll
+		for (int q = 0; q < TQ; ++q) {
+			const int kv_len_q = a.pf_kv0 + b0 + q + 1; // src/infer.c:332 for this token
+			float s[UA];
+#pragma unroll
+			for (int u = 0; u < UA; ++u) {
+				float d = 0.f;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					d = fmaf(qv[q][i], kf[u][i], d);
+				}
+#pragma unroll
+				for (int ofs = LPR / 2; ofs > 0; ofs >>= 1) {
+					d += __shfl_xor(d, ofs);
+				}
+				s[u] = trow[u] < kv_len_q ? d / sqrt_hd : -INFINITY; // src/infer.c:247
+			}
+			float mn = m[q];
+#pragma unroll
+			for (int u = 0; u < UA; ++u) {
+				mn = fmaxf(mn, s[u]);
+			}
+			if (mn != -INFINITY) {
+				float c = (m[q] == -INFINITY) ? 0.f : __expf(m[q] - mn);
+				l[q] *= c;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					o[q][i] *= c;
+				}
+#pragma unroll
+				for (int u = 0; u < UA; ++u) {
+					float p = s[u] == -INFINITY ? 0.f : __expf(s[u] - mn);
+					l[q] += p;
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						o[q][i] = fmaf(p, vf[u][i], o[q][i]);
+					}
+				}
+				m[q] = mn;
+			}
+		}
+	}
+
+	// merge the lane groups of the wave, then the waves through LDS; wave q finishes query q
+#pragma unroll
+	for (int q = 0; q < TQ; ++q) {
+#pragma unroll
+		for (int ofs = LPR; ofs < 64; ofs <<= 1) {
+			float m2 = __shfl_xor(m[q], ofs), l2 = __shfl_xor(l[q], ofs), o2[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				o2[i] = __shfl_xor(o[q][i], ofs);
+			}
+			sm_merge(m[q], l[q], o[q], m2, l2, o2);
+		}
+		if (g == 0) {
+			if (r == 0) {
+				sm_m[q][wave] = m[q];
+				sm_l[q][wave] = l[q];
+			}
+			if (dvalid) {
+#pragma unroll
+				for (int i = 0; i < 8; ++i) {
+					sm_o[q][wave][d0 + i] = o[q][i];
+				}
+			}
+		}
+	}
+	__syncthreads();
+	if (wave < nq && g == 0) {
+		const int q = wave;
+		float mm = sm_m[q][0], ll = sm_l[q][0], oo[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			oo[i] = sm_o[q][0][d0 + i];
+		}
+#pragma unroll
+		for (int w = 1; w < NW; ++w) {
+			float o2[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				o2[i] = sm_o[q][w][d0 + i];
+			}
+			sm_merge(mm, ll, oo, sm_m[q][w], sm_l[q][w], o2);
+		}
+		if (dvalid) {
+			const int k = h * a.head_dim + d0, ns = pf_steps(a.pf_stride);
+			float4* out4 = (float4*)a.out;
+			out4[pf_idx(b0 + q, k, ns)] = make_float4(oo[0] / ll, oo[1] / ll, oo[2] / ll, oo[3] / ll);
+			out4[pf_idx(b0 + q, k + 4, ns)] = make_float4(oo[4] / ll, oo[5] / ll, oo[6] / ll, oo[7] / ll);
+		}
+	}
+}
+
 struct PfGemmArgs {
 	const float4* xin;   // fragment-major activations (pf_idx), rows of K floats
 	const void *w0, *w1, *w2; // QKV: wq, wk, wv;  FFN_UP: w1, w3;  RESID: the matrix
