@@ -48,6 +48,9 @@ template <int DB>
 struct Fmt {
 	static constexpr int G = 128 / DB; // fp16: 8, fp8: 16, gf4: 32
 	static constexpr int F4 = G / 4;
+	// float4 slots of the LDS activation image per 1-KiB chunk of a row: 64 lanes x F4, and for gf4 one more
+	// float4 per lane holding the activation sum of each of its four 8-weight words (see dot16<4>)
+	static constexpr int CS = 64 * F4 + (DB == 4 ? 64 : 0);
 };
 
 __device__ __forceinline__ int lane_id() {
@@ -131,6 +134,11 @@ __device__ __forceinline__ float mul_mix_lo(unsigned h2, float x) {
 	asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(x));
 	return r;
 }
+__device__ __forceinline__ float mul_mix_hi(unsigned h2, float x) {
+	float r;
+	asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(x));
+	return r;
+}
 __device__ __forceinline__ float fma_mix_hi(unsigned h2, float x, float acc) {
 	asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(x));
 	return acc;
@@ -169,29 +177,43 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 	} else {
 		// gf4: word = 8-bit e5m2 scale S + 8 x 3-bit codes, w_k = (q_k - 4) * S / -4   (src/infer.c:37-40)
 		//   sum_k w_k x_k = (-S/4) * sum_k q_k x_k + S * sum_k x_k
-		// The codes are never converted: each is extracted (one v_bfe_u32) into the low bits of a dword
-		// where, read as binary16, q is the SUBNORMAL q * 2^-24 -- exact -- and v_fma_mix_f32 multiplies
-		// that half by an fp32 activation into an fp32 accumulator in one instruction.  2 VALU ops per
-		// weight (+ scale and activation sum per word); the 2^24 folds into the scale.
+		// The codes are never converted.  A 3-bit field anywhere in the mantissa of a binary16 half, everything
+		// else masked off, IS the subnormal q * 2^(a-24), and v_fma_mix_f32 multiplies a half by an fp32
+		// activation into an fp32 accumulator in one instruction; the LDS image carries x_k * 2^-a per column
+		// (exact), so the product is q x 2^-24 whatever a is.  One rotation of the word puts c5 c6 c7 into the
+		// mantissa of the low half and c0 c1 c2 into that of the high half, so three ANDs isolate six codes;
+		// c3 and c4 already sit in the high half's mantissa of the word itself: 6 integer ops + 8 fma_mix per
+		// 8 weights, and the activation sum of the word comes precomputed from the image (float4 #8).
 		f32x4 xv[4][2];
-		float t[4], S[4], xsum[4];
+		unsigned m[4][5];
+		float t[4], S[4];
+		const f32x4 xsum = xp[8 * 64];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
+			const unsigned w = v[j];
 			xv[j][0] = xp[(2 * j) * 64];
 			xv[j][1] = xp[(2 * j + 1) * 64];
-			S[j] = bf8_byte0(v[j]);
-			f32x2 s2 = (xv[j][0].lo + xv[j][0].hi) + (xv[j][1].lo + xv[j][1].hi); // v_pk_add_f32 on the pairs as loaded
-			xsum[j] = s2[0] + s2[1];
+			S[j] = bf8_byte0(w);
+			const unsigned r = __builtin_amdgcn_alignbit(w, w, 23); // rotate right by 23
+			m[j][0] = r & 0x000E0007u; // lo: c5 (a = 0)   hi: c0 (a = 1)
+			m[j][1] = r & 0x00700038u; // lo: c6 (a = 3)   hi: c1 (a = 4)
+			m[j][2] = r & 0x038001C0u; // lo: c7 (a = 6)   hi: c2 (a = 7)
+			m[j][3] = w & 0x000E0000u; //                  hi: c3 (a = 1)
+			m[j][4] = w & 0x00700000u; //                  hi: c4 (a = 4)
 		}
 		// v_fma_mix_f32 is written as (pure, non-volatile) inline asm: left to itself the SLP vectoriser
 		// keeps re-pairing these chains into v_pk_fma_f32 and converts every code with v_cvt_f32_f16 again.
 		// One chain per word; the four words' chains are interleaved code-major for ILP.
 #pragma unroll
-		for (int k = 0; k < 8; ++k) {
+		for (int j = 0; j < 4; ++j) {
+			t[j] = mul_mix_hi(m[j][0], xv[j][0][0]);
+		}
+#pragma unroll
+		for (int k = 1; k < 8; ++k) {
 #pragma unroll
 			for (int j = 0; j < 4; ++j) {
-				unsigned q = k == 7 ? v[j] >> 29 : __builtin_amdgcn_ubfe(v[j], 8 + 3 * k, 3);
-				t[j] = k == 0 ? mul_mix_lo(q, xv[j][0][0]) : fma_mix_lo(q, xv[j][k >> 2][k & 3], t[j]);
+				const float x = xv[j][k >> 2][k & 3];
+				t[j] = k < 5 ? fma_mix_hi(m[j][k], x, t[j]) : fma_mix_lo(m[j][k - 5], x, t[j]);
 			}
 		}
 #pragma unroll
@@ -207,18 +229,42 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 
 // Swizzled LDS image of an n-float vector for weight format DB.  Logical float4 p (columns
 // 4p..4p+3) belongs to chunk p / (16G), lane (p % 16G) / F4, sub-index i = p % F4 and is stored at
-// float4 slot chunk*16G + i*64 + lane: a wave reading "its float4 #i" hits 64 consecutive slots.
+// float4 slot chunk*CS + i*64 + lane: a wave reading "its float4 #i" hits 64 consecutive slots.
+// gf4 only: the image holds x_k * 2^-a(k % 8), a = {1,4,7,1,4,0,3,6} (dot16<4> multiplies by codes that
+// sit 2^a too high), and slot chunk*CS + 8*64 + lane holds the four UNSCALED 8-column sums of the lane.
 template <int DB>
 __device__ __forceinline__ int swz4(int p) {
 	constexpr int G = Fmt<DB>::G, F4 = Fmt<DB>::F4;
 	int chunk = p / (16 * G), r = p % (16 * G);
-	return chunk * 16 * G + (r % F4) * 64 + r / F4;
+	return chunk * Fmt<DB>::CS + (r % F4) * 64 + r / F4;
 }
 
-// number of float4 slots the image of n floats occupies (whole chunks; the tail is zero-filled)
+// logical float4 count of the image of n floats (whole chunks; the tail is zero-filled) ...
+template <int DB>
+__host__ __device__ constexpr int xs_logical(int n) {
+	return ((n + 64 * Fmt<DB>::G - 1) / (64 * Fmt<DB>::G)) * 16 * Fmt<DB>::G;
+}
+// ... and the float4 slots it occupies in LDS
 template <int DB>
 __host__ __device__ constexpr int xs_slots(int n) {
-	return ((n + 64 * Fmt<DB>::G - 1) / (64 * Fmt<DB>::G)) * 16 * Fmt<DB>::G;
+	return ((n + 64 * Fmt<DB>::G - 1) / (64 * Fmt<DB>::G)) * Fmt<DB>::CS;
+}
+
+// gf4: write float4 p of the image (scaled per column) and, from the even p of a pair, the pair's unscaled sum.
+// Lanes p and p^1 are adjacent threads (p = tid + i * BLOCK, BLOCK even) and are active together (n % 32 == 0).
+__device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
+	float s = (t.x + t.y) + (t.z + t.w);
+	s += __shfl_xor(s, 1);
+	const bool odd = p & 1;
+	t.x *= odd ? 0.0625f : 0.5f;       // 2^-a: columns 4..7 = {4,0,3,6}, columns 0..3 = {1,4,7,1}
+	t.y *= odd ? 1.0f : 0.0625f;
+	t.z *= odd ? 0.125f : 0.0078125f;
+	t.w *= odd ? 0.015625f : 0.5f;
+	xs4[swz4<4>(p)] = t;
+	if (!odd) {
+		const int chunk = p / 512, r = p % 512; // 512 logical float4 per gf4 chunk; lane r / 8, word (r % 8) / 2
+		((float*)&xs4[chunk * Fmt<4>::CS + 512 + r / 8])[(r % 8) >> 1] = s;
+	}
 }
 
 // block-wide sum; every thread gets the same value.  red: >= BLOCK/64 floats of LDS.
@@ -284,7 +330,7 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float
 	constexpr int MAXV = V;
 	const int tid = threadIdx.x;
 	const int n4 = n >> 2;
-	const int slots = xs_slots<DB>(n);
+	const int slots = xs_logical<DB>(n);
 	const float4* src4 = (const float4*)src;
 	const float4(&v)[MAXV] = sr.v;
 
@@ -329,9 +375,13 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float
 			t.z = (t.z - mean) * scale * gw.z;
 			t.w = (t.w - mean) * scale * gw.w;
 		}
-		xs4[swz4<DB>(p)] = t;
 		if (dump && blockIdx.x == 0) {
 			((float4*)dump)[p] = t;
+		}
+		if constexpr (DB == 4) {
+			stage_store_gf4(xs4, p, t);
+		} else {
+			xs4[swz4<DB>(p)] = t;
 		}
 	};
 #pragma unroll
@@ -346,7 +396,11 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float
 	}
 	// zero the tail of the last chunk so masked-off lanes multiply 0 * 0
 	for (int p = n4 + tid; p < slots; p += BLOCK) {
-		xs4[swz4<DB>(p)] = make_float4(0.f, 0.f, 0.f, 0.f);
+		if constexpr (DB == 4) {
+			stage_store_gf4(xs4, p, make_float4(0.f, 0.f, 0.f, 0.f));
+		} else {
+			xs4[swz4<DB>(p)] = make_float4(0.f, 0.f, 0.f, 0.f);
+		}
 	}
 	__syncthreads();
 }
@@ -379,11 +433,10 @@ __device__ __forceinline__ void tile_load(Tile<NR, U>& t, const unsigned char* c
 
 template <int DB, int NR, int U, bool FULL>
 __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR], const float4* xs4, int k0, int nl, int lane) {
-	constexpr int G = Fmt<DB>::G;
 #pragma unroll
 	for (int u = 0; u < U; ++u) {
 		if ((k0 + u) * 64 < nl) { // wave-uniform: skip chunks past the end of the row
-			const f32x4* xp = (const f32x4*)xs4 + (k0 + u) * 16 * G + lane;
+			const f32x4* xp = (const f32x4*)xs4 + (k0 + u) * Fmt<DB>::CS + lane;
 			const bool live = FULL || (k0 + u) * 64 + lane < nl;
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
@@ -1233,7 +1286,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 			for (int k = 0; k * 64 < nl; ++k) {
 				int li = k * 64 + lane;
 				u32x4 w = li < nl ? *((const u32x4*)row + li) : (u32x4){0u, 0u, 0u, 0u};
-				acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * 16 * Fmt<DB>::G + lane, acc2);
+				acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
 			}
 			float acc = wave_sum(acc2[0] + acc2[1]);
 			if (lane == 0) {
