@@ -480,3 +480,21 @@ def test_generate_with_a_batched_prompt_continues_the_reference_stream(hiplib, c
         assert out[:-1] == toks[1:]
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 33])
+def test_prefill_of_very_short_and_odd_prompts(hiplib, n):
+    """1, 2, 5 tokens (partial query groups of the attention kernel) and 33 (one token past an MFMA column tile),
+    each followed by one decode step checked against the reference's logits; the 33-token case wraps the
+    16-slot rolling buffer of sink_fp16 inside the call"""
+    case = "sink_fp16" if n == 33 else "ragged_fp8"
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    if n >= len(toks):
+        pytest.skip("golden stream too short")
+    b = HipBackend(model)
+    try:
+        b.prefill(toks[:n], 0)
+        assert rel_err(b.forward(toks[n], n, 0), z["logits"][n]) < LOGIT_TOL
+    finally:
+        b.close()
