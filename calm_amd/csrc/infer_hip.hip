@@ -128,6 +128,9 @@ struct Ctx {
 	// ... of a mixture-of-experts model: gate logits, per-expert row lists, one expert's gathered rows
 	float *pf_gate = nullptr, *pf_listw = nullptr, *pf_xe = nullptr;
 	int *pf_list = nullptr, *pf_count = nullptr;
+	// ... when the caller wants the log-probability of every next token: logits of the chunk, targets, results
+	float *pf_logits = nullptr, *pf_lp = nullptr;
+	int* pf_target = nullptr;
 	// graph cache: (n_split, kv_only, sink, chained, argmax)
 	std::map<std::tuple<int, int, int, int, int>, GraphEntry> graphs;
 	// argument block of the begin-token kernel (patched per replay)
@@ -613,7 +616,7 @@ void launch_pf_attn(Ctx* c, int l, int nb, int pos0) {
 // one chunk of nb <= PF_NT tokens at positions pos0 .. pos0 + nb - 1 (no wrap of the rolling buffer):
 // the layer loop of src/infer.c:349-458 with a token dimension
 template <int DB, int KVB>
-void prefill_chunk(Ctx* c, int nb, int pos0) {
+void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 	struct Config* p = &c->t->config;
 	struct Weights* w = &c->t->weights;
 	const int half_hd = c->head_dim / 2;
@@ -700,13 +703,21 @@ void prefill_chunk(Ctx* c, int nb, int pos0) {
 			gemm(m, std::integral_constant<int, PF_EPI_SCATTER>());
 		}
 	}
+	if (score) {
+		// final norm + classifier for every token of the chunk (src/infer.c:465-469), then log softmax of the target
+		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_final_weight, c->dim, p->norm_eps, (int)p->norm_ln);
+		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->vocab, a.w0 = w->wcls, a.out = c->pf_logits;
+		a.nb_dev = nullptr;
+		gemm(a, std::integral_constant<int, PF_EPI_STORE>());
+		hipLaunchKernelGGL(k_pf_logprob, dim3(nb), block, 0, g_stream, c->pf_logits, c->vocab, c->pf_target, c->pf_lp);
+	}
 	HIP_CHECK(hipGetLastError());
 }
 
-void dispatch_prefill_chunk(Ctx* c, int nb, int pos0) {
+void dispatch_prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 #define CASE(db, kvb)                       \
 	if (c->dbits == db && c->kvbits == kvb) \
-	return prefill_chunk<db, kvb>(c, nb, pos0)
+	return prefill_chunk<db, kvb>(c, nb, pos0, score)
 	CASE(16, 16);
 	CASE(8, 16);
 	CASE(4, 16);
@@ -966,7 +977,7 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}
-	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_listw, c->pf_xe, c->pf_list, c->pf_count};
+	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_listw, c->pf_xe, c->pf_list, c->pf_count, c->pf_logits, c->pf_lp, c->pf_target};
 	for (void* b : pf_bufs) {
 		if (b) {
 			HIP_CHECK(hipFree(b));
@@ -1015,33 +1026,82 @@ extern "C" void copy_hip(void* dst, const void* src, size_t size) {
 	HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyDefault));
 }
 
-extern "C" void prefill_hip(struct Transformer* t, const int* tokens, int n, int pos) {
+namespace {
+
+// prefill_hip / prefill_logprobs_hip: logprob == nullptr -> KV cache only
+void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, float* logprob) {
 	Ctx* c = ctx_of(t);
 	CALM_REQUIRE(n >= 0 && pos >= 0, "negative token count / position");
 	for (int i = 0; i < n; ++i) {
 		CALM_REQUIRE(tokens[i] >= 0 && tokens[i] < c->vocab, "token out of range");
 	}
+	CALM_REQUIRE(!logprob || (t->weights.wcls && t->weights.rms_final_weight), "scoring needs the final norm and the classifier");
 	// The batched path covers the positions before the rolling buffer wraps; positions at or past seq_len
 	// (sink rotation between tokens) go through the decode path one token at a time, still on the device.
 	int done = 0;
 	if ((c->n_experts == 0 || c->n_active <= PF_MAX_ACTIVE) && c->t->weights.token_embedding_table) {
 		pf_alloc(c);
+		if (logprob && !c->pf_logits) {
+			c->pf_logits = (float*)dev_alloc((size_t)PF_NT * c->vocab * sizeof(float));
+			c->pf_lp = (float*)dev_alloc(PF_NT * sizeof(float));
+			c->pf_target = (int*)dev_alloc(PF_NT * sizeof(int));
+		}
 		while (done < n && pos + done < c->seq_len) {
 			int nb = n - done < PF_NT ? n - done : PF_NT;
 			if (pos + done + nb > c->seq_len) {
 				nb = c->seq_len - (pos + done);
 			}
 			HIP_CHECK(hipMemcpyAsync(c->pf_tok, tokens + done, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
-			dispatch_prefill_chunk(c, nb, pos + done);
+			if (logprob) {
+				int target[PF_NT];
+				for (int b = 0; b < nb; ++b) {
+					target[b] = done + b + 1 < n ? tokens[done + b + 1] : -1;
+				}
+				HIP_CHECK(hipMemcpyAsync(c->pf_target, target, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
+			}
+			dispatch_prefill_chunk(c, nb, pos + done, logprob != nullptr);
+			if (logprob) {
+				HIP_CHECK(hipMemcpyAsync(logprob + done, c->pf_lp, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+				HIP_CHECK(hipStreamSynchronize(g_stream)); // `target` lives on this stack frame
+			}
 			done += nb;
 		}
 	}
 	for (; done < n; ++done) {
 		StepPlan sp = {};
-		sp.kv_only = true;
+		sp.kv_only = logprob == nullptr;
+		sp.copy_logits = !sp.kv_only;
 		run_step(c, tokens[done], nullptr, pos + done, sp);
+		if (logprob) {
+			HIP_CHECK(hipStreamSynchronize(g_stream));
+			float lp = 0.f;
+			if (done + 1 < n) { // src/sampler.c:19-32, then the log of src/run.c:298
+				const float* l = c->logits_h;
+				float mx = l[0];
+				for (int i = 1; i < c->vocab; ++i) {
+					mx = l[i] > mx ? l[i] : mx;
+				}
+				float sum = 0.f;
+				for (int i = 0; i < c->vocab; ++i) {
+					sum += expf(l[i] - mx);
+				}
+				lp = (l[tokens[done + 1]] - mx) - logf(sum);
+			}
+			logprob[done] = lp;
+		}
 	}
 	HIP_CHECK(hipStreamSynchronize(g_stream)); // `tokens` may be reused by the caller; KV rows are complete
+}
+
+} // namespace
+
+extern "C" void prefill_hip(struct Transformer* t, const int* tokens, int n, int pos) {
+	prefill_impl(t, tokens, n, pos, nullptr);
+}
+
+extern "C" void prefill_logprobs_hip(struct Transformer* t, const int* tokens, int n, int pos, float* logprob) {
+	CALM_REQUIRE(logprob != nullptr, "logprob buffer missing");
+	prefill_impl(t, tokens, n, pos, logprob);
 }
 
 extern "C" float* decode_greedy_hip(struct Transformer* t, int token, int pos, int n_steps, int* out_tokens) {

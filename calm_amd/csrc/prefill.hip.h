@@ -333,6 +333,34 @@ __global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
 	}
 }
 
+// log of the softmax probability of `target[b]` under row b of the logits (src/sampler.c:19-32 followed by the
+// log of src/run.c:298): one workgroup per token.  target < 0: nothing to score, the slot gets 0.
+__global__ __launch_bounds__(256) void k_pf_logprob(const float* logits, int vocab, const int* target, float* out) {
+	__shared__ float red[16];
+	const int b = blockIdx.x;
+	const float* l = logits + (size_t)b * vocab;
+	float mx = -3.402823466e+38f;
+	for (int i = threadIdx.x; i < vocab; i += 256) {
+		mx = fmaxf(mx, l[i]);
+	}
+	mx = wave_max(mx);
+	__syncthreads();
+	if (lane_id() == 0) {
+		red[threadIdx.x >> 6] = mx;
+	}
+	__syncthreads();
+	mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+	float s = 0.f;
+	for (int i = threadIdx.x; i < vocab; i += 256) {
+		s += expf(l[i] - mx);
+	}
+	s = block_sum<256>(s, red);
+	if (threadIdx.x == 0) {
+		const int t = target[b];
+		out[b] = t >= 0 ? (l[t] - mx) - logf(s) : 0.f;
+	}
+}
+
 struct PfGemmArgs {
 	const float4* xin;   // fragment-major activations (pf_idx), rows of K floats
 	const void *w0, *w1, *w2; // QKV: wq, wk, wv;  FFN_UP: w1, w3;  RESID: the matrix
@@ -568,8 +596,13 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 					float4 t = *p;
 					t.x += acc[n][c][4 * g], t.y += acc[n][c][4 * g + 1], t.z += acc[n][c][4 * g + 2], t.w += acc[n][c][4 * g + 3];
 					*p = t;
-				} else if constexpr (EPI == PF_EPI_STORE) {
-					*(float4*)(a.out + (size_t)token * a.M + ub) = make_float4(acc[n][c][4 * g], acc[n][c][4 * g + 1], acc[n][c][4 * g + 2], acc[n][c][4 * g + 3]);
+				} else if constexpr (EPI == PF_EPI_STORE) { // M is arbitrary here (a vocabulary): scalar, bounded stores
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						if (ub + e < a.M) {
+							a.out[(size_t)token * a.M + ub + e] = acc[n][c][4 * g + e];
+						}
+					}
 				} else if constexpr (EPI == PF_EPI_SCATTER) { // x[token of the row] += routing weight * (w2_e . h)   (src/infer.c:452-456)
 					const float wgt = a.roww[token];
 					float4* p = (float4*)(a.out + (size_t)a.rows[token] * a.M + ub);

@@ -49,6 +49,7 @@ def load_lib() -> C.CDLL:
         "free_hip": (None, [C.c_void_p]),
         "decode_greedy_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
         "prefill_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int]),
+        "prefill_logprobs_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int, fp]),
         "forward_stage_hip": (fp, [T, C.c_int, C.c_int, C.c_uint, C.c_uint]),
         "copy_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "perf_stage_hip": (C.c_double, [T, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
@@ -70,7 +71,7 @@ def load_lib() -> C.CDLL:
 
 EXPORTS = [
     "init_hip", "upload_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
-    "free_hip", "decode_greedy_hip", "prefill_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
+    "free_hip", "decode_greedy_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
     "calm_hip_test_argmax", "download_hip", "calm_hip_read_kv", "calm_hip_membench",
 ]
 
@@ -237,6 +238,13 @@ class HipBackend:
         arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
         self.lib.prefill_hip(C.byref(self.t), arr, len(tokens), pos)
 
+    def prefill_logprobs(self, tokens, pos: int) -> np.ndarray:
+        """prefill + log softmax probability of every next token (len(tokens) - 1 values): perplexity's raw material"""
+        arr = (C.c_int * len(tokens))(*[int(t) for t in tokens])
+        out = np.zeros(max(len(tokens), 1), dtype=np.float32)
+        self.lib.prefill_logprobs_hip(C.byref(self.t), arr, len(tokens), pos, fptr(out))
+        return out[: max(len(tokens) - 1, 0)]
+
     def stage_us(self, stage: int, iters: int = 4):
         b = C.c_uint64(0)
         us = self.lib.perf_stage_hip(C.byref(self.t), stage, iters, C.byref(b))
@@ -310,3 +318,26 @@ def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int
     dt = time.perf_counter() - t0
     stats = {"tokens": pos, "seconds": dt, "tok_s": pos / dt, "GBps": read_bytes / 1e9 / dt, "read_bytes": read_bytes}
     return out, stats
+
+
+def perplexity(backend, tokens: Sequence[int], steps: int = 0):
+    """the arithmetic of the reference's perplexity mode (study(), src/run.c:286-308) on top of
+    backend.prefill_logprobs: positions wrap every `steps` tokens (0 = never), every window is scored in one
+    batched call.  Returns (perplexity, standard error) exactly as the reference prints them."""
+    import math
+
+    n = len(tokens)
+    logprobs: List[float] = []
+    start = 0
+    while start + 1 < n:
+        end = n if steps <= 0 else min(n, start + steps)
+        # the window's last token is scored against the first token of the next window (pos restarts at 0 there)
+        window = list(tokens[start:end]) + ([tokens[end]] if end < n else [])
+        lp = backend.prefill_logprobs(window, 0)
+        logprobs.extend(float(v) for v in lp[: end - start if end < n else end - start - 1])
+        start = end
+    s = sum(logprobs)
+    ss = sum(v * v for v in logprobs)
+    den = float(len(logprobs))
+    ppl = math.exp(-s / den)
+    return ppl, ppl * math.sqrt(max(ss - s * s / den, 0.0) / den / den)

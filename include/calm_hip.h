@@ -84,6 +84,12 @@ float* decode_greedy_hip(struct Transformer* transformer, int token, int pos, in
  * through the decode path one token at a time inside the call -- same result, no speed-up. */
 void prefill_hip(struct Transformer* transformer, const int* tokens, int n, int pos);
 
+/* The same, plus the model's verdict on the text: logprob[i] = log softmax(logits after tokens[i])[tokens[i + 1]]
+ * for i < n - 1 (logprob[n - 1] = 0) -- the quantity the reference's perplexity mode accumulates one forward()
+ * at a time (src/run.c:294-298, sample_prob src/sampler.c:19-32); final norm + classifier run as one more GEMM
+ * per 256-token chunk.  `logprob` is host memory, n floats. */
+void prefill_logprobs_hip(struct Transformer* transformer, const int* tokens, int n, int pos, float* logprob);
+
 /* Layer-pipeline stage (for models beyond one GPU's 288 GB): `transformer` describes
  * only THIS stage's slice of the model -- config.n_layers = the stage's layer count, weights indexed from 0,
  * token_embedding_table set on the first stage only, rms_final_weight / wcls on the last stage only.

@@ -157,6 +157,16 @@ class _CpuBackend:
         for i, tok in enumerate(tokens):
             self._forward(C.byref(self.t), int(tok), pos + i, abi.FF_UPDATE_KV_ONLY)
 
+    def prefill_logprobs(self, tokens, pos: int) -> np.ndarray:
+        """the reference's perplexity inner loop (src/run.c:294-298; sample_prob, src/sampler.c:19-32), one forward per token"""
+        out = np.zeros(max(len(tokens) - 1, 0), dtype=np.float32)
+        for i, tok in enumerate(tokens):
+            lg = self.forward(int(tok), pos + i, 0)
+            if i + 1 < len(tokens):
+                e = np.exp(lg - lg.max(), dtype=np.float32)
+                out[i] = np.log(np.float64(e[int(tokens[i + 1])] / e.sum(dtype=np.float32)))
+        return out
+
     def kv(self, layer: int, which: int) -> np.ndarray:
         c = self.model.config
         kv_dim = c.head_dim * c.n_kv_heads

@@ -498,3 +498,46 @@ def test_prefill_of_very_short_and_odd_prompts(hiplib, n):
         assert rel_err(b.forward(toks[n], n, 0), z["logits"][n]) < LOGIT_TOL
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_prefill_logprobs_match_the_reference_logits(hiplib, case):
+    """prefill_logprobs_hip: log softmax(logits_i)[token_{i+1}] for the teacher-forced golden stream, against the same
+    quantity computed from the REFERENCE's logits (src/run.c:294-298 with sample_prob of src/sampler.c:19-32);
+    sink_fp16 scores its last 24 positions through the serial path inside the call (rolling buffer wrapped)"""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    ref = z["logits"].astype(np.float64)
+    want = np.array([(ref[i] - ref[i].max())[toks[i + 1]] - np.log(np.exp(ref[i] - ref[i].max()).sum()) for i in range(len(toks) - 1)])
+    b = HipBackend(model)
+    try:
+        got = b.prefill_logprobs(toks, 0)
+        assert got.shape == want.shape
+        tol = 2 * LOGIT_TOL * np.abs(ref).max()
+        assert np.abs(got - want).max() < tol, (np.abs(got - want).max(), tol)
+        if case != "sink_fp16":  # (past seq_len a repeated position would rotate the sink keys a second time)
+            lg = b.forward(toks[-1], len(toks) - 1, 0)  # the cache it leaves behind is the serial loop's
+            assert rel_err(lg, z["logits"][-1]) < LOGIT_TOL
+        ppl = float(np.exp(-got.astype(np.float64).mean()))
+        assert abs(ppl - float(np.exp(-want.mean()))) < 1e-2 * float(np.exp(-want.mean()))
+    finally:
+        b.close()
+
+
+def test_perplexity_windows_on_the_gpu_equal_the_cpu_loop(hiplib):
+    """host.perplexity (the reference's study() arithmetic, src/run.c:286-308) with every window scored by one
+    prefill_logprobs_hip call, against the same windows walked one forward() at a time by the CPU oracle"""
+    from calm_amd.host import perplexity
+
+    model, z = load_golden("tiny_fp8")
+    rng = np.random.default_rng(11)
+    toks = [int(t) for t in rng.integers(0, model.config.vocab_size, size=61)]
+    o = oracle.OracleBackend(model)
+    b = HipBackend(model)
+    try:
+        want, want_err = perplexity(o, toks, 16)
+        got, got_err = perplexity(b, toks, 16)
+        assert abs(got - want) < 2e-3 * want and abs(got_err - want_err) < 2e-2 * max(want_err, 1e-6)
+    finally:
+        b.close()
+        o.close()

@@ -3,7 +3,7 @@ import numpy as np
 
 from calm_amd import abi
 from calm_amd import calmfile as cf
-from calm_amd.host import HostModel, argmax_first, generate
+from calm_amd.host import HostModel, argmax_first, generate, perplexity
 from conftest import load_golden
 from oracle import oracle
 
@@ -72,3 +72,26 @@ def test_generate_with_batched_prompt_is_the_same_loop():
     assert calls == [(toks[:6], 0)]
     assert st_a["read_bytes"] == st_b["read_bytes"] and st_a["tokens"] == st_b["tokens"]
     a.close(), b.close()
+
+
+def test_perplexity_matches_the_reference_cli_arithmetic():
+    """perplexity() over windows of `steps` tokens == the reference's study() loop: one forward per token with
+    pos = i % steps (src/run.c:294-308), here both over the oracle backend"""
+    import math
+
+    model, z = load_golden("tiny_fp16")
+    rng = np.random.default_rng(3)
+    toks = [int(t) for t in rng.integers(0, model.config.vocab_size, size=37)]
+    steps = 10
+    o = oracle.OracleBackend(model)
+    s = ss = den = 0.0
+    for i in range(len(toks) - 1):
+        lg = o.forward(toks[i], i % steps, 0)
+        e = np.exp(lg - lg.max(), dtype=np.float32)
+        lp = math.log(float(e[toks[i + 1]] / e.sum(dtype=np.float32)))
+        s, ss, den = s + lp, ss + lp * lp, den + 1
+    want = math.exp(-s / den)
+    want_err = want * math.sqrt((ss - s * s / den) / den / den)
+    got, got_err = perplexity(oracle.OracleBackend(model), toks, steps)
+    assert abs(got - want) < 1e-4 * want and abs(got_err - want_err) < 1e-3 * max(want_err, 1e-6)
+    o.close()
