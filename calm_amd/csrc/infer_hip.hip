@@ -126,8 +126,9 @@ struct Ctx {
 	float2* pf_rope = nullptr;
 	int* pf_tok = nullptr;
 	// ... of a mixture-of-experts model: gate logits, per-expert row lists, one expert's gathered rows
-	float *pf_gate = nullptr, *pf_listw = nullptr, *pf_xe = nullptr;
-	int *pf_list = nullptr, *pf_count = nullptr;
+	float *pf_gate = nullptr, *pf_wsel = nullptr, *pf_xe = nullptr, *pf_y = nullptr;
+	int *pf_rows = nullptr, *pf_colexp = nullptr, *pf_slot = nullptr;
+	int pf_max_cols = 0;
 	// ... when the caller wants the log-probability of every next token: logits of the chunk, targets, results
 	float *pf_logits = nullptr, *pf_lp = nullptr;
 	int* pf_target = nullptr;
@@ -560,25 +561,30 @@ void pf_alloc(Ctx* c) {
 	}
 	// fragment-major matrices (prefill.hip.h: pf_idx) are sized in whole 64-column steps and zeroed once:
 	// their padding is read as a multiplicand of zero weights and must stay finite
-	auto frag = [&](int n) {
-		size_t bytes = (size_t)PF_NT * pf_steps(n) * 64 * sizeof(float);
+	auto frag = [&](int n, int rows) {
+		size_t bytes = (size_t)rows * pf_steps(n) * 64 * sizeof(float);
 		float* p = (float*)dev_alloc(bytes);
 		HIP_CHECK(hipMemset(p, 0, bytes));
 		return p;
 	};
+	// a mixture-of-experts chunk packs (token, expert) pairs into 64-row columns, one group per expert
+	c->pf_max_cols = c->n_experts > 0 ? (PF_NT * c->n_active + 63) / 64 + c->n_experts : 0;
+	const int erows = c->n_experts > 0 ? c->pf_max_cols * 64 : PF_NT;
 	c->pf_x = (float*)dev_alloc((size_t)PF_NT * c->dim * sizeof(float));
-	c->pf_xn = frag(c->dim);
+	c->pf_xn = frag(c->dim, PF_NT);
 	c->pf_q = (float*)dev_alloc((size_t)PF_NT * c->q_dim * sizeof(float));
-	c->pf_att = frag(c->q_dim);
-	c->pf_h = frag(c->hidden);
+	c->pf_att = frag(c->q_dim, PF_NT);
+	c->pf_h = frag(c->hidden, erows);
 	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
 	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
 	if (c->n_experts > 0) {
 		c->pf_gate = (float*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(float));
-		c->pf_list = (int*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(int));
-		c->pf_listw = (float*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(float));
-		c->pf_count = (int*)dev_alloc(c->n_experts * sizeof(int));
-		c->pf_xe = frag(c->dim);
+		c->pf_rows = (int*)dev_alloc((size_t)erows * sizeof(int));
+		c->pf_colexp = (int*)dev_alloc((size_t)c->pf_max_cols * sizeof(int));
+		c->pf_slot = (int*)dev_alloc((size_t)PF_NT * c->n_active * sizeof(int));
+		c->pf_wsel = (float*)dev_alloc((size_t)PF_NT * c->n_active * sizeof(float));
+		c->pf_xe = frag(c->dim, erows);
+		c->pf_y = (float*)dev_alloc((size_t)erows * c->dim * sizeof(float));
 	}
 }
 
@@ -684,30 +690,28 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 			gemm(a, EpiResid());
 			continue;
 		}
-		// mixture of experts (src/infer.c:422-457): gate logits of every token, routing, then per expert its
-		// rows are gathered, pushed through w1/w3 and w2, and scattered back weighted.  Experts run one after
-		// the other on the stream, so a token's contributions are added in expert order -- deterministic.
+		// mixture of experts (src/infer.c:422-457): gate logits of every token, routing into packed per-expert row
+		// groups, ONE grouped GEMM per matrix over all experts' rows, then the experts' outputs are added to the
+		// residual in rank order
 		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->n_experts, a.w0 = w->moegate[l], a.out = c->pf_gate;
 		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_STORE, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
-		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, c->pf_list, c->pf_listw, c->pf_count);
-		const size_t up_bytes = (size_t)c->hidden * c->dim * DB / 8;
-		for (int e = 0; e < c->n_experts; ++e) {
-			hipLaunchKernelGGL(k_pf_gather, dim3(nb), block, 0, g_stream, (float4*)c->pf_xe, (const float4*)c->pf_xn, c->pf_list + (size_t)e * PF_NT, c->pf_count + e, c->dim);
-			PfGemmArgs m = a;
-			m.nb_dev = c->pf_count + e;
-			m.xin = (const float4*)c->pf_xe, m.K = c->dim, m.M = c->hidden;
-			m.w0 = (const char*)w->w1[l] + e * up_bytes, m.w1 = (const char*)w->w3[l] + e * up_bytes, m.out = c->pf_h;
-			gemm(m, EpiUp());
-			m.xin = (const float4*)c->pf_h, m.K = c->hidden, m.M = c->dim, m.w0 = (const char*)w->w2[l] + e * up_bytes, m.out = c->pf_x;
-			m.rows = c->pf_list + (size_t)e * PF_NT, m.roww = c->pf_listw + (size_t)e * PF_NT;
-			gemm(m, std::integral_constant<int, PF_EPI_SCATTER>());
-		}
+		const int ecols = (nb * c->n_active + 63) / 64 + c->n_experts; // worst case for this chunk
+		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, ecols, c->pf_rows, c->pf_colexp, c->pf_slot,
+		                   c->pf_wsel);
+		hipLaunchKernelGGL(k_pf_gather, dim3(ecols * 64), block, 0, g_stream, (float4*)c->pf_xe, (const float4*)c->pf_xn, c->pf_rows, c->pf_colexp, c->dim);
+		PfGemmArgs m = a;
+		m.nb = ecols * 64;
+		m.col_expert = c->pf_colexp, m.expert_stride = (size_t)c->hidden * c->dim * DB / 8;
+		m.xin = (const float4*)c->pf_xe, m.K = c->dim, m.M = c->hidden, m.w0 = w->w1[l], m.w1 = w->w3[l], m.out = c->pf_h;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_FFN_UP, 1>), dim3((m.M + 31) / 32, ecols), block, 0, g_stream, m);
+		m.xin = (const float4*)c->pf_h, m.K = c->hidden, m.M = c->dim, m.w0 = w->w2[l], m.out = c->pf_y;
+		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_STORE, 2>), dim3((m.M + 63) / 64, ecols), block, 0, g_stream, m);
+		hipLaunchKernelGGL(k_pf_combine, dim3(nb), block, 0, g_stream, c->pf_x, c->pf_y, c->pf_slot, c->pf_wsel, c->n_active, c->dim);
 	}
 	if (score) {
 		// final norm + classifier for every token of the chunk (src/infer.c:465-469), then log softmax of the target
 		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_final_weight, c->dim, p->norm_eps, (int)p->norm_ln);
 		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->vocab, a.w0 = w->wcls, a.out = c->pf_logits;
-		a.nb_dev = nullptr;
 		gemm(a, std::integral_constant<int, PF_EPI_STORE>());
 		hipLaunchKernelGGL(k_pf_logprob, dim3(nb), block, 0, g_stream, c->pf_logits, c->vocab, c->pf_target, c->pf_lp);
 	}
@@ -977,7 +981,7 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}
-	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_listw, c->pf_xe, c->pf_list, c->pf_count, c->pf_logits, c->pf_lp, c->pf_target};
+	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_wsel, c->pf_xe, c->pf_y, c->pf_rows, c->pf_colexp, c->pf_slot, c->pf_logits, c->pf_lp, c->pf_target};
 	for (void* b : pf_bufs) {
 		if (b) {
 			HIP_CHECK(hipFree(b));

@@ -30,7 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
 
-enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3, PF_EPI_SCATTER = 4 };
+enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3 };
 constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
 
 // Fragment-major activation matrix of n-float rows (GEMM B operand).  The float4 holding columns k..k+3
@@ -97,11 +97,17 @@ __global__ __launch_bounds__(256) void k_pf_norm(float4* out, const float* X, co
 }
 
 // Mixture-of-experts routing of a chunk (src/infer.c:277-305 per token): top-k by logit, first maximum wins
-// ties, weights = softmax over the selected logits; then one list of (token, weight) rows per expert, in
-// token order (deterministic).  One workgroup of PF_NT threads.
-__global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int* list, float* listw, int* count) {
+// ties, weights = softmax over the selected logits.  The (token, rank) pairs are then packed expert by expert
+// into rows of ONE matrix, every expert's group padded to whole 64-row workgroup columns, so that a single
+// grouped GEMM launch serves all experts:
+//   rows[r]      token of packed row r, or -1 for padding          col_expert[c]  expert of column c, -1 past the end
+//   slot[t*k+j]  packed row of token t's rank-j expert             wsel[t*k+j]    its routing weight
+// One workgroup of PF_NT threads; everything is in token order (deterministic).
+__global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int max_cols, int* rows, int* col_expert, int* slot,
+                                                    float* wsel) {
 	__shared__ int se[PF_NT * PF_MAX_ACTIVE];
-	__shared__ float sw[PF_NT * PF_MAX_ACTIVE];
+	__shared__ int first_col[CALM_MAX_EXPERTS + 1];
+	__shared__ int cnt[CALM_MAX_EXPERTS];
 	const int t = threadIdx.x;
 	if (t < nb) {
 		const float* g = gate + (size_t)t * n_experts;
@@ -123,34 +129,75 @@ __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, i
 			mask |= 1ull << best;
 		}
 		for (int k = 0; k < n_active; ++k) {
-			sw[t * n_active + k] = expf(g[se[t * n_active + k]] - max_val) / wsum;
+			wsel[t * n_active + k] = expf(g[se[t * n_active + k]] - max_val) / wsum;
 		}
 	}
 	__syncthreads();
 	if (t < n_experts) {
 		int c = 0;
+		for (int i = 0; i < nb * n_active; ++i) {
+			c += se[i] == t;
+		}
+		cnt[t] = c;
+	}
+	__syncthreads();
+	if (t == 0) {
+		int col = 0;
+		for (int e = 0; e < n_experts; ++e) {
+			first_col[e] = col;
+			for (int c = 0; c < (cnt[e] + 63) / 64; ++c) {
+				col_expert[col++] = e;
+			}
+		}
+		first_col[n_experts] = col;
+		for (; col < max_cols; ++col) {
+			col_expert[col] = -1;
+		}
+	}
+	__syncthreads();
+	if (t < n_experts) {
+		int r = first_col[t] * 64;
 		for (int tok = 0; tok < nb; ++tok) {
 			for (int k = 0; k < n_active; ++k) {
 				if (se[tok * n_active + k] == t) {
-					list[t * PF_NT + c] = tok;
-					listw[t * PF_NT + c] = sw[tok * n_active + k];
-					++c;
+					rows[r] = tok;
+					slot[tok * n_active + k] = r;
+					++r;
 				}
 			}
 		}
-		count[t] = c;
+		for (; r < first_col[t + 1] * 64; ++r) {
+			rows[r] = -1;
+		}
 	}
 }
 
-// rows of one expert: dst row i (fragment-major) = src row list[i]; grid = PF_NT workgroups
-__global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* src, const int* list, const int* count, int n) {
-	const int i = blockIdx.x;
-	if (i >= *count) {
+// packed row r (fragment-major) = row rows[r] of src; padding rows keep whatever they held (finite)
+__global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* src, const int* rows, const int* col_expert, int n) {
+	const int r = blockIdx.x;
+	if (col_expert[r >> 6] < 0) {
 		return;
 	}
-	const int t = list[i], nsteps = pf_steps(n);
+	const int t = rows[r], nsteps = pf_steps(n);
+	if (t < 0) {
+		return;
+	}
 	for (int k4 = threadIdx.x; k4 < (n >> 2); k4 += 256) {
-		dst[pf_idx(i, 4 * k4, nsteps)] = src[pf_idx(t, 4 * k4, nsteps)];
+		dst[pf_idx(r, 4 * k4, nsteps)] = src[pf_idx(t, 4 * k4, nsteps)];
+	}
+}
+
+// x[t] += sum_j wsel[t][j] * y[slot[t][j]]: the experts' outputs added in rank order (src/infer.c:452-456)
+__global__ __launch_bounds__(256) void k_pf_combine(float* X, const float* Y, const int* slot, const float* wsel, int n_active, int dim) {
+	const int t = blockIdx.x;
+	for (int i = threadIdx.x; i < (dim >> 2); i += 256) {
+		float4 x = ((float4*)(X + (size_t)t * dim))[i];
+		for (int j = 0; j < n_active; ++j) {
+			const float w = wsel[t * n_active + j];
+			const float4 y = ((const float4*)(Y + (size_t)slot[t * n_active + j] * dim))[i];
+			x.x += w * y.x, x.y += w * y.y, x.z += w * y.z, x.w += w * y.w;
+		}
+		((float4*)(X + (size_t)t * dim))[i] = x;
 	}
 }
 
@@ -372,10 +419,10 @@ struct PfGemmArgs {
 	int q_dim, kv_dim, head_dim, seq_len, kv_pos0;
 	float clip;
 	int gelu;
-	// mixture of experts: the GEMM runs over the rows gathered for ONE expert
-	const int* nb_dev;   // != nullptr: the number of valid rows is read from device memory (the routing decided it)
-	const int* rows;     // SCATTER: token of each gathered row
-	const float* roww;   // SCATTER: routing weight of each gathered row
+	// mixture of experts: a grouped GEMM over the packed rows of all experts (k_pf_route); workgroup column c
+	// multiplies by the matrices of expert col_expert[c] (w0 / w1 + expert * expert_stride bytes)
+	const int* col_expert;
+	size_t expert_stride;
 };
 
 // one 16-byte piece of a weight row -> its G weights as f32 (exact in all three formats)
@@ -425,9 +472,14 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
 	const int unit0 = blockIdx.x * PfTile<EPI, S>::UNITS, tok0 = blockIdx.y * 64;
-	const int nb = a.nb_dev ? *a.nb_dev : a.nb;
-	if (tok0 >= nb) {
-		return; // an expert that received fewer rows than the grid was sized for
+	const int nb = a.nb;
+	size_t expert_off = 0;
+	if (a.col_expert) {
+		const int e = a.col_expert[blockIdx.y];
+		if (e < 0) {
+			return; // the grid is sized for the worst-case number of columns
+		}
+		expert_off = (size_t)e * a.expert_stride;
 	}
 	const size_t row_bytes = (size_t)a.K * DB / 8;
 	const int npieces = a.K / G;      // 16-byte pieces per row
@@ -445,9 +497,9 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 			const int ul = u - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
 			rowp[s] = base + (size_t)ul * row_bytes;
 		} else if constexpr (EPI == PF_EPI_FFN_UP) {
-			rowp[s] = (const unsigned char*)(s ? a.w1 : a.w0) + (size_t)min(unit0 + j, a.M - 1) * row_bytes;
+			rowp[s] = (const unsigned char*)(s ? a.w1 : a.w0) + expert_off + (size_t)min(unit0 + j, a.M - 1) * row_bytes;
 		} else {
-			rowp[s] = (const unsigned char*)a.w0 + (size_t)min(unit0 + 32 * s + j, a.M - 1) * row_bytes;
+			rowp[s] = (const unsigned char*)a.w0 + expert_off + (size_t)min(unit0 + 32 * s + j, a.M - 1) * row_bytes;
 		}
 	}
 	// B: the two 32-token groups of this workgroup (the matrix is allocated for whole groups of 64 tokens)
@@ -603,12 +655,6 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 							a.out[(size_t)token * a.M + ub + e] = acc[n][c][4 * g + e];
 						}
 					}
-				} else if constexpr (EPI == PF_EPI_SCATTER) { // x[token of the row] += routing weight * (w2_e . h)   (src/infer.c:452-456)
-					const float wgt = a.roww[token];
-					float4* p = (float4*)(a.out + (size_t)a.rows[token] * a.M + ub);
-					float4 t = *p;
-					t.x += wgt * acc[n][c][4 * g], t.y += wgt * acc[n][c][4 * g + 1], t.z += wgt * acc[n][c][4 * g + 2], t.w += wgt * acc[n][c][4 * g + 3];
-					*p = t;
 				} else if constexpr (EPI == PF_EPI_FFN_UP) {
 					float h[4];
 #pragma unroll
