@@ -30,6 +30,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
 
+
 enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3 };
 constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
 
@@ -463,9 +464,12 @@ struct PfTile {
 
 // grid = (ceil(M / UNITS), ceil(nb / 64)), 256 threads
 template <int DB, int KVB, int EPI, int S>
-__global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
+__global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 	constexpr int G = Fmt<DB>::G;
-	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and step (32 weights per k-half)
+	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and 64-column step (32 weights per k-half)
+	// a wave's unit of work is a SUB-step: 1 / HS of a step (16 weights per k-half for fp16 / fp8), which halves
+	// the operand registers in flight so that two workgroups fit a CU (one wave per SIMD left every stall exposed)
+	constexpr int HS = (P >= 2 && S < 3) ? 2 : 1, PH = P / HS, QH = 8 / HS;
 	constexpr int NA = PfTile<EPI, S>::NA, NC = 2;
 	__shared__ float part[2][NA * NC * 16][64]; // partial tiles in flight during the two-round reduction (16 KiB per stream)
 
@@ -506,14 +510,16 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 	const float4* xg = a.xin + (size_t)(tok0 >> 5) * nsteps * 512 + lane;
 
 	struct Frag {
-		u32x4 w[NA][P];
-		f32x4 x[NC][8];
+		u32x4 w[NA][PH];
+		f32x4 x[NC][QH];
 	};
-	auto load = [&](Frag& f, int s) {
-		const int sc = min(s, nsteps - 1);
-		const int p0 = (2 * sc + kk) * P;
+	const int nsub = nsteps * HS;
+	auto load = [&](Frag& f, int u) {
+		const int uc = min(u, nsub - 1);
+		const int sc = uc / HS, h = uc % HS;
+		const int p0 = (2 * sc + kk) * P + h * PH;
 #pragma unroll
-		for (int i = 0; i < P; ++i) {
+		for (int i = 0; i < PH; ++i) {
 			const int piece = min(p0 + i, npieces - 1);
 #pragma unroll
 			for (int n = 0; n < NA; ++n) {
@@ -522,9 +528,9 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 		}
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
-			const f32x4* xp = (const f32x4*)(xg + ((size_t)c * nsteps + sc) * 512);
+			const f32x4* xp = (const f32x4*)(xg + ((size_t)c * nsteps + sc) * 512 + h * QH * 64);
 #pragma unroll
-			for (int q = 0; q < 8; ++q) {
+			for (int q = 0; q < QH; ++q) {
 				f.x[c][q] = xp[q * 64];
 			}
 		}
@@ -541,10 +547,10 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 			}
 		}
 	}
-	auto compute = [&](const Frag& f, int s) {
-		const int p0 = (2 * s + kk) * P;
+	auto compute = [&](const Frag& f, int u) {
+		const int p0 = (2 * (u / HS) + kk) * P + (u % HS) * PH;
 #pragma unroll
-		for (int i = 0; i < P; ++i) {
+		for (int i = 0; i < PH; ++i) {
 			const bool valid = p0 + i < npieces; // ragged rows: pieces past the row's end multiply as zeros
 			float wf[NA][G];
 #pragma unroll
@@ -568,20 +574,20 @@ __global__ __launch_bounds__(256) void k_pf_gemm(PfGemmArgs a) {
 		}
 	};
 
-	// wave w takes steps w, w+4, ...  The loop is unrolled by two so the two operand buffers alternate by name
+	// wave w takes sub-steps w, w+4, ...  The loop is unrolled by two so the two operand buffers alternate by name
 	// (no register copies, which would wait for the loads just issued), and a scheduling barrier after each
 	// load block keeps the compiler from sinking the loads down to their first use (it did: vmcnt(0) in front
 	// of every other MFMA).  Loads are clamped, never skipped, so s_waitcnt stays counted.
 	Frag f0, f1;
 	load(f0, wave);
-	for (int s = wave; s < nsteps; s += 8) {
-		load(f1, s + 4);
+	for (int u = wave; u < nsub; u += 8) {
+		load(f1, u + 4);
 		__builtin_amdgcn_sched_barrier(0);
-		compute(f0, s);
-		load(f0, s + 8);
+		compute(f0, u);
+		load(f0, u + 8);
 		__builtin_amdgcn_sched_barrier(0);
-		if (s + 4 < nsteps) {
-			compute(f1, s + 4);
+		if (u + 4 < nsub) {
+			compute(f1, u + 4);
 		}
 	}
 
