@@ -10,18 +10,20 @@
 // on this chip); the activations are NOT narrowed to fp16 / bf16 to reach the 16x faster MFMA forms --
 // that costs 3e-4..2e-3 per matvec and breaks the 1e-3 logits parity with the CPU path.
 //
-// GEMM structure (k_pf_gemm).  A wave owns NA x 2 accumulator tiles of 32 units x 32 tokens: NA = 2 unit
-// strips (QKV, residual GEMMs) or the w1 / w3 pair of one strip (FFN-up), times two token tiles -- so every
-// decoded weight feeds two MFMAs and every activation fragment feeds two, which halves the operand traffic
-// per MFMA (one strip x one token tile measured 40 % of the MFMA peak with the operand fetch in the way).
-// The four waves of a workgroup split the reduction dimension (wave w takes every 4th step of 64 weights
-// per row) and add their partial tiles through LDS in a fixed order.  Operands go global -> registers:
-//   A  32 consecutive weights of this lane's row per step (lane = unit i, k-half kk), decoded to f32;
-//   B  the matching 32 activations of token j (lane = token j, k-half kk) from a FRAGMENT-MAJOR activation
+// GEMM structure (k_pf_gemm).  A wave owns NA x 2 accumulator tiles of 32 units x 32 tokens: NA = 1..3 unit
+// strips (QKV, residual, classifier GEMMs; the count that wastes the fewest workgroup rounds) or the w1 / w3 pair
+// of one strip (FFN-up), times two token tiles -- so every decoded weight feeds two MFMAs and every activation
+// fragment feeds NA, which cuts the operand traffic per MFMA (one strip x one token tile measured 40 % of the
+// MFMA peak with the operand fetch in the way).  The four waves of a workgroup split the reduction dimension
+// (wave w takes every 4th sub-step of a row) and add their partial tiles through LDS in a fixed order.
+// Operands go global -> registers:
+//   A  consecutive weights of this lane's row (lane = unit i, k-half kk), decoded to f32;
+//   B  the matching activations of token j (lane = token j, k-half kk) from a FRAGMENT-MAJOR activation
 //      matrix (pf_idx below): a wave's 16-byte loads are 1 KiB contiguous, and the matrix is L2 resident.
 // The k order inside the dot product is permuted (both operands agree), which fp32 addition does not mind
-// beyond rounding.  Operands of the next step are loaded (double buffer, scheduling barrier) before the
-// current step's 128 MFMAs (8192 cycles) are issued.
+// beyond rounding.  Operands of the next sub-step are loaded (double buffer, scheduling barrier) before the
+// current one's 64..192 MFMAs are issued.  Mixture-of-experts layers run the same kernel as a grouped GEMM
+// (k_pf_route packs the rows, a workgroup column looks up its expert).
 #pragma once
 
 namespace calm {
@@ -29,7 +31,6 @@ namespace calm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
-
 
 enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3 };
 constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
