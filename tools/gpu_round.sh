@@ -41,18 +41,18 @@ python tools/prof_summary.py $OUT/prof $OUT/pmc --tag $TAG >> $OUT/summary.txt 2
 mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/ 2>/dev/null
 
 echo "== prompt ingestion: rates, kernel trace, MFMA counters" | tee -a $OUT/summary.txt
-for cfg in "mistral-7b fp8 4 1024" "mistral-7b fp8 4 64" "llama-3-8b gf4 4 512" "tinyllama-1.1b fp16 8 512"; do
+for cfg in "mistral-7b fp8 4 1024" "mistral-7b fp8 4 4000" "mistral-7b fp8 4 64" "llama-3-8b gf4 4 512" "tinyllama-1.1b fp16 8 512" "mixtral-8x7b fp8 2 512" "dbrx-132b fp8 1 512"; do
   timeout 300 python tools/prefill_bench.py $cfg >> $OUT/prefill.txt 2>&1
 done
 cat $OUT/prefill.txt >> $OUT/summary.txt
 R=$PWD
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/pfprof -o pf -- python $R/tools/prefill_bench.py mistral-7b fp8 2 512 > $R/$OUT/pfprof.log 2>&1)
+(cd /tmp && PF_PROFILE=1 timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/pfprof -o pf -- python $R/tools/prefill_bench.py mistral-7b fp8 2 256 > $R/$OUT/pfprof.log 2>&1)
 python tools/prof_summary.py $OUT/pfprof --tag ${TAG}_prefill > $OUT/prefill_kernel_stats.md 2>> $OUT/pfprof.log
 cp profiles/${TAG}_prefill_kernel_stats.md $OUT/profiles/ 2>/dev/null
 grep -E "kernel \||k_pf|true>" $OUT/prefill_kernel_stats.md >> $OUT/summary.txt
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" "GRBM_GUI_ACTIVE SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_BUSY_CYCLES" "FETCH_SIZE"; do
   n=$(echo $set | cut -d' ' -f1)
-  (cd /tmp && timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pfpmc/$n -o pmc -- python $R/tools/prefill_bench.py mistral-7b fp8 2 512 > $R/$OUT/pfpmc_$n.log 2>&1)
+  (cd /tmp && PF_PROFILE=1 timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $R/$OUT/pfpmc/$n -o pmc -- python $R/tools/prefill_bench.py mistral-7b fp8 2 256 > $R/$OUT/pfpmc_$n.log 2>&1)
 done
 python tools/pmc_table.py $OUT/pfpmc | grep -E "^kernel|k_pf|true>" > $OUT/profiles/${TAG}_prefill_pmc.txt 2>&1
 cat $OUT/profiles/${TAG}_prefill_pmc.txt >> $OUT/summary.txt

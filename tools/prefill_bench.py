@@ -25,8 +25,9 @@ be = HipBackend(model, stream=cf.synth_stream_big(spec, dtype, 1, L))
 rng = np.random.default_rng(0)
 toks = [int(t) for t in rng.integers(0, spec.vocab_size, size=N)]
 
-be.prefill(toks[:64], 0)  # warm-up (allocations, code load)
-for n in (64, N):
+PROFILE = bool(os.environ.get("PF_PROFILE"))  # under rocprofv3: launches of ONE chunk size only, no serial comparison
+be.prefill(toks[: N if PROFILE else 64], 0)  # warm-up (allocations, code load)
+for n in ((N,) if PROFILE else (64, N)):
     t0 = time.perf_counter()
     be.prefill(toks[:n], 0)
     dt = time.perf_counter() - t0
@@ -34,6 +35,9 @@ for n in (64, N):
     flop = 2.0 * n * L * (spec.dim * (spec.n_heads * spec.head_dim * 2 + 2 * spec.n_kv_heads * spec.head_dim) + 3 * act * spec.dim * spec.hidden_dim)
     print(f"prefill {n:5d} tokens, L={L}: {dt*1e3:8.2f} ms = {n/dt:9.0f} tok/s ({dt/n/L*1e6:7.2f} us/token/layer, {flop/dt/1e12:6.1f} TFLOP/s f32); "
           f"full depth ({spec.n_layers} layers): {n/dt*L/spec.n_layers:8.0f} tok/s")
+if PROFILE:
+    be.close()
+    sys.exit(0)
 lg_b = be.forward(toks[N - 1], N - 1, 0).copy()
 
 be.forward(toks[0], 0, abi.FF_UPDATE_KV_ONLY)
