@@ -93,6 +93,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("CALM_HIP_DEVICE", str(local_rank))
+    if world > 1:
+        # every rank synthesises its own copy of the weights with an OpenMP filler: share the host cores
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or world) // world)))
 
     dist = None
     if world > 1:
@@ -199,7 +202,7 @@ def main():
 
     cpu = None
     parity = None
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:  # the CPU baseline is an N = 1 measurement (rank 0 would otherwise hold the others up)
         cpu, (rt, rmd) = cpu_baseline(spec, args.dtype, args.seed, args.cpu_tokens, first_token)
         # parity spot check on the L=2 sample: HIP vs the CPU reference, teacher-forced
         from oracle import oracle
