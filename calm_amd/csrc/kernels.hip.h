@@ -83,6 +83,33 @@ __device__ __forceinline__ float wave_sum63(float v) {
 __device__ __forceinline__ float wave_sum(float v) {
 	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wave_sum63(v)), RED_LANE));
 }
+// Sum over each group of LPR consecutive lanes (LPR = 4 .. 64, a power of two), result in EVERY lane of the
+// group.  Up to 16 lanes (one DPP row) it is VALU only: quad swaps, then row_half_mirror and row_mirror add
+// the other 4 / 8 lanes' (already uniform) sums; wider groups finish with cross-row shuffles.  (__shfl_xor
+// compiles to ds_bpermute + s_waitcnt: the attention kernels spent more time there than in their loads.)
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+	auto dpp = [](float x, auto ctrl) {
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+	};
+	if constexpr (LPR >= 2) {
+		v += dpp(v, std::integral_constant<int, 0xb1>()); // quad_perm [1,0,3,2]
+	}
+	if constexpr (LPR >= 4) {
+		v += dpp(v, std::integral_constant<int, 0x4e>()); // quad_perm [2,3,0,1]
+	}
+	if constexpr (LPR >= 8) {
+		v += dpp(v, std::integral_constant<int, 0x141>()); // row_half_mirror
+	}
+	if constexpr (LPR >= 16) {
+		v += dpp(v, std::integral_constant<int, 0x140>()); // row_mirror
+	}
+#pragma unroll
+	for (int ofs = 16; ofs < LPR; ofs <<= 1) {
+		v += __shfl_xor(v, ofs);
+	}
+	return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) {
@@ -844,10 +871,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			for (int i = 0; i < 8; ++i) {
 				d = fmaf(qv[i], kf[u][i], d);
 			}
-#pragma unroll
-			for (int ofs = LPR / 2; ofs > 0; ofs >>= 1) {
-				d += __shfl_xor(d, ofs);
-			}
+			d = group_sum<LPR>(d);
 			s[u] = valid[u] ? d / sqrt_hd : -INFINITY; // src/infer.c:247
 		}
 		float mn = m;
@@ -974,7 +998,7 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(AttnArgs a) {
 			qv[q][i] = dvalid ? qi : 0.f;
 		}
 	}
-	const float sqrt_hd = sqrtf((float)a.head_dim);
+	const float inv_sqrt_hd = 1.0f / sqrtf((float)a.head_dim); // one rounding away from the reference's division (src/infer.c:247)
 	float m[QH], l[QH], o[QH][8];
 #pragma unroll
 	for (int q = 0; q < QH; ++q) {
@@ -1030,11 +1054,8 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(AttnArgs a) {
 				for (int i = 0; i < 8; ++i) {
 					d = fmaf(qv[q][i], kf[u][i], d);
 				}
-#pragma unroll
-				for (int ofs = LPR / 2; ofs > 0; ofs >>= 1) {
-					d += __shfl_xor(d, ofs);
-				}
-				sc[u] = valid[u] ? d / sqrt_hd : -INFINITY;
+				d = group_sum<LPR>(d);
+				sc[u] = valid[u] ? d * inv_sqrt_hd : -INFINITY;
 			}
 			float mn = m[q];
 #pragma unroll

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
 			qv[q][i] = dvalid ? qi : 0.f;
 		}
 	}
-	const float sqrt_hd = sqrtf((float)a.head_dim);
+	const float inv_sqrt_hd = 1.0f / sqrtf((float)a.head_dim); // one rounding away from the reference's division (src/infer.c:247)
 
 	float m[TQ], l[TQ], o[TQ][8];
 #pragma unroll
@@ -299,11 +299,8 @@ __global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
 				for (int i = 0; i < 8; ++i) {
 					d = fmaf(qv[q][i], kf[u][i], d);
 				}
-#pragma unroll
-				for (int ofs = LPR / 2; ofs > 0; ofs >>= 1) {
-					d += __shfl_xor(d, ofs);
-				}
-				s[u] = trow[u] < kv_len_q ? d / sqrt_hd : -INFINITY; // src/infer.c:247
+				d = group_sum<LPR>(d);
+				s[u] = trow[u] < kv_len_q ? d * inv_sqrt_hd : -INFINITY;
 			}
 			float mn = m[q];
 #pragma unroll

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Decode rate deep into a long context (the reference README's "last 32 tokens" columns): Mistral-7B fp8 shape cut
+to L layers, context 32768 with the fp8 KV cache the reference switches to beyond 4096 (src/run.c:536-540).
+The cache is not filled by a real prompt -- attention cost does not depend on the values -- only its length matters."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from calm_amd import calmfile as cf
+from calm_amd.host import STAGES, HipBackend, HostModel, generate, load_lib
+
+L = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+spec = cf.SPECS["mistral-7b"]
+lib = load_lib()
+for kvbits, ctx in ((16, 4096), (8, 32768)):
+    md = cf.dataclasses.replace(spec, n_layers=L, max_seq_len=ctx).metadata("fp8")
+    model = HostModel(cf.stub_tensors(spec, "fp8", L), md, context=ctx)
+    be = HipBackend(model, kvbits=kvbits, stream=cf.synth_stream_big(spec, "fp8", 1, L))
+    generate(be, model, [17], 16, kvbits=kvbits)
+    for pos in ([256, 4000] if ctx == 4096 else [256, 4000, 8000, 16000, 32000]):
+        generate(be, model, [17], 8, pos_offset=pos, kvbits=kvbits)
+        t0 = time.perf_counter()
+        _, st = generate(be, model, [17], 32, pos_offset=pos + 8, kvbits=kvbits)
+        dt = time.perf_counter() - t0
+        us, b = be.stage_us(1, 6)
+        kv_mb = 2 * (kvbits // 8) * 1024 * (pos + 40) / 1e6
+        print(f"kv{kvbits:2d} ctx {ctx:5d} pos ~{pos:5d}: {dt/32*1e6:8.1f} us/token (L={L}); attention stage {us:7.2f} us for {kv_mb:6.1f} MB/layer = {kv_mb/us*1e3:6.0f} GB/s; "
+              f"full depth ~{32/dt*L/32:7.1f} tok/s", flush=True)
+    be.close()
