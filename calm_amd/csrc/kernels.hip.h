@@ -281,7 +281,7 @@ __host__ __device__ constexpr int xs_slots(int n) {
 // Lanes p and p^1 are adjacent threads (p = tid + i * BLOCK, BLOCK even) and are active together (n % 32 == 0).
 __device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
 	float s = (t.x + t.y) + (t.z + t.w);
-	s += __shfl_xor(s, 1);
+	s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xb1, 0xf, 0xf, true)); // lane ^ 1 (quad_perm [1,0,3,2])
 	const bool odd = p & 1;
 	t.x *= odd ? 0.0625f : 0.5f;       // 2^-a: columns 4..7 = {4,0,3,6}, columns 0..3 = {1,4,7,1}
 	t.y *= odd ? 1.0f : 0.0625f;
