@@ -462,6 +462,12 @@ def test_prefill_full_width_matches_serial(hiplib, name, dtype, layers):
         batched.prefill(toks[:100], 0)
         lb = batched.forward(toks[100], 100, 0)
         assert rel_err(lb, ls) < 2e-4, rel_err(lb, ls)
+        # scoring at the full vocabulary (the classifier as a [vocab x dim] GEMM over the chunk): the log-probability
+        # of the token that follows position 100, from the batched call, against the serial path's logits
+        lp = batched.prefill_logprobs(toks[:101], 0)
+        serial99 = serial.forward(toks[99], 99, 0).astype(np.float64)  # position 99's logits score toks[100]
+        want = (serial99[toks[100]] - serial99.max()) - np.log(np.exp(serial99 - serial99.max()).sum())
+        assert abs(float(lp[99]) - want) < 2e-3 * max(1.0, abs(want)), (float(lp[99]), want)
     finally:
         serial.close()
         batched.close()
