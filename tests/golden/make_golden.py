@@ -13,7 +13,7 @@ where /root/reference exists (the build container); its outputs are committed:
     cli_tiny_fp16.txt -- text decoded by the reference CLI (run_cpu) on one case
     cli_tiny_fp16_perplexity.txt -- its perplexity line for sample.txt (-x mode)
 
-Usage:  python tests/golden/make_golden.py
+Usage:  python tests/golden/make_golden.py [case ...]
 """
 import os
 import subprocess
@@ -42,6 +42,18 @@ CASES = {
     "sink_fp16": (dict(max_seq_len=16), "fp16", 40),
     # ragged shapes: rows that are not a whole number of 1-KiB wave-loads, head_dim 32, kv_mul 1, odd vocab
     "ragged_fp8": (dict(dim=96, hidden_dim=176, head_dim=32, n_heads=3, n_kv_heads=3, vocab_size=301), "fp8", 16),
+    # partial rotary embedding (phi-style): pairs beyond rotary_dim are not rotated (src/infer.c:226-228)
+    "partial_rope_fp16": (dict(rotary_dim=8), "fp16", 24),
+    # the DBRX combination at toy size: 16 experts top-4, LayerNorm without bias, qkv clip, kv_mul 3
+    "dbrx_like_fp8": (dict(dim=96, hidden_dim=128, head_dim=16, n_heads=6, n_kv_heads=2, n_experts=16, n_experts_active=4, norm_type="layernorm", qkv_clip=1.5), "fp8", 24),
+    # multi-query attention (one kv head), head_dim 96 (not a power of two: phi-3).  q_dim must not exceed dim in
+    # a golden, nor dim hidden_dim: the reference's attention output lands in xb2 (dim floats) and wo's result in hb
+    # (hidden_dim floats), src/infer.c:152-153,404,410, and both overflow otherwise
+    "mqa_hd96_fp16": (dict(dim=192, hidden_dim=224, head_dim=96, n_heads=2, n_kv_heads=1, vocab_size=160), "fp16", 24),
+    # mixture of experts over 4-bit weights, tied classifier
+    "moe_gf4": (dict(n_experts=4, n_experts_active=2, tied=True), "gf4", 24),
+    # head_dim 256 (gemma-style), GELU, runs past a 12-row rolling buffer with fp8 weights
+    "hd256_sink_fp8": (dict(dim=512, hidden_dim=544, head_dim=256, n_heads=2, n_kv_heads=1, n_layers=1, vocab_size=160, act_type="gelu", max_seq_len=12), "fp8", 30),
 }
 FIRST_TOKEN = 5
 
@@ -49,7 +61,10 @@ FIRST_TOKEN = 5
 def main():
     if not oracle.have_ref():
         sys.exit("oracle/_ref/libcalm_ref.so missing: run `make -C oracle ref` where /root/reference exists")
+    only = set(sys.argv[1:])  # optional: regenerate just these cases (existing fixtures stay byte-identical)
     for name, (kw, dtype, steps) in CASES.items():
+        if only and name not in only:
+            continue
         spec = cf.tiny_spec(name, **kw)
         path = os.path.join(HERE, name + ".calm")
         cf.write_synth(path, spec, dtype, seed=1234)
@@ -71,6 +86,8 @@ def main():
         )
         print(f"{name}: {os.path.getsize(path)} B model, {steps} steps, |logit|max {np.abs(logits[-1]).max():.3g}")
 
+    if only and "cli" not in only:
+        return
     # the reference CLI end to end (tokenizer + sampler + generate loop) on one case
     env = dict(os.environ, CALM_CPU="1", OMP_NUM_THREADS="2")
     r = subprocess.run([oracle.RUN_CPU, os.path.join(HERE, "tiny_fp16.calm"), "-i", "abc abc", "-t", "0", "-n", "32"], env=env, capture_output=True, text=True, check=True)
