@@ -6,6 +6,14 @@
 //   mode 1  chained: kernels alternate between two streams; kernel k+1 issues its first weight loads,
 //           then waits on a device-side completion counter of kernel k (agent-scope release/acquire per
 //           cdna_hip_programming.md Guideline 16), then reads k's output vector.
+//   mode 2  the same with system-scope loads/stores of the vector instead of the acquire fence
+//   mode 3  ONE stream, dependent kernels launched with hipExtAnyOrderLaunch (AQL packet without the barrier
+//           bit): the queue dispatches kernel k+1 as soon as kernel k's workgroups have all been dispatched and
+//           slots free up, so k+1's prefetch overlaps k's tail; the data dependency is the same device-side
+//           counter as in mode 1.  Kernel i keeps its barrier bit when i % depth == 0 (exp_set_depth), which
+//           bounds how many spinning successors pile up behind a running kernel.  hip_ext.h says the flag is
+//           "not supported on GFX9xx": exp_concurrency_anyorder() tests exactly that before any timing is read.
+//   mode 4  mode 3 with system-scope loads/stores (as mode 2)
 //
 // Each kernel: 256 blocks x 512 threads; every wave streams 8 KiB tasks with 16 KiB in flight; the
 // prologue reads the 16 KiB "activation" vector produced by the previous kernel (all blocks need all of
@@ -14,6 +22,7 @@
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_overlap.so tools/exp_overlap.hip
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -396,6 +405,52 @@ extern "C" int exp_concurrency(int nblocks) {
 	return ok;
 }
 
+static int g_depth = 0;
+extern "C" void exp_set_depth(int depth) {
+	g_depth = depth;
+}
+
+// the same probe on ONE stream: the waiting kernel first, then the flag-setting kernel launched with
+// hipExtAnyOrderLaunch.  If the waiters see the flag, the second packet ran without waiting for the first to
+// complete, i.e. the any-order flag is honoured on this chip; if not, they give up after their bounded spin.
+extern "C" int exp_concurrency_anyorder(int nblocks) {
+	hipStream_t s0;
+	CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking));
+	unsigned *flag, *seen;
+	unsigned long long* cyc;
+	CK(hipMalloc(&flag, 4));
+	CK(hipMalloc(&seen, 4 * nblocks));
+	CK(hipMalloc(&cyc, 8 * nblocks));
+	CK(hipMemset(flag, 0, 4));
+	CK(hipMemset(seen, 0, 4 * nblocks));
+	CK(hipDeviceSynchronize());
+	hipLaunchKernelGGL(k_wait_flag, dim3(nblocks), dim3(256), 0, s0, flag, seen, cyc);
+	void* args[1] = {&flag};
+	hipError_t e = hipExtLaunchKernel((const void*)k_set_flag, dim3(1), dim3(64), args, 0, s0, nullptr, nullptr, hipExtAnyOrderLaunch);
+	if (e != hipSuccess) {
+		printf("any-order probe: hipExtLaunchKernel(hipExtAnyOrderLaunch) refused: %s\n", hipGetErrorString(e));
+		(void)hipGetLastError();
+		hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(64), 0, s0, flag);
+	}
+	CK(hipDeviceSynchronize());
+	std::vector<unsigned> h(nblocks);
+	std::vector<unsigned long long> c(nblocks);
+	CK(hipMemcpy(h.data(), seen, 4 * nblocks, hipMemcpyDeviceToHost));
+	CK(hipMemcpy(c.data(), cyc, 8 * nblocks, hipMemcpyDeviceToHost));
+	int ok = 0;
+	unsigned long long mx = 0;
+	for (int i = 0; i < nblocks; ++i) {
+		ok += h[i];
+		mx = c[i] > mx ? c[i] : mx;
+	}
+	printf("any-order probe: %d / %d waiting blocks saw the flag set by an any-order kernel queued BEHIND them on the same stream (max wait %llu ticks @100MHz)\n", ok,
+	       nblocks, mx);
+	CK(hipFree(flag));
+	CK(hipFree(seen));
+	CK(hipFree(cyc));
+	return ok;
+}
+
 // One "token" = n_layers x 4 dependent streaming kernels.  Returns microseconds per layer; *checksum = sum of final vector.
 extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, double* checksum, int grid) {
 	static const size_t sizes[4] = {25165824, 16777216, 117440512, 58720256};
@@ -429,7 +484,7 @@ extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, do
 		CK(hipMemcpyAsync(xbuf[0], x0.data(), VEC * 4, hipMemcpyHostToDevice, s[0]));
 		CK(hipMemsetAsync(done, 0, 4 * (total + 1), s[0]));
 		hipEvent_t fork, join;
-		if (mode >= 1) {
+		if (mode == 1 || mode == 2) {
 			CK(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
 			CK(hipEventCreateWithFlags(&join, hipEventDisableTiming));
 			CK(hipEventRecord(fork, s[0]));
@@ -445,10 +500,16 @@ extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, do
 			a.expect_prev = grid;
 			a.done_me = done + i;
 			a.timeout = timeout;
-			a.chained = mode;
-			hipLaunchKernelGGL(k_stream, dim3(grid), dim3(BLOCK), 0, s[mode >= 1 ? (i & 1) : 0], a);
+			a.chained = mode >= 3 ? mode - 2 : mode;
+			if (mode >= 3) {
+				void* args[1] = {&a};
+				const bool barrier = g_depth > 0 ? (i % g_depth == 0) : (i == 0);
+				CK(hipExtLaunchKernel((const void*)k_stream, dim3(grid), dim3(BLOCK), args, 0, s[0], nullptr, nullptr, barrier ? 0 : hipExtAnyOrderLaunch));
+			} else {
+				hipLaunchKernelGGL(k_stream, dim3(grid), dim3(BLOCK), 0, s[mode >= 1 ? (i & 1) : 0], a);
+			}
 		}
-		if (mode >= 1) {
+		if (mode == 1 || mode == 2) {
 			CK(hipEventRecord(join, s[1]));
 			CK(hipStreamWaitEvent(s[0], join, 0));
 		}

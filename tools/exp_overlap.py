@@ -16,8 +16,23 @@ lib = C.CDLL(so)
 lib.exp_concurrency.restype = C.c_int
 lib.exp_chain.restype = C.c_double
 lib.exp_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
-lib.exp_concurrency(256)
+lib.exp_concurrency_anyorder.restype = C.c_int
+lib.exp_set_depth.argtypes = [C.c_int]
 L = 8
+if "anyorder" in sys.argv:
+    # same-stream overlap through hipExtAnyOrderLaunch (exp_overlap.hip modes 3 / 4); eager launches only
+    seen = lib.exp_concurrency_anyorder(256)
+    rows = [(0, 1, 0), (0, 0, 0)]
+    if seen > 0:
+        rows += [(3, 0, 0), (3, 0, 2), (3, 0, 4), (4, 0, 0), (4, 0, 2), (3, 1, 0)]
+    label = {0: "plain", 3: "any-order chain (acquire fence)", 4: "any-order chain (system-scope)"}
+    for mode, graph, depth in rows:
+        lib.exp_set_depth(depth)
+        cs = C.c_double(0)
+        us = lib.exp_chain(mode, graph, L, 10, C.byref(cs), 256)
+        print(f"grid=256 graph={graph} depth={depth} mode={label[mode]:34s}: {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+    sys.exit(0)
+lib.exp_concurrency(256)
 lib.exp_persist.restype = C.c_double
 lib.exp_persist.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.c_int]
 for grid in (256, 512):
