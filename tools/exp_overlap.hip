@@ -445,6 +445,7 @@ extern "C" int exp_concurrency_anyorder(int nblocks) {
 	}
 	printf("any-order probe: %d / %d waiting blocks saw the flag set by an any-order kernel queued BEHIND them on the same stream (max wait %llu ticks @100MHz)\n", ok,
 	       nblocks, mx);
+	fflush(stdout);
 	CK(hipFree(flag));
 	CK(hipFree(seen));
 	CK(hipFree(cyc));
