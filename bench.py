@@ -87,10 +87,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-device-greedy", action="store_true", help="skip the extra device-side greedy decode leg (rocprofv3 7.2 crashes in it)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--chain", default="auto",
-                    help="launch mode of the decode loop: 0 = hipGraph replay; 1 | 2 = eager launches with the dependent kernels chained without queue barriers "
-                         "(CALM_HIP_CHAIN; 2 chains the attention kernel too); auto = try all three on a few UNTIMED tokens during warm-up and keep the fastest "
-                         "whose token stream equals graph replay's")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,33 +124,6 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # launch mode of the decode loop (all three run the same kernels' arithmetic; see --chain).  Calibration is part of
-    # the untimed warm-up: 8 + 40 tokens per mode.
-    launch_names = {0: "hipGraph replay", 1: "eager, matvec kernels chained without queue barriers", 2: "eager, all kernels chained without queue barriers"}
-    # bpc: resident 256-thread workgroups per CU the grids are sized for -- a chained successor starts early only if its
-    # workgroups fit beside its producer's, so the chained modes are also tried at 1.
-    calibration = None
-    chain_bpc = 2
-    if args.chain == "auto":
-        calibration, ref_toks, best = {}, None, (0, 2, None)
-        for mode, bpc in ((0, 2), (1, 2), (2, 2), (1, 1), (2, 1)):
-            be.lib.calm_hip_configure(b"chain", mode)
-            be.lib.calm_hip_configure(b"bpc", bpc)
-            generate(be, model, [first_token], 8)
-            t0 = time.perf_counter()
-            ctoks, _ = generate(be, model, [first_token], 40)
-            dt = (time.perf_counter() - t0) / 40
-            ref_toks = ctoks if mode == 0 else ref_toks
-            ok = ctoks == ref_toks
-            calibration[f"{launch_names[mode]}, bpc {bpc}"] = {"us_per_token": round(dt * 1e6, 1), "same_tokens": bool(ok)}
-            if ok and (best[2] is None or dt < best[2]):
-                best = (mode, bpc, dt)
-        chain_mode, chain_bpc = best[0], best[1]
-    else:
-        chain_mode = int(args.chain)
-    be.lib.calm_hip_configure(b"chain", chain_mode)
-    be.lib.calm_hip_configure(b"bpc", chain_bpc)
-
     # warm-up: W untimed decode steps (captures the hipGraphs, touches every weight once)
     generate(be, model, [first_token], args.warmup)
     barrier()
@@ -162,8 +131,6 @@ def main():
     toks, stats = generate(be, model, [first_token], args.steps)  # ends synchronised: forward_hip returned logits
     elapsed = time.perf_counter() - t0
     barrier()
-    be.lib.calm_hip_configure(b"chain", 0)  # the remaining legs (stage timings, device-side decode, prefill) do not use it
-    be.lib.calm_hip_configure(b"bpc", 2)
     from calm_amd.replicas import aggregate_throughput
 
     agg = aggregate_throughput(dist, args.steps, elapsed)
@@ -270,7 +237,6 @@ def main():
             "weights": f"{args.dtype} ({cf.DBITS[args.dtype]} bit), fp32 activations/accumulate, fp16 KV cache",
             "n_layers": n_layers, "dim": spec.dim, "hidden_dim": spec.hidden_dim, "vocab": spec.vocab_size, "context": model.config.seq_len,
             "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
-            "launch": f"{launch_names[chain_mode]}, bpc {chain_bpc}", "launch_calibration": calibration,
             "device": be.lib.calm_hip_device_name().decode(),
         },
         "achieved_GBps": round(achieved, 1),

@@ -7,7 +7,6 @@
 // (kernel boundary ~1.2-1.9 us).  All per-token scalars travel through a device-resident
 // TokState written by the graph's first kernel, whose arguments are patched before each replay.
 #include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdio.h>
@@ -17,7 +16,6 @@
 #include <map>
 #include <tuple>
 #include <type_traits>
-#include <utility>
 #include <vector>
 
 #include "../../include/calm_hip.h"
@@ -56,7 +54,6 @@ int g_ncu = 256;
 int g_bpc = 2;       // cap on resident 256-thread workgroups per CU when sizing grids (measured: 2 beats 3 and 4)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
-int g_chain = 0;     // CALM_HIP_CHAIN=1|2 -> eager launches, dependent kernels chained without the queue barrier (kernels.hip.h: ChainArgs; 2: attention too)
 int g_split_t = 128;   // kv positions per attention split (one round of the 8-wave GQA kernel)
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
 char g_devname[256] = "none";
@@ -124,11 +121,6 @@ struct Ctx {
 	size_t kv_layer_bytes = 0;
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
-	// chained launches: completion counters [5 * n_layers] (qkv, attn, attn_out, ffn_up, ffn_down of each layer), the values they
-	// will have once the launches enqueued so far are complete, and a give-up flag in host-mapped memory
-	unsigned* sync = nullptr;
-	std::vector<unsigned> sync_tgt;
-	unsigned *chain_err_h = nullptr, *chain_err_d = nullptr;
 	// batched prompt ingestion (allocated on first use): token-major [PF_NT][...] activations of one chunk
 	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
 	float2* pf_rope = nullptr;
@@ -207,59 +199,6 @@ void allow_lds(K kernel, size_t bytes) {
 	}
 }
 
-// How one kernel of a step is launched.  on: the CHAIN variant of the kernel (write-through results, counters);
-// any: without the queue's barrier bit (hipExtAnyOrderLaunch) -- it may start while its predecessors still run and
-// must then name the counter slot it waits on; done: the slot it bumps (-1: none).
-struct ChainLaunch {
-	bool on = false, any = false;
-	int wait = -1, done = -1;
-};
-
-ChainArgs chain_args(Ctx* c, const ChainLaunch& cl) {
-	ChainArgs a = {nullptr, 0u, nullptr, nullptr};
-	if (cl.on) {
-		a.wait = cl.wait >= 0 ? c->sync + cl.wait : nullptr;
-		a.target = cl.wait >= 0 ? c->sync_tgt[cl.wait] : 0u;
-		a.done = cl.done >= 0 ? c->sync + cl.done : nullptr;
-		a.err = c->chain_err_d;
-	}
-	return a;
-}
-
-void chain_launched(Ctx* c, const ChainLaunch& cl, unsigned grid) {
-	if (cl.on && cl.done >= 0) {
-		c->sync_tgt[cl.done] += grid; // one arrival per workgroup
-	}
-}
-
-int g_any_order_ok = 1; // cleared the first time the runtime refuses hipExtAnyOrderLaunch (hip_ext.h: "not supported on GFX9xx")
-
-template <class... P, size_t... I>
-bool launch_any_order(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, std::tuple<P...>& args, std::index_sequence<I...>) {
-	void* ptrs[] = {(void*)&std::get<I>(args)...};
-	hipError_t e = hipExtLaunchKernel((const void*)kernel, grid, block, ptrs, lds, g_stream, nullptr, nullptr, hipExtAnyOrderLaunch);
-	if (e != hipSuccess) {
-		(void)hipGetLastError();
-		fprintf(stderr, "calm_hip: hipExtAnyOrderLaunch refused (%s): chained kernels keep their queue barriers\n", hipGetErrorString(e));
-		g_any_order_ok = 0;
-		return false;
-	}
-	return true;
-}
-
-// ordinary launch, or (any_order) an AQL packet without the barrier bit; a chained kernel launched the ordinary way
-// is still correct (its producer's counter is simply complete by the time it starts)
-template <class... P, class... A>
-void launch_k(void (*kernel)(P...), dim3 grid, dim3 block, size_t lds, bool any_order, A... a) {
-	if (any_order && g_any_order_ok) {
-		std::tuple<P...> args{a...};
-		if (launch_any_order(kernel, grid, block, lds, args, std::index_sequence_for<P...>())) {
-			return;
-		}
-	}
-	hipLaunchKernelGGL(kernel, grid, block, lds, g_stream, a...);
-}
-
 // ---------------------------------------------------------------- stage launchers ---------------
 
 template <int DB>
@@ -277,7 +216,7 @@ void launch_rotate_sink(Ctx* c) {
 }
 
 template <int DB, int KVB>
-void launch_qkv(Ctx* c, int l, const ChainLaunch& cl = ChainLaunch()) {
+void launch_qkv(Ctx* c, int l) {
 	struct Config* p = &c->t->config;
 	struct Weights* w = &c->t->weights;
 	QkvArgs a;
@@ -293,23 +232,18 @@ void launch_qkv(Ctx* c, int l, const ChainLaunch& cl = ChainLaunch()) {
 	a.rope_cs = c->rope_cs;
 	a.dim = c->dim, a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len;
 	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
-	a.kv_pos = c->ba.kv_pos;
 	int ntasks = (c->q_dim + 2 * c->kv_dim) / Shape<DB>::NR;
 	dim3 grid(pick_blocks(ntasks, 4)), block(256);
 	size_t lds = lds_bytes<DB>(c->dim);
-	const ChainArgs ch = chain_args(c, cl);
 	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			by_bool(cl.on, [&](auto CH) {
-				launch_k(k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(CH)::value>, grid, block, lds, cl.any, a, ch);
-			});
+			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a);
 		});
 	});
-	chain_launched(c, cl, grid.x);
 }
 
 template <int KVB, int LPR>
-void launch_attn_lpr(Ctx* c, int l, int n_split, const ChainLaunch& cl) {
+void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	AttnArgs a;
 	a.q = c->q;
 	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
@@ -319,15 +253,11 @@ void launch_attn_lpr(Ctx* c, int l, int n_split, const ChainLaunch& cl) {
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
 	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
-	a.kv_len = c->ba.kv_len;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
-		const ChainArgs ch = chain_args(c, cl);
-		by_bool(cl.on, [&](auto CH) { launch_k(k_attn<KVB, LPR, decltype(CH)::value>, dim3(c->n_heads), dim3(ATTN_BLOCK), 0, cl.any, a, ch); });
-		chain_launched(c, cl, (unsigned)c->n_heads);
+		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a);
 		return;
 	}
-	CALM_REQUIRE(!cl.on, "the split attention kernels are not chained");
 	// long context: K/V rows loaded once per kv head for up to 4 query heads, kv range split, then merged
 	const int qh = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
 	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
@@ -342,43 +272,38 @@ void launch_attn_lpr(Ctx* c, int l, int n_split, const ChainLaunch& cl) {
 }
 
 template <int KVB>
-void launch_attn(Ctx* c, int l, int n_split, const ChainLaunch& cl = ChainLaunch()) {
+void launch_attn(Ctx* c, int l, int n_split) {
 	switch (c->lpr) {
 	case 4:
-		return launch_attn_lpr<KVB, 4>(c, l, n_split, cl);
+		return launch_attn_lpr<KVB, 4>(c, l, n_split);
 	case 8:
-		return launch_attn_lpr<KVB, 8>(c, l, n_split, cl);
+		return launch_attn_lpr<KVB, 8>(c, l, n_split);
 	case 16:
-		return launch_attn_lpr<KVB, 16>(c, l, n_split, cl);
+		return launch_attn_lpr<KVB, 16>(c, l, n_split);
 	case 32:
-		return launch_attn_lpr<KVB, 32>(c, l, n_split, cl);
+		return launch_attn_lpr<KVB, 32>(c, l, n_split);
 	case 64:
-		return launch_attn_lpr<KVB, 64>(c, l, n_split, cl);
+		return launch_attn_lpr<KVB, 64>(c, l, n_split);
 	default:
 		CALM_REQUIRE(false, "unsupported head_dim");
 	}
 }
 
 template <int DB>
-void launch_attn_out(Ctx* c, int l, const ChainLaunch& cl = ChainLaunch()) {
+void launch_attn_out(Ctx* c, int l) {
 	int ntasks = c->dim / Shape<DB>::NR;
 	dim3 grid(pick_blocks(ntasks, 4)), block(256);
 	size_t lds = lds_bytes<DB>(c->q_dim);
 	const void* wo = c->t->weights.wo[l];
-	const ChainArgs ch = chain_args(c, cl);
 	by_bool(stage_v4(c->q_dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->q_dim), [&](auto FULL) {
-			by_bool(cl.on, [&](auto CH) {
-				launch_k(k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(CH)::value>, grid, block, lds, cl.any, c->x, (const float*)c->att, wo,
-				         c->dim, c->q_dim, ch);
-			});
+			hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim);
 		});
 	});
-	chain_launched(c, cl, grid.x);
 }
 
 template <int DB>
-void launch_ffn_up(Ctx* c, int l, const ChainLaunch& cl = ChainLaunch()) {
+void launch_ffn_up(Ctx* c, int l) {
 	struct Config* p = &c->t->config;
 	struct Weights* w = &c->t->weights;
 	FfnUpArgs a;
@@ -392,20 +317,13 @@ void launch_ffn_up(Ctx* c, int l, const ChainLaunch& cl = ChainLaunch()) {
 	int ntasks = nact * (c->hidden / (Shape<DB>::NR / 2));
 	dim3 grid(pick_blocks(ntasks, 4)), block(256);
 	size_t lds = lds_bytes<DB>(c->dim);
-	const ChainArgs ch = chain_args(c, cl);
-	CALM_REQUIRE(!(cl.on && c->n_experts > 0), "chained launches are for dense models");
 	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			if (c->n_experts > 0) {
-				launch_k(k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, true, false>, grid, block, lds, false, a, ch);
-			} else {
-				by_bool(cl.on, [&](auto CH) {
-					launch_k(k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, false, decltype(CH)::value>, grid, block, lds, cl.any, a, ch);
-				});
-			}
+			by_bool(c->n_experts > 0, [&](auto MOE) {
+				hipLaunchKernelGGL((k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(MOE)::value>), grid, block, lds, g_stream, a);
+			});
 		});
 	});
-	chain_launched(c, cl, grid.x);
 }
 
 // gf4 rows of exactly 7 KiB chunks (hidden 14336) take the 2 x 7 tile shape: one exact step per task instead
@@ -417,43 +335,35 @@ inline bool ffn_down_u7(int hidden, int dbits) {
 }
 
 template <int DB>
-void launch_ffn_down(Ctx* c, int l, const ChainLaunch& cl = ChainLaunch()) {
+void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
 	const bool u7 = ffn_down_u7(c->hidden, DB);
 	int ntasks = c->dim / (u7 ? 2 : Shape<DB>::NR);
 	dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 	size_t lds = lds_bytes<DB>(c->hidden);
 	const void* w2 = c->t->weights.w2[l];
-	const ChainArgs ch = chain_args(c, cl);
 	by_bool(stage_v4(c->hidden, BLOCK), [&](auto V4) {
 		by_bool(u7, [&](auto U7) {
 			by_bool(rows_full<DB>(c->hidden), [&](auto FULL) {
-				by_bool(cl.on, [&](auto CH) {
-					launch_k(k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value, decltype(CH)::value>, grid, block, lds, cl.any, c->x,
-					         (const float*)c->he, w2, (const float*)c->moe_w, (const int*)c->moe_e, c->dim, c->hidden, c->n_active, ch);
-				});
+				hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->he, w2,
+				                   c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
 			});
 		});
 	});
-	chain_launched(c, cl, grid.x);
 }
 
 template <int DB>
-void launch_output(Ctx* c, const ChainLaunch& cl = ChainLaunch()) {
+void launch_output(Ctx* c) {
 	struct Config* p = &c->t->config;
 	int ntasks = (c->vocab + Shape<DB>::NR - 1) / Shape<DB>::NR;
 	dim3 grid(pick_blocks(ntasks, 4)), block(256);
 	size_t lds = lds_bytes<DB>(c->dim);
-	const ChainArgs ch = chain_args(c, cl);
 	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			by_bool(cl.on, [&](auto CH) {
-				launch_k(k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(CH)::value>, grid, block, lds, cl.any, c->logits_d, (const float*)c->x,
-				         (const float*)c->t->weights.rms_final_weight, (const void*)c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln, ch);
-			});
+			hipLaunchKernelGGL((k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
+			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
 		});
 	});
-	chain_launched(c, cl, grid.x);
 }
 
 void launch_argmax(Ctx* c) {
@@ -495,7 +405,6 @@ uint64_t stage_bytes(Ctx* c, int stage, int kv_len) {
 struct StepPlan {
 	int n_split;
 	bool kv_only, sink, chained, argmax, copy_logits;
-	bool chain; // eager step whose dependent matvec kernels overlap (ChainLaunch); never captured into a graph
 };
 
 template <int DB, int KVB>
@@ -515,34 +424,21 @@ void enqueue_step(Ctx* c, const StepPlan& sp, bool timed) {
 	if (sp.sink) {
 		launch_rotate_sink<KVB>(c);
 	}
-	// Chained step (counter slots per layer: qkv, attn, attn_out, ffn_up, ffn_down).
-	//   level 1: attention keeps its ordinary launches (a queue barrier on either side); the matvec kernels between one
-	//            attention and the next -- attn_out -> ffn_up -> ffn_down -> next layer's qkv (or the classifier) -- run
-	//            without barriers between them, each waiting on its producer's completion counter;
-	//   level 2: the unsplit attention kernel joins the chain, so the whole step after layer 0's qkv is barrier-free.
-	auto CL = [&](bool any, int wait, int done) {
-		ChainLaunch cl;
-		cl.on = sp.chain, cl.any = sp.chain && any, cl.wait = wait, cl.done = done;
-		return cl;
-	};
-	const bool chain_attn = sp.chain && g_chain >= 2 && sp.n_split == 1;
-	enum { S_QKV, S_ATTN, S_AO, S_UP, S_DOWN, S_PER_LAYER };
 	for (int l = 0; l < c->n_layers; ++l) {
-		const int s0 = S_PER_LAYER * l;
 		mark();
-		launch_qkv<DB, KVB>(c, l, l == 0 ? CL(false, -1, chain_attn ? s0 + S_QKV : -1) : CL(true, s0 - S_PER_LAYER + S_DOWN, chain_attn ? s0 + S_QKV : -1));
+		launch_qkv<DB, KVB>(c, l);
 		mark();
-		launch_attn<KVB>(c, l, sp.n_split, chain_attn ? CL(true, s0 + S_QKV, s0 + S_ATTN) : ChainLaunch());
+		launch_attn<KVB>(c, l, sp.n_split);
 		mark();
-		launch_attn_out<DB>(c, l, chain_attn ? CL(true, s0 + S_ATTN, s0 + S_AO) : CL(false, -1, s0 + S_AO));
+		launch_attn_out<DB>(c, l);
 		mark();
-		launch_ffn_up<DB>(c, l, CL(true, s0 + S_AO, s0 + S_UP));
+		launch_ffn_up<DB>(c, l);
 		mark();
-		launch_ffn_down<DB>(c, l, CL(true, s0 + S_UP, s0 + S_DOWN));
+		launch_ffn_down<DB>(c, l);
 	}
 	mark();
 	if (!sp.kv_only) {
-		launch_output<DB>(c, CL(true, S_PER_LAYER * (c->n_layers - 1) + S_DOWN, -1));
+		launch_output<DB>(c);
 		mark();
 		if (sp.argmax) {
 			launch_argmax(c);
@@ -621,21 +517,6 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 			span(CALM_STAGE_OUTPUT);
 		}
 		g_prof_ctx = c;
-		return;
-	}
-	// chained launches: dense models whose FFN norm is applied in k_ffn_up, host-fed tokens (the per-token scalars
-	// travel by value), eager only
-	sp.chain = g_chain && !tok_src && c->n_experts == 0 && !p->norm_par;
-	if (sp.chain && *c->chain_err_h != 0) {
-		// a bounded spin gave up (the queue did not dispatch in order, or a producer never ran): the steps since
-		// the last check are invalid; say so and go back to ordinary launches for the rest of the process
-		fprintf(stderr, "calm_hip: a chained kernel gave up waiting for its producer -- results since the last synchronisation are invalid; chained launches disabled\n");
-		*c->chain_err_h = 0;
-		g_chain = 0;
-		sp.chain = false;
-	}
-	if (sp.chain) {
-		dispatch_step(c, sp, false);
 		return;
 	}
 	if (!g_use_graph) {
@@ -863,23 +744,12 @@ void set_lds_attrs(Ctx* c) {
 		allow_lds(k_ffn_down<DB, 512, 8, false, false>, big);
 		allow_lds(k_ffn_down<DB, 512, 8, false, true>, big);
 		allow_lds(k_ffn_down<DB, 512, 8, true, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 4, false, false, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 4, false, true, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 4, true, true, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 8, false, false, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 8, false, true, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 8, true, true, true>, big);
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
 		if (d > 48 * 1024) {
 			allow_lds(k_qkv<DB, 16, 8, true>, d), allow_lds(k_qkv<DB, 16, 8, false>, d), allow_lds(k_qkv<DB, 8, 8, true>, d), allow_lds(k_qkv<DB, 8, 8, false>, d);
 			allow_lds(k_attn_out<DB, 8, true>, d), allow_lds(k_attn_out<DB, 8, false>, d);
 			allow_lds(k_ffn_up<DB, 8, true, true>, d), allow_lds(k_ffn_up<DB, 8, true, false>, d), allow_lds(k_ffn_up<DB, 8, false, true>, d), allow_lds(k_ffn_up<DB, 8, false, false>, d);
 			allow_lds(k_output<DB, 8, true>, d), allow_lds(k_output<DB, 8, false>, d);
-			// ... and their chained variants
-			allow_lds(k_qkv<DB, 16, 8, true, true>, d), allow_lds(k_qkv<DB, 16, 8, false, true>, d), allow_lds(k_qkv<DB, 8, 8, true, true>, d), allow_lds(k_qkv<DB, 8, 8, false, true>, d);
-			allow_lds(k_attn_out<DB, 8, true, true>, d), allow_lds(k_attn_out<DB, 8, false, true>, d);
-			allow_lds(k_ffn_up<DB, 8, true, false, true>, d), allow_lds(k_ffn_up<DB, 8, false, false, true>, d);
-			allow_lds(k_output<DB, 8, true, true>, d), allow_lds(k_output<DB, 8, false, true>, d);
 		}
 	});
 }
@@ -908,8 +778,6 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_use_graph;
 	} else if (!strcmp(key, "prof")) {
 		slot = &g_prof;
-	} else if (!strcmp(key, "chain")) {
-		slot = &g_chain;
 	} else if (!strcmp(key, "bpc")) {
 		slot = &g_bpc;
 	} else if (!strcmp(key, "split_t")) {
@@ -949,7 +817,6 @@ extern "C" void init_hip(void) {
 	g_device = dev;
 	g_bpc = env_int("CALM_HIP_BPC", g_bpc);
 	g_use_graph = env_int("CALM_HIP_GRAPH", 1);
-	g_chain = env_int("CALM_HIP_CHAIN", g_chain);
 	g_prof = env_int("CALM_HIP_PROF", 0);
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
@@ -1023,12 +890,6 @@ extern "C" void prepare_hip(struct Transformer* t) {
 	c->trace = (int*)dev_alloc((size_t)c->trace_cap * sizeof(int));
 	c->ts = (TokState*)dev_alloc(sizeof(TokState));
 	HIP_CHECK(hipMemset(c->ts, 0, sizeof(TokState)));
-	c->sync = (unsigned*)dev_alloc((size_t)5 * c->n_layers * sizeof(unsigned));
-	HIP_CHECK(hipMemset(c->sync, 0, (size_t)5 * c->n_layers * sizeof(unsigned)));
-	c->sync_tgt.assign((size_t)5 * c->n_layers, 0u);
-	HIP_CHECK(hipHostMalloc((void**)&c->chain_err_h, 64, hipHostMallocMapped));
-	*c->chain_err_h = 0;
-	HIP_CHECK(hipHostGetDevicePointer((void**)&c->chain_err_d, c->chain_err_h, 0));
 	HIP_CHECK(hipMemset(c->trace_count, 0, sizeof(int)));
 	HIP_CHECK(hipMemset(c->xb, 0, c->dim * sizeof(float)));
 
@@ -1127,8 +988,6 @@ extern "C" void release_hip(struct Transformer* t) {
 		}
 	}
 	HIP_CHECK(hipHostFree(c->logits_h));
-	HIP_CHECK(hipFree(c->sync));
-	HIP_CHECK(hipHostFree(c->chain_err_h));
 	if (g_prof_ctx == c) {
 		g_prof_ctx = nullptr;
 	}
@@ -1386,7 +1245,7 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n, ChainArgs{nullptr, 0u, nullptr, nullptr});
+				hipLaunchKernelGGL(k, dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
 			});
 		});
 	});
@@ -1410,7 +1269,7 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln, ChainArgs{nullptr, 0u, nullptr, nullptr});
+				hipLaunchKernelGGL(k, dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
 			});
 		});
 	});
@@ -1444,7 +1303,6 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 2) * sizeof(float));
 	TokState ts = {};
 	ts.kv_len = kv_len;
-	c.ba.kv_len = kv_len;
 	c.ts = (TokState*)upload_hip(&ts, sizeof(ts));
 	c.lpr = 4;
 	while (c.lpr * 8 < head_dim) {

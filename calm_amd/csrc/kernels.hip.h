@@ -432,78 +432,6 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float
 	__syncthreads();
 }
 
-// ---------------------------------------------------------------- chained launches ------------
-//
-// CHAIN variants of the matvec kernels can be launched WITHOUT the queue's barrier bit (hipExtAnyOrderLaunch): the
-// command processor then dispatches kernel k+1 as soon as kernel k's workgroups have all been dispatched and slots
-// free up, so k+1's launch, ramp-up and first 16 KiB per wave of weight stream overlap k's tail instead of following
-// its completion (the ~3.5 us every dependent launch costs).  The data dependency moves into the
-// kernels: k publishes its results with write-through (sc1) stores, drains them and bumps a completion counter once
-// per workgroup; k+1 issues its first two weight tiles, THEN waits for the counter, acquires, and only then touches
-// the activation vector (cdna_hip_programming.md Guideline 16: drained sc1 payload -> flag; acquire on the reader).
-// Dispatch is in order and every grid here is fully resident, so a waiting kernel never holds a slot its producer
-// still needs.  Every spin is bounded; a give-up sets *err and the host aborts.
-struct ChainArgs {
-	const unsigned* wait; // completion counter of the producer kernel (nullptr: ordinary launch order is enough)
-	unsigned target;      // value of *wait once the producer is complete (counters are monotonic over tokens)
-	unsigned* done;       // this kernel's completion counter, +1 per workgroup (nullptr: nobody waits on it)
-	unsigned* err;        // set to 1 when a bounded spin gave up
-};
-
-__device__ __forceinline__ void chain_wait(const ChainArgs& ch) {
-	if (ch.wait) { // kernel-uniform
-		if (threadIdx.x == 0) {
-			unsigned spins = 0;
-			// wrap-safe "counter has reached target"
-			while ((int)(__hip_atomic_load(ch.wait, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ch.target) < 0) {
-				__builtin_amdgcn_s_sleep(4);
-				if (++spins > (1u << 20)) {
-					__hip_atomic_store(ch.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // host-mapped word
-					break;
-				}
-			}
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // drop this CU's L1 and the XCD L2's stale lines
-		}
-		__syncthreads();
-	}
-}
-
-__device__ __forceinline__ void chain_done(const ChainArgs& ch) {
-	if (ch.done) { // kernel-uniform
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have been acknowledged
-		__syncthreads();
-		if (threadIdx.x == 0) {
-			__hip_atomic_fetch_add(ch.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-	}
-}
-
-// result stores: plain, or write-through to memory (sc1) when another kernel may read them while this one runs
-template <bool CHAIN>
-__device__ __forceinline__ void st_f32(float* p, float v) {
-	if constexpr (CHAIN) {
-		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	} else {
-		*p = v;
-	}
-}
-template <bool CHAIN>
-__device__ __forceinline__ void st_u32(unsigned* p, unsigned v) {
-	if constexpr (CHAIN) {
-		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	} else {
-		*p = v;
-	}
-}
-template <bool CHAIN>
-__device__ __forceinline__ void st_u16(unsigned short* p, unsigned short v) {
-	if constexpr (CHAIN) {
-		__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	} else {
-		*p = v;
-	}
-}
-
 // ---------------------------------------------------------------- the row engine --------------
 
 // A tile = U consecutive 1-KiB wave-loads of each of NR rows, held in registers.
@@ -560,13 +488,9 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // register tiles alternate through a 2x-unrolled loop body so all tile indices are compile-time.
 // aux_of(t, aux) may issue small loads the epilogue needs (residual value, RoPE pair); it runs before the
 // task's last multiply-add so that latency hides behind it.  epi(t, acc, aux): sums valid in lane RED_LANE.
-//
-// CHAIN: the producer of the activation vector may still be running when this kernel starts.  The two tiles go out
-// first (weights depend on nothing), then the workgroup waits for the producer's completion counter, and only then
-// pre() and stage() read the vector.
-template <int DB, int NR, int U, bool FULL, bool CHAIN, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                              StageFn stage, AuxFn aux_of, EpiFn epi, const ChainArgs& ch) {
+                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
 	const unsigned char* rows[2][NR];
@@ -603,9 +527,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? k0 : 0, nl, lane);
 	};
 
-	if constexpr (!CHAIN) {
-		pre(); // the activation vector's loads go first: they must retire before, not behind, the tiles
-	}
+	pre(); // the activation vector's loads go first: they must retire before, not behind, the tiles
 	int t = first, k0 = 0;   // step being consumed
 	bool live = t < ntasks;
 	int t1 = t, k1 = 0;      // step s+1
@@ -619,10 +541,6 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		}
 	}
 	issue(1, t1, k1, live1);
-	if constexpr (CHAIN) {
-		chain_wait(ch);
-		pre();
-	}
 	stage();
 	if (!live) {
 		return;
@@ -670,13 +588,10 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 // FULL (rows are whole KiB chunks) is a KERNEL template parameter picked by the host: carrying both variants
 // in one kernel doubled its code size for a branch that never changes (kernels this short feel their
 // instruction-cache warm-up).
-template <int DB, int NR, int U, bool FULL, bool CHAIN = false, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                         StageFn stage, AuxFn aux_of, EpiFn epi, const ChainArgs& ch = ChainArgs{nullptr, 0u, nullptr, nullptr}) {
-	run_rows_impl<DB, NR, U, FULL, CHAIN>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi, ch);
-	if constexpr (CHAIN) {
-		chain_done(ch); // every wave of the workgroup comes through here, with or without tasks
-	}
+                                         StageFn stage, AuxFn aux_of, EpiFn epi) {
+	run_rows_impl<DB, NR, U, FULL>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
 // rows per task / tile depth per weight format: 8 x 1 KiB loads in flight per wave in all cases
@@ -758,13 +673,12 @@ struct QkvArgs {
 	int dim, q_dim, kv_dim, head_dim, seq_len;
 	float eps, clip;
 	int ln;
-	int kv_pos; // CHAIN only: the slot by value (ts may be read through a scalar cache no kernel boundary has flushed)
 };
 
 // attention norm + fused q/k/v matvec + bias + clip + RoPE + KV append   (src/infer.c:352-381)
 // task = NR consecutive rows of the concatenated [wq; wk; wv]; rows come in RoPE pairs (2i, 2i+1).
-template <int DB, int KVB, int V, bool FULL, bool CHAIN = false>
-__global__ __launch_bounds__(256) void k_qkv(QkvArgs a, ChainArgs ch) {
+template <int DB, int KVB, int V, bool FULL>
+__global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -792,7 +706,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a, ChainArgs ch) {
 	StageRegs<V, true> sr;
 	auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
-	const int kv_pos = CHAIN ? a.kv_pos : a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
+	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
 	// aux = (cos, sin) of each row pair's RoPE angle, fetched before the task's last multiply-add
 	auto aux_of = [&](int t, float(&aux)[NR]) {
 #pragma unroll
@@ -825,12 +739,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a, ChainArgs ch) {
 				v1 = r1;
 			}
 			if (j < a.q_dim) {
-				if constexpr (CHAIN) {
-					st_f32<true>(a.q + j, v0);
-					st_f32<true>(a.q + j + 1, v1);
-				} else {
-					*(float2*)(a.q + j) = make_float2(v0, v1);
-				}
+				*(float2*)(a.q + j) = make_float2(v0, v1);
 			} else {
 				int jl = j - a.q_dim;
 				void* cache = a.kc;
@@ -840,15 +749,14 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a, ChainArgs ch) {
 				}
 				size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + kv_pos) * a.head_dim + (jl % a.head_dim);
 				if constexpr (KVB == 16) {
-					const __half2 hv = __floats2half2_rn(v0, v1); // RNE, as (half)x: src/infer.c:378-381
-					st_u32<CHAIN>((unsigned*)((__half*)cache + off), __builtin_bit_cast(unsigned, hv));
+					*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // RNE, as (half)x: src/infer.c:378-381
 				} else {
-					st_u16<CHAIN>((unsigned short*)((unsigned char*)cache + off), (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff));
+					*(unsigned short*)((unsigned char*)cache + off) = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff);
 				}
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL, CHAIN>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, aux_of, epi, ch);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -863,7 +771,6 @@ struct AttnArgs {
 	// batched prompt ingestion (prefill.hip.h: k_pf_attn): token b of the chunk reads q + b * pf_stride, attends to
 	// cache rows [0, pf_kv0 + b] and writes row b of the fragment-major matrix `out`; pf_nb tokens in the chunk
 	int pf_kv0, pf_stride, pf_nb;
-	int kv_len; // CHAIN only: by value (see QkvArgs::kv_pos)
 };
 
 // merge two online-softmax states (m, l, o[8])
@@ -886,10 +793,8 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // tiles of positions.  Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are
 // computed in one pass with running (max, sum, out) per lane group -- algebraically the same
 // result as the reference's three loops.
-// CHAIN: launched without the queue barrier behind k_qkv -- waits for its completion counter before touching q or the
-// cache (the new row is k_qkv's), publishes the head's output write-through for a chained k_attn_out.
-template <int KVB, int LPR, bool CHAIN = false>
-__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a, ChainArgs ch) {
+template <int KVB, int LPR>
+__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
 	constexpr int NW = ATTN_BLOCK / 64;
 	constexpr int UA = 4; // tiles in flight per wave
@@ -902,13 +807,10 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a, ChainArgs ch) {
 	const int r = lane % LPR, g = lane / LPR;
 	const bool dvalid = r * 8 < a.head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
-	const int kv_len = CHAIN ? a.kv_len : a.ts->kv_len;
+	const int kv_len = a.ts->kv_len;
 	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
-	if constexpr (CHAIN) {
-		chain_wait(ch);
-	}
 
 	float qv[8];
 #pragma unroll
@@ -1040,7 +942,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a, ChainArgs ch) {
 			if (a.n_split == 1) {
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
-					st_f32<CHAIN>(a.out + h * a.head_dim + d0 + i, o[i] / l);
+					a.out[h * a.head_dim + d0 + i] = o[i] / l;
 				}
 			} else {
 				float* p = a.partial + ((size_t)h * a.n_split + split) * (a.head_dim + 2);
@@ -1054,9 +956,6 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a, ChainArgs ch) {
 				}
 			}
 		}
-	}
-	if constexpr (CHAIN) {
-		chain_done(ch);
 	}
 }
 
@@ -1289,8 +1188,8 @@ __global__ __launch_bounds__(256) void k_attn_merge(const float* partial, float*
 }
 
 // ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
-template <int DB, int V, bool FULL, bool CHAIN = false>
-__global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim, ChainArgs ch) {
+template <int DB, int V, bool FULL>
+__global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -1316,11 +1215,11 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 		if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
-				st_f32<CHAIN>(x + t * NR + r, aux[r] + acc[r]);
+				x[t * NR + r] = aux[r] + acc[r];
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL, CHAIN>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi, ch);
+	run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
@@ -1345,10 +1244,8 @@ __device__ __forceinline__ float act_gelu(float x) {
 }
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
-// (CHAIN exists for dense models only: the routing of a mixture-of-experts layer needs the vector before any row can be chosen)
-template <int DB, int V, bool FULL, bool MOE, bool CHAIN = false>
-__global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a, ChainArgs ch) {
-	static_assert(!(MOE && CHAIN), "chained launches are for dense FFNs");
+template <int DB, int V, bool FULL, bool MOE>
+__global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	constexpr int JP = NR / 2; // hidden units per task
@@ -1381,7 +1278,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a, ChainArgs ch) {
 #pragma unroll
 			for (int p = 0; p < JP; ++p) {
 				float u = acc[2 * p], g = acc[2 * p + 1];
-				st_f32<CHAIN>(a.he + (size_t)k * a.hidden + j + p, (a.gelu ? act_gelu(u) : act_silu(u)) * g); // src/infer.c:440-450
+				a.he[(size_t)k * a.hidden + j + p] = (a.gelu ? act_gelu(u) : act_silu(u)) * g; // src/infer.c:440-450
 			}
 		}
 	};
@@ -1390,8 +1287,8 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a, ChainArgs ch) {
 	if constexpr (!MOE) {
 		auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
 		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL, CHAIN>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, no_aux, epi, ch);
-		if (!CHAIN && blockIdx.x == 0 && threadIdx.x == 0) { // (k_ffn_down does not read these for a dense model)
+		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, no_aux, epi);
+		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
 		}
@@ -1460,9 +1357,9 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a, ChainArgs ch) {
 // U7: rows of 7k KiB (hidden 14336 at fp8 = 14 chunks, fp16 = 28, gf4 = 7): tiles of 2 rows x 7 chunks, so a
 // wave's first two steps -- issued before the prologue -- already cover 28 KiB, the whole task at fp8;
 // the long prologue of this kernel (staging the hidden-sized vector) then hides behind the full stream.
-template <int DB, int BLOCK, int V, bool U7, bool FULL, bool CHAIN = false>
+template <int DB, int BLOCK, int V, bool U7, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
-                                                    int n_active, ChainArgs ch) {
+                                                    int n_active) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = U7 ? 2 : Shape<DB>::NR, U = U7 ? 7 : Shape<DB>::U;
 	constexpr int NW = BLOCK / 64;
@@ -1472,9 +1369,8 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 	const int lane = lane_id();
 	const int nact = n_active > 0 ? n_active : 1;
 	for (int k = 0; k < nact; ++k) {
-		// a dense model has one "expert" of weight 1 (src/infer.c:430-432); nothing to read from the routing buffers
-		const float wk = n_active > 0 ? moe_w[k] : 1.0f;
-		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)(n_active > 0 ? moe_e[k] : 0) * dim * row_bytes;
+		const float wk = moe_w[k];
+		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes;
 		auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
@@ -1499,19 +1395,17 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 			if (lane == RED_LANE) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
-					st_f32<CHAIN>(x + t * NR + r, aux[r] + acc[r] * wk);
+					x[t * NR + r] = aux[r] + acc[r] * wk;
 				}
 			}
 		};
-		const ChainArgs chk = {k == 0 ? ch.wait : nullptr, ch.target, k == nact - 1 ? ch.done : nullptr, ch.err};
-		run_rows<DB, NR, U, FULL, CHAIN>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, aux_of, epi, chk);
+		run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, aux_of, epi);
 	}
 }
 
 // ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
-template <int DB, int V, bool FULL, bool CHAIN = false>
-__global__ __launch_bounds__(256) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln,
-                                                ChainArgs ch) {
+template <int DB, int V, bool FULL>
+__global__ __launch_bounds__(256) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -1535,12 +1429,12 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
 				if (t * NR + r < vocab) {
-					st_f32<CHAIN>(logits + t * NR + r, acc[r]);
+					logits[t * NR + r] = acc[r];
 				}
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL, CHAIN>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi, ch);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
