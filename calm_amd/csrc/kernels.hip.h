@@ -788,29 +788,46 @@ __device__ __forceinline__ void sm_merge(float& m, float& l, float (&o)[8], floa
 
 constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions in flight per round
 
-// One workgroup (16 waves) per (query head, kv split).  LPR lanes cover one cached row (8 dims per
-// lane, one 16-byte load for fp16), so a wave-load covers 64/LPR positions; the 16 waves interleave
-// tiles of positions.  Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are
-// computed in one pass with running (max, sum, out) per lane group -- algebraically the same
-// result as the reference's three loops.
+// Short-context attention: one workgroup (16 waves) per query head, the whole cached range in one or two rounds, no
+// merge pass (longer contexts: k_attn_gqa + k_attn_merge).  LPR lanes cover one cached row (8 dims per lane, one
+// 16-byte load for fp16), so a wave-load covers 64/LPR positions; the 16 waves interleave tiles of positions.
+// Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are computed in one pass with running
+// (max, sum, out) per lane group -- algebraically the same result as the reference's three loops.
+// The kernel is latency, not bandwidth: its K/V rows were last touched a token ago and come from HBM.  So the first
+// round's loads are SPECULATIVE -- issued straight from the kernel arguments, clamped to the cache instead of to
+// kv_len, before the scalar load of kv_len has returned; rows past the live range hold zeros or older (finite) rows
+// and are masked like the tail of any round.  Later rounds are loaded one round ahead.
 template <int KVB, int LPR>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
 	constexpr int NW = ATTN_BLOCK / 64;
 	constexpr int UA = 4; // tiles in flight per wave
+	constexpr int STEP = NW * RPW * UA; // positions per round of the workgroup
 	__shared__ float sm_m[NW], sm_l[NW];
 	__shared__ float sm_o[NW][LPR * 8];
 
 	const int lane = lane_id(), wave = wave_id();
-	const int h = blockIdx.x / a.n_split, split = blockIdx.x % a.n_split;
+	const int h = blockIdx.x;
 	const int kvh = h / a.kv_mul;
 	const int r = lane % LPR, g = lane / LPR;
 	const bool dvalid = r * 8 < a.head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
-	const int kv_len = a.ts->kv_len;
-	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
-	const int t0 = split * chunk;
-	const int t1 = min(kv_len, t0 + chunk);
+
+	constexpr int EB = KVB / 8; // bytes per element
+	using Raw = std::conditional_t<KVB == 16, u32x4, u32x2>; // 8 cached elements
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
+	const size_t rstride = (size_t)a.head_dim * EB;
+	Raw kw[UA], vw[UA];
+	auto load_round = [&](int tb, int last_row) { // always issued, clamped into [0, last_row]
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			const int t = min(tb + u * NW * RPW + g, last_row);
+			kw[u] = *(const Raw*)(kbase + (size_t)t * rstride);
+			vw[u] = *(const Raw*)(vbase + (size_t)t * rstride);
+		}
+	};
+	load_round(wave * RPW, a.seq_len - 1);
 
 	float qv[8];
 #pragma unroll
@@ -826,40 +843,29 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 		o[i] = 0.f;
 	}
 
-	constexpr int EB = KVB / 8; // bytes per element
-	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const size_t rstride = (size_t)a.head_dim * EB;
-
-	for (int tb = t0 + wave * RPW; tb < t1; tb += NW * RPW * UA) {
+	// Round 0 runs unconditionally (a wave past the live range computes on masked rows): nothing before the
+	// dot products depends on kv_len, so its scalar load overlaps the K/V loads instead of preceding them.
+	const int kv_len = a.ts->kv_len;
+	int tb = wave * RPW;
+	do {
 		float kf[UA][8], vf[UA][8];
-		bool valid[UA];
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {
-			int t = tb + u * NW * RPW + g;
-			valid[u] = t < t1;
-			t = min(t, kv_len - 1); // always load (clamped); masked below -- keeps the vmcnt bookkeeping exact
-			{
-				if constexpr (KVB == 16) {
-					u32x4 kw = *(const u32x4*)(kbase + (size_t)t * rstride);
-					u32x4 vw = *(const u32x4*)(vbase + (size_t)t * rstride);
+			if constexpr (KVB == 16) {
 #pragma unroll
-					for (int i = 0; i < 4; ++i) {
-						kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[i] & 0xffff));
-						kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[i] >> 16));
-						vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[i] & 0xffff));
-						vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[i] >> 16));
-					}
-				} else {
-					u32x2 kw = *(const u32x2*)(kbase + (size_t)t * rstride);
-					u32x2 vw = *(const u32x2*)(vbase + (size_t)t * rstride);
+				for (int i = 0; i < 4; ++i) {
+					kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[u][i] & 0xffff));
+					kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[u][i] >> 16));
+					vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[u][i] & 0xffff));
+					vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[u][i] >> 16));
+				}
+			} else {
 #pragma unroll
-					for (int i = 0; i < 2; ++i) {
-						f32x2 k0 = bf8x2_lo(kw[i]), k1 = bf8x2_hi(kw[i]);
-						f32x2 v0 = bf8x2_lo(vw[i]), v1 = bf8x2_hi(vw[i]);
-						kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
-						vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
-					}
+				for (int i = 0; i < 2; ++i) {
+					f32x2 k0 = bf8x2_lo(kw[u][i]), k1 = bf8x2_hi(kw[u][i]);
+					f32x2 v0 = bf8x2_lo(vw[u][i]), v1 = bf8x2_hi(vw[u][i]);
+					kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
+					vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
 				}
 			}
 		}
@@ -871,8 +877,16 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			for (int i = 0; i < 8; ++i) {
 				d = fmaf(qv[i], kf[u][i], d);
 			}
-			d = group_sum<LPR>(d);
-			s[u] = valid[u] ? d / sqrt_hd : -INFINITY; // src/infer.c:247
+			s[u] = group_sum<LPR>(d);
+		}
+		if (tb + STEP < kv_len) { // wave-uniform: one round ahead
+			load_round(tb + STEP, kv_len - 1);
+		}
+		bool valid[UA];
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			valid[u] = tb + u * NW * RPW + g < kv_len;
+			s[u] = valid[u] ? s[u] / sqrt_hd : -INFINITY; // src/infer.c:247
 		}
 		float mn = m;
 #pragma unroll
@@ -897,7 +911,8 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			}
 			m = mn;
 		}
-	}
+		tb += STEP;
+	} while (tb < kv_len);
 
 	// merge the RPW lane groups of the wave
 #pragma unroll
@@ -923,39 +938,23 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 		}
 	}
 	__syncthreads();
-	if (wave == 0 && g == 0) {
-		m = sm_m[0], l = sm_l[0];
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			o[i] = sm_o[0][d0 + i];
-		}
+	// Merge the NW wave partials with one THREAD per output dim: the weights exp(m_w - M) are recomputed by every
+	// thread (NW exps), then one pass over the partials -- all of it parallel over head_dim threads.  (One lane group
+	// folding the waves in one after the other was a chain of NW dependent exp + rescale steps: ~1 us of this kernel.)
+	for (int d = threadIdx.x; d < a.head_dim; d += ATTN_BLOCK) {
+		float M = sm_m[0];
 #pragma unroll
 		for (int w = 1; w < NW; ++w) {
-			float o2[8];
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				o2[i] = sm_o[w][d0 + i];
-			}
-			sm_merge(m, l, o, sm_m[w], sm_l[w], o2);
+			M = fmaxf(M, sm_m[w]);
 		}
-		if (dvalid) {
-			if (a.n_split == 1) {
+		float L = 0.f, O = 0.f;
 #pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					a.out[h * a.head_dim + d0 + i] = o[i] / l;
-				}
-			} else {
-				float* p = a.partial + ((size_t)h * a.n_split + split) * (a.head_dim + 2);
-#pragma unroll
-				for (int i = 0; i < 8; ++i) {
-					p[d0 + i] = o[i];
-				}
-				if (r == 0) {
-					p[a.head_dim] = m;
-					p[a.head_dim + 1] = l;
-				}
-			}
+		for (int w = 0; w < NW; ++w) {
+			const float e = (sm_m[w] == -INFINITY) ? 0.f : __expf(sm_m[w] - M); // a wave without positions
+			L = fmaf(sm_l[w], e, L);
+			O = fmaf(sm_o[w][d], e, O);
 		}
+		a.out[h * a.head_dim + d] = O / L;
 	}
 }
 
@@ -1109,33 +1108,26 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(AttnArgs a) {
 		}
 	}
 	__syncthreads();
-	// wave q (q < QH) finishes query head q
-	if (wave < QH && g == 0) {
-		const int q = wave;
-		float mm = sm_m[q][0], ll = sm_l[q][0], oo[8];
-#pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			oo[i] = sm_o[q][0][d0 + i];
-		}
+	// one thread per (query head, output dim) folds the NW wave partials (see k_attn)
+	for (int idx = threadIdx.x; idx < QH * a.head_dim; idx += ATTN_GQA_BLOCK) {
+		const int q = idx / a.head_dim, d = idx % a.head_dim;
+		float M = sm_m[q][0];
 #pragma unroll
 		for (int w = 1; w < NW; ++w) {
-			float o2[8];
-#pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				o2[i] = sm_o[q][w][d0 + i];
-			}
-			sm_merge(mm, ll, oo, sm_m[q][w], sm_l[q][w], o2);
+			M = fmaxf(M, sm_m[q][w]);
 		}
-		if (dvalid) {
-			float* p = a.partial + ((size_t)(h0 + q) * a.n_split + split) * (a.head_dim + 2);
+		float L = 0.f, O = 0.f;
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				p[d0 + i] = oo[i];
-			}
-			if (r == 0) {
-				p[a.head_dim] = mm;
-				p[a.head_dim + 1] = ll;
-			}
+		for (int w = 0; w < NW; ++w) {
+			const float e = (sm_m[q][w] == -INFINITY) ? 0.f : __expf(sm_m[q][w] - M);
+			L = fmaf(sm_l[q][w], e, L);
+			O = fmaf(sm_o[q][w][d], e, O);
+		}
+		float* p = a.partial + ((size_t)(h0 + q) * a.n_split + split) * (a.head_dim + 2);
+		p[d] = O;
+		if (d == 0) {
+			p[a.head_dim] = M;
+			p[a.head_dim + 1] = L;
 		}
 	}
 }

@@ -207,13 +207,19 @@ class HipBackend:
         model.fill_transformer(self.t, lambda n: self._dev[n], kvbits)
         self.lib.prepare_hip(C.byref(self.t))
         self.vocab = model.config.vocab_size
+        self._logits_addr, self._logits_view = 0, None
 
     def forward(self, token: int, pos: int, flags: int = 0) -> Optional[np.ndarray]:
         """-> view of the backend's logits buffer (valid until the next call), or None for KV-only"""
         p = self.lib.forward_hip(C.byref(self.t), token, pos, flags)
         if not p:
             return None
-        return np.ctypeslib.as_array(p, shape=(self.vocab,))
+        # the backend's logits buffer never moves (pinned host memory, include/calm_hip.h): wrap it once
+        addr = C.addressof(p.contents)
+        if addr != self._logits_addr:
+            self._logits_view = np.ctypeslib.as_array(p, shape=(self.vocab,))
+            self._logits_addr = addr
+        return self._logits_view
 
     def forward_stage(self, token: int, pos: int, flags: int, stage_flags: int) -> Optional[np.ndarray]:
         p = self.lib.forward_stage_hip(C.byref(self.t), token, pos, flags, stage_flags)
@@ -278,7 +284,7 @@ class HipBackend:
 
 def argmax_first(logits: np.ndarray) -> int:
     """greedy sampler of the reference (src/sampler.c:34-42): first index of the strict maximum"""
-    return int(np.argmax(logits))
+    return int(logits.argmax())
 
 
 def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int, pos_offset: int = 0, kvbits: int = 16, batched_prompt: bool = False):
