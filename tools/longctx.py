@@ -19,12 +19,17 @@ for kvbits, ctx in ((16, 4096), (8, 32768)):
     be = HipBackend(model, kvbits=kvbits, stream=cf.synth_stream_big(spec, "fp8", 1, L))
     generate(be, model, [17], 16, kvbits=kvbits)
     for pos in ([256, 4000] if ctx == 4096 else [256, 4000, 8000, 16000, 32000]):
-        generate(be, model, [17], 8, pos_offset=pos, kvbits=kvbits)
-        t0 = time.perf_counter()
-        _, st = generate(be, model, [17], 32, pos_offset=pos + 8, kvbits=kvbits)
-        dt = time.perf_counter() - t0
-        us, b = be.stage_us(1, 6)
-        kv_mb = 2 * (kvbits // 8) * 1024 * (pos + 40) / 1e6
-        print(f"kv{kvbits:2d} ctx {ctx:5d} pos ~{pos:5d}: {dt/32*1e6:8.1f} us/token (L={L}); attention stage {us:7.2f} us for {kv_mb:6.1f} MB/layer = {kv_mb/us*1e3:6.0f} GB/s; "
-              f"full depth ~{32/dt*L/32:7.1f} tok/s", flush=True)
+        for split_t in [int(x) for x in os.environ.get("SPLITS", "0").split(",")]:  # 0 = the backend's default
+            old = lib.calm_hip_configure(b"split_t", split_t) if split_t else None
+            generate(be, model, [17], 8, pos_offset=pos, kvbits=kvbits)
+            t0 = time.perf_counter()
+            _, st = generate(be, model, [17], 32, pos_offset=pos + 8, kvbits=kvbits)
+            dt = time.perf_counter() - t0
+            us, b = be.stage_us(1, 6)
+            kv_mb = 2 * (kvbits // 8) * 1024 * (pos + 40) / 1e6
+            tag = f" split_t {split_t:3d}" if split_t else ""
+            print(f"kv{kvbits:2d} ctx {ctx:5d} pos ~{pos:5d}{tag}: {dt/32*1e6:8.1f} us/token (L={L}); attention stage {us:7.2f} us for {kv_mb:6.1f} MB/layer = {kv_mb/us*1e3:6.0f} GB/s; "
+                  f"full depth ~{32/dt*L/32:7.1f} tok/s", flush=True)
+            if split_t:
+                lib.calm_hip_configure(b"split_t", old)
     be.close()
