@@ -793,10 +793,9 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // 16-byte load for fp16), so a wave-load covers 64/LPR positions; the 16 waves interleave tiles of positions.
 // Scores, max-subtracted softmax and the V mix (src/infer.c:238-267) are computed in one pass with running
 // (max, sum, out) per lane group -- algebraically the same result as the reference's three loops.
-// The kernel is latency, not bandwidth: its K/V rows were last touched a token ago and come from HBM.  So the first
-// round's loads are SPECULATIVE -- issued straight from the kernel arguments, clamped to the cache instead of to
-// kv_len, before the scalar load of kv_len has returned; rows past the live range hold zeros or older (finite) rows
-// and are masked like the tail of any round.  Later rounds are loaded one round ahead.
+// The kernel is latency, not bandwidth: its K/V rows were last touched a token ago and come from HBM.  Rounds are
+// loaded one ahead of the arithmetic.  (Issuing the first round before kv_len is known -- clamped to the cache instead
+// of the live range -- measured the same 4.7 us and fetched 4 MB per launch of rows nobody needs: not kept.)
 template <int KVB, int LPR>
 __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
@@ -827,7 +826,8 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			vw[u] = *(const Raw*)(vbase + (size_t)t * rstride);
 		}
 	};
-	load_round(wave * RPW, a.seq_len - 1);
+	const int kv_len = a.ts->kv_len;
+	load_round(wave * RPW, kv_len - 1);
 
 	float qv[8];
 #pragma unroll
@@ -843,11 +843,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 		o[i] = 0.f;
 	}
 
-	// Round 0 runs unconditionally (a wave past the live range computes on masked rows): nothing before the
-	// dot products depends on kv_len, so its scalar load overlaps the K/V loads instead of preceding them.
-	const int kv_len = a.ts->kv_len;
-	int tb = wave * RPW;
-	do {
+	for (int tb = wave * RPW; tb < kv_len; tb += STEP) {
 		float kf[UA][8], vf[UA][8];
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {
@@ -911,8 +907,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 			}
 			m = mn;
 		}
-		tb += STEP;
-	} while (tb < kv_len);
+	}
 
 	// merge the RPW lane groups of the wave
 #pragma unroll

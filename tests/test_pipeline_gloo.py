@@ -30,7 +30,9 @@ WORKER = textwrap.dedent(
     sm, flags = stage_model(model, dist.get_rank(), dist.get_world_size())
     stage = PipelineStage(oracle.OracleBackend(sm), sm.config.dim, flags, dist, "cpu")
     toks = stage.generate(int(os.environ["CALM_FIRST"]), int(os.environ["CALM_STEPS"]))
-    print(json.dumps({"rank": dist.get_rank(), "layers": sm.config.n_layers, "tokens": toks}), flush=True)
+    # one write() per rank, newline included: the ranks share the launcher's pipe and print()'s separate newline interleaves
+    sys.stdout.write(json.dumps({"rank": dist.get_rank(), "layers": sm.config.n_layers, "tokens": toks}) + "\\n")
+    sys.stdout.flush()
     dist.destroy_process_group()
     """
 )
@@ -64,7 +66,7 @@ def test_pipeline_matches_unsharded_greedy_stream(tmp_path, case, world):
     env = dict(os.environ, CALM_ROOT=ROOT, CALM_MODEL=os.path.join(GOLDEN, case + ".calm"), CALM_FIRST=str(int(z["tokens"][0])), CALM_STEPS="12", OMP_NUM_THREADS="1")
     r = run_torchrun(script, world, env)
     assert r.returncode == 0, r.stderr[-3000:]
-    outs = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    outs = [json.loads(l) for l in r.stdout.replace("}{", "}\n{").splitlines() if l.startswith("{")]
     assert len(outs) == world and sum(o["layers"] for o in outs) == model.config.n_layers
     for o in outs:
         assert o["tokens"] == want, o
