@@ -300,28 +300,26 @@ def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int
     token = int(prompt_tokens[0])
     pos = 0
     out: List[int] = []
-    read_bytes = 0
-    _, _, n_bw = model.accounting()
+    forward = backend.forward  # (the loop body is on the clock: keep Python's share of a token small)
     t0 = time.perf_counter()
     if batched_prompt and n_prompt > 1 and steps >= n_prompt:
         backend.prefill(prompt_tokens[: n_prompt - 1], pos_offset)
-        for p in range(n_prompt - 1):
-            read_bytes += n_bw + model.kv_bandwidth(kvbits, p + pos_offset)
         out.extend(int(t) for t in prompt_tokens[1:])
         pos = n_prompt - 1
         token = int(prompt_tokens[pos])
     while pos < steps:
-        flags = FF if pos < n_prompt - 1 else 0
-        logits = backend.forward(token, pos + pos_offset, flags)
-        read_bytes += n_bw + model.kv_bandwidth(kvbits, pos + pos_offset)
         if pos < n_prompt - 1:
+            forward(token, pos + pos_offset, FF)
             nxt = int(prompt_tokens[pos + 1])
         else:
-            nxt = argmax_first(logits)
+            nxt = int(forward(token, pos + pos_offset, 0).argmax())  # src/sampler.c:34-42: first index of the maximum
         pos += 1
         out.append(nxt)
         token = nxt
     dt = time.perf_counter() - t0
+    # the reference's bandwidth accounting (src/run.c:161-165,211-212), summed off the clock
+    _, _, n_bw = model.accounting()
+    read_bytes = sum(n_bw + model.kv_bandwidth(kvbits, p + pos_offset) for p in range(pos))
     stats = {"tokens": pos, "seconds": dt, "tok_s": pos / dt, "GBps": read_bytes / 1e9 / dt, "read_bytes": read_bytes}
     return out, stats
 
