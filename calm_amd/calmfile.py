@@ -157,6 +157,33 @@ def write_calm(path: str, tensors: Dict[str, np.ndarray], metadata: Dict[str, ob
             np.ascontiguousarray(a).view(np.uint8).reshape(-1).tofile(f)
 
 
+def write_calm_stream(path: str, layout: Dict[str, np.ndarray], stream: Iterable[Tuple[str, np.ndarray]], metadata: Dict[str, object]) -> int:
+    """write_calm for models that should not sit in host memory: the header is laid out from `layout` (name ->
+    anything with the tensor's shape / dtype / nbytes, e.g. stub_tensors' placeholders), the bytes then come one
+    tensor at a time from `stream`, in the same order, and go straight to the file (the reference converter holds the
+    whole model, tools/convert.py:502-536).  Returns the file size."""
+    header = {"__metadata__": {k: str(v) for k, v in metadata.items()}}
+    off = 0
+    for name, a in layout.items():
+        header[name] = {"dtype": _tag(a), "shape": list(a.shape), "data_offsets": [off, off + a.nbytes]}
+        off += a.nbytes
+    hjson = json.dumps(header).encode("utf-8")
+    assert b"\\" not in hjson, "the reference parser rejects backslashes (src/tensors.c:31)"
+    hjson += b" " * (-(len(hjson) + 8) % _ALIGN)
+    names = iter(layout.items())
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hjson)))
+        f.write(hjson)
+        for name, a in stream:
+            want_name, want = next(names)
+            if name != want_name or tuple(a.shape) != tuple(want.shape) or _tag(a) != _tag(want):
+                raise ValueError(f"stream item {name} {a.shape} {_tag(a)} does not match the layout's {want_name} {want.shape} {_tag(want)}")
+            np.ascontiguousarray(a).view(np.uint8).reshape(-1).tofile(f)
+        if next(names, None) is not None:
+            raise ValueError("stream ended before the layout did")
+        return f.tell()
+
+
 class CalmFile:
     """read-only view of a .calm file (mmap); tensors come back as numpy views"""
 
@@ -583,3 +610,28 @@ def synth_model_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Option
     own array) -- use for layer-reduced models; for 7 GB+ models stream with synth_stream_big"""
     s = dataclasses.replace(spec, n_layers=n_layers if n_layers is not None else spec.n_layers)
     return dict(synth_stream_big(spec, dtype, seed, n_layers, reuse=False)), s.metadata(dtype)
+
+
+def write_synth_big(path: str, spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None) -> int:
+    """a full-size synthetic .calm file (synth_stream_big's content) written with one tensor in memory at a time:
+    the file the reference CLI -- or the CLI linked to libcalm_hip.so, INTEGRATION.md section A -- can be pointed at"""
+    s = dataclasses.replace(spec, n_layers=n_layers if n_layers is not None else spec.n_layers)
+    layout = stub_tensors(spec, dtype, n_layers)
+    toks, scores = _toy_tokenizer(s.vocab_size)
+    layout["tokenizer.tokens"] = toks
+    layout["tokenizer.scores"] = scores
+    return write_calm_stream(path, layout, synth_stream_big(spec, dtype, seed, n_layers, reuse=True), s.metadata(dtype))
+
+
+if __name__ == "__main__":
+    import argparse
+
+    ap = argparse.ArgumentParser(description="write a synthetic .calm model of a BASELINE shape (seeded random weights, toy tokenizer)")
+    ap.add_argument("model", choices=sorted(SPECS))
+    ap.add_argument("dtype", choices=sorted(DBITS))
+    ap.add_argument("out")
+    ap.add_argument("--layers", type=int, default=None, help="cut the depth (a layer-reduced model for CPU-affordable runs)")
+    ap.add_argument("--seed", type=int, default=1)
+    a = ap.parse_args()
+    n = write_synth_big(a.out, SPECS[a.model], a.dtype, a.seed, a.layers)
+    print(f"{a.out}: {n / 1e9:.3f} GB, {a.model} {a.dtype}, {a.layers or SPECS[a.model].n_layers} layers")

@@ -109,3 +109,48 @@ def test_reference_cli_reads_our_files_and_reproduces_golden_text():
     env = dict(os.environ, CALM_CPU="1", OMP_NUM_THREADS="2")
     r = subprocess.run([oracle.RUN_CPU, os.path.join(GOLDEN, "tiny_fp16.calm"), "-i", "abc abc", "-t", "0", "-n", "32"], env=env, capture_output=True, text=True, check=True)
     assert r.stdout.splitlines()[1] + "\n" == open(os.path.join(GOLDEN, "cli_tiny_fp16.txt")).read()
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp8", "gf4"])
+def test_streamed_writer_equals_the_in_memory_model(tmp_path, dtype):
+    """write_synth_big (one tensor in memory at a time) writes the file synth_model_big describes, tokenizer included"""
+    spec = cf.ModelSpec("streamed", 128, 352, 32, 3, 4, 2, 500, 1e4, max_seq_len=64, n_experts=4 if dtype == "fp8" else 0, n_experts_active=2 if dtype == "fp8" else 0)
+    path = str(tmp_path / "m.calm")
+    size = cf.write_synth_big(path, spec, dtype, seed=5, n_layers=2)
+    assert size == os.path.getsize(path)
+    want, md = cf.synth_model_big(spec, dtype, seed=5, n_layers=2)
+    f = cf.CalmFile(path)
+    try:
+        assert list(f.names()) == list(want)
+        assert f.metadata == {k: str(v) for k, v in md.items()} and f.metadata["n_layers"] == "2"
+        for name, a in want.items():
+            assert f.tensor(name).tobytes() == np.ascontiguousarray(a).tobytes(), name
+    finally:
+        f.close()
+    m = HostModel.from_file(path)
+    assert m.config.n_layers == 2 and m.config.dim == 128 and m.accounting() == HostModel(want, md).accounting()
+
+
+def test_streamed_writer_rejects_a_stream_that_leaves_the_layout(tmp_path):
+    spec = cf.tiny_spec()
+    layout = cf.stub_tensors(spec, "fp8")
+    stream = list(cf.synth_stream_big(spec, "fp8", 1, reuse=False))
+    with pytest.raises(ValueError):
+        cf.write_calm_stream(str(tmp_path / "a.calm"), layout, iter(stream[:3] + stream[4:]), spec.metadata("fp8"))
+    with pytest.raises(ValueError):
+        cf.write_calm_stream(str(tmp_path / "b.calm"), layout, iter(stream[:5]), spec.metadata("fp8"))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(GOLDEN), "..", "oracle", "_ref", "run_cpu")), reason="reference CLI not built on this box")
+def test_reference_cli_decodes_a_streamed_file(tmp_path):
+    """the reference CLI (its own safetensors parser, tokenizer and CPU backend) runs a file written by the streaming
+    writer, and produces the token stream our oracle produces for the same model"""
+    from oracle import oracle
+
+    spec = cf.ModelSpec("streamed", 128, 352, 32, 2, 4, 2, 300, 1e4, max_seq_len=64)
+    path = str(tmp_path / "m.calm")
+    cf.write_synth_big(path, spec, "fp8", seed=2)
+    env = dict(os.environ, CALM_CPU="1", OMP_NUM_THREADS="2")
+    r = subprocess.run([oracle.RUN_CPU, path, "-i", "ab", "-t", "0", "-n", "12"], env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "tok/s" in r.stderr
