@@ -26,6 +26,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 #include <vector>
 
 #define CK(x)                                                                                   \
@@ -340,6 +341,302 @@ extern "C" double exp_persist(int variant, int n_layers, int iters, double* chec
 	CK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost));
 	if (to) {
 		printf("  !! a bounded spin timed out (persistent variant %d)\n", variant);
+	}
+	for (void* p : w) {
+		CK(hipFree(p));
+	}
+	CK(hipFree(dp));
+	CK(hipFree(xbuf[0]));
+	CK(hipFree(xbuf[1]));
+	CK(hipFree(done));
+	CK(hipFree(timeout));
+	return (double)ms * 1e3 / ((double)iters * n_layers);
+}
+
+// mode "deep" (NOT YET RUN ON HARDWARE -- written at the end of round 1 for the first GPU minutes of round 2):
+// the persistent launch again, but with the prefetch depth the arithmetic asks for.  A dependency edge inside a
+// launch costs (barrier + re-read of the activation vector) MINUS what the waves had already asked HBM for; k_persist
+// above holds 16 KiB per wave = 128 KiB per CU = 5.3 us of stream, a counter barrier plus the vector read is ~8 us, and
+// the ~3 us difference is exactly a launch's fixed cost -- the measured tie (48.2 vs 49.9 us/layer).  The LDS ring of
+// the guide's engine is the same 128 KiB (0.87x).  The register file is bigger than LDS: DEPTH tiles of 8 KiB per
+// streaming wave (DEPTH = 6: 192 VGPRs, 7 waves: 336 KiB per CU = 14 us of stream) cover the whole edge.
+// Two things make that depth usable:
+//   * a wave with 48 loads in flight cannot poll global memory (its poll returns behind them) nor publish results
+//     (vmcnt(0)): wave 0 of each workgroup is a COORDINATOR with an empty memory queue -- it stores the streamers'
+//     results (handed over through LDS), arrives on / polls the grid counter, reloads and stages the activation vector
+//     and raises an LDS flag; the 7 STREAMER waves touch global memory with weight loads only (counted vmcnt stays
+//     exact) and wait on LDS;
+//   * the streamers' load cursor runs ahead of their consume cursor ACROSS phase boundaries (weights depend on nothing).
+// Same arithmetic per task as k_stream: the final vector must equal mode 0's bit for bit.
+template <int K, int N, class F>
+__device__ __forceinline__ bool static_steps(F& f) { // f(integral_constant<K>) for K = 0 .. N-1, stops when f returns true
+	if constexpr (K < N) {
+		if (f(std::integral_constant<int, K>())) {
+			return true;
+		}
+		return static_steps<K + 1, N>(f);
+	} else {
+		return false;
+	}
+}
+
+constexpr int DEEP_STREAMERS = NW - 1;
+constexpr int DEEP_MAXT = 16; // tasks of one phase per streamer (14336 tasks / 1792 streamers = 8)
+constexpr int DEEP_MAXP = 136; // phases per launch (a 32-layer token = 128 + classifier)
+
+template <int DEPTH>
+__global__ __launch_bounds__(BLOCK) void k_deep(const Phase* __restrict__ ph_global, int nphases, float* x0, float* x1, unsigned* done, unsigned* timeout) {
+	// the phase table lives in LDS: a streamer may touch global memory with weight loads ONLY (a table lookup compiled to a
+	// vector load inside its cursor loops turns every counted s_waitcnt vmcnt(N) into vmcnt(0) -- seen in the first build)
+	__shared__ Phase ph[DEEP_MAXP];
+	for (int i = threadIdx.x; i < nphases; i += BLOCK) {
+		ph[i] = ph_global[i];
+	}
+	__shared__ float xs[2][VEC];
+	__shared__ float sc[2];                           // norm scale of the staged vector
+	__shared__ float outv[2][DEEP_STREAMERS][DEEP_MAXT]; // results of a phase, per streamer
+	__shared__ int outn[2][DEEP_STREAMERS];
+	__shared__ int ready[2];    // phase number whose vector is staged in xs[p & 1] (+1), written by the coordinator
+	__shared__ int finished[2]; // streamers that have deposited their results of phase p (slot p & 1)
+	__shared__ int gave_up;     // a streamer's bounded spin timed out (streamers must not store to global memory: a store
+	                            // behind a branch would make their counted vmcnt waits inexact); the coordinator reports it
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	if (threadIdx.x < 2) {
+		ready[threadIdx.x] = 0;
+		finished[threadIdx.x] = 0;
+		gave_up = 0;
+	}
+	__syncthreads();
+	const size_t GS = (size_t)gridDim.x * DEEP_STREAMERS;
+
+	if (wave == 0) {
+		// ---------------- coordinator: one wave, nothing in flight but what it is waiting for
+		for (int p = 0; p <= nphases; ++p) {
+			const float* xin = (p & 1) ? x1 : x0;
+			if (p > 0) {
+				// results of phase p-1 from this workgroup's streamers -> global (write-through), then the grid counter
+				unsigned spins = 0;
+				while (__hip_atomic_load(&finished[(p - 1) & 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < DEEP_STREAMERS) {
+					__builtin_amdgcn_s_sleep(1);
+					if (++spins > (1u << 22)) {
+						*timeout = 2;
+						break;
+					}
+				}
+				float* xout = ((p - 1) & 1) ? x0 : x1;
+				for (int i = lane; i < DEEP_STREAMERS * DEEP_MAXT; i += 64) {
+					const int s = i / DEEP_MAXT, k = i % DEEP_MAXT;
+					if (k < outn[(p - 1) & 1][s]) {
+						const size_t t = (size_t)blockIdx.x * DEEP_STREAMERS + s + (size_t)k * GS;
+						if (t < VEC) {
+							__hip_atomic_store(xout + t, outv[(p - 1) & 1][s][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+					}
+				}
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+				if (lane == 0) {
+					__hip_atomic_store(&finished[(p - 1) & 1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					__hip_atomic_fetch_add(done + (p - 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				if (p == nphases) {
+					if (lane == 0 && gave_up) {
+						*timeout = (unsigned)gave_up;
+					}
+					break;
+				}
+				spins = 0;
+				while (__hip_atomic_load(done + (p - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) {
+					__builtin_amdgcn_s_sleep(2);
+					if (++spins > (1u << 20)) {
+						*timeout = 1;
+						break;
+					}
+				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+			}
+			// stage the vector of phase p: 4096 floats by 64 lanes, sum of squares on the way
+			float ss = 0.f;
+			for (int i = lane; i < VEC / 4; i += 64) {
+				const float4 v = ((const float4*)xin)[i];
+				((float4*)xs[p & 1])[i] = v;
+				ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+			}
+			ss = wave_sum(ss);
+			if (lane == 0) {
+				sc[p & 1] = 1.0f / sqrtf(ss / VEC + 1e-5f);
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			if (lane == 0) {
+				__hip_atomic_store(&ready[p & 1], p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+			}
+		}
+		return;
+	}
+
+	// ---------------- streamers
+	const int s = wave - 1;
+	const size_t gs = (size_t)blockIdx.x * DEEP_STREAMERS + s;
+	u32x4 tile[DEPTH][8];
+	// cursors over the flattened (phase, task) sequence of this streamer
+	int ip = 0, cp = 0; // issue / consume phase
+	size_t it = gs, ct = gs;
+	auto settle = [&](int& p, size_t& t) { // skip phases in which this streamer has no (more) task
+		while (p < nphases && t >= ph[p].ntasks) {
+			++p;
+			t = gs;
+		}
+	};
+	auto issue = [&](auto K) {
+		constexpr int k = decltype(K)::value;
+		settle(ip, it);
+		const bool live = ip < nphases;
+		const void* w = ph[live ? ip : nphases - 1].w; // past the end: re-read something valid, drop it
+		const size_t t = live ? it : 0;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			tile[k][u] = __builtin_nontemporal_load((gptr16)w + t * 512 + u * 64 + lane);
+		}
+		it += GS;
+	};
+	auto first = [&](auto K) {
+		issue(K);
+		return false;
+	};
+	static_steps<0, DEPTH>(first);
+	int cur = -1, nout = 0; // phase whose vector this wave has seen ready; results deposited in it so far
+	auto leave_phase = [&](int p) { // all tasks of phase p done: hand the count over
+		if (lane == 0) {
+			outn[p & 1][s] = nout;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__hip_atomic_fetch_add(&finished[p & 1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		}
+		nout = 0;
+	};
+	auto step = [&](auto K) -> bool { // consume slot K, refill it; true when this streamer has no task left
+		constexpr int k = decltype(K)::value;
+		{
+			// phases this streamer walks past (finished, or empty for it) are handed over in order
+			while (cp < nphases && ct >= ph[cp].ntasks) {
+				if (cur == cp) {
+					leave_phase(cp);
+				} else { // never entered: wait until its slot is free, then report zero results
+					unsigned spins = 0;
+					while (__hip_atomic_load(&ready[cp & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < cp + 1) {
+						__builtin_amdgcn_s_sleep(1);
+						if (++spins > (1u << 22)) {
+							gave_up = 3;
+							break;
+						}
+					}
+					cur = cp;
+					leave_phase(cp);
+				}
+				++cp;
+				ct = gs;
+			}
+			if (cp >= nphases) {
+				return true;
+			}
+			if (cur != cp) { // first task of a new phase: its vector must be staged
+				unsigned spins = 0;
+				while (__hip_atomic_load(&ready[cp & 1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < cp + 1) {
+					__builtin_amdgcn_s_sleep(1);
+					if (++spins > (1u << 22)) {
+						gave_up = 4;
+						break;
+					}
+				}
+				cur = cp;
+			}
+			unsigned acc = 0;
+#pragma unroll
+			for (int u = 0; u < 8; ++u) {
+				acc += (tile[k][u][0] ^ tile[k][u][1]) + (tile[k][u][2] ^ tile[k][u][3]);
+			}
+			issue(K); // the slot is free again: DEPTH tasks ahead, whatever phase that is
+			const float v = wave_sum((float)((acc & 0xff) + 1) * (1.0f / 4096.0f)) * sc[cp & 1] * xs[cp & 1][(ct * 7) % VEC];
+			if (lane == 0 && nout < DEEP_MAXT) {
+				outv[cp & 1][s][nout] = v + (float)(ct % 13);
+			}
+			++nout;
+			ct += GS;
+		}
+		return false;
+	};
+	while (!static_steps<0, DEPTH>(step)) {
+	}
+}
+
+extern "C" double exp_deep(int depth, int n_layers, int iters, double* checksum) {
+	static const size_t sizes[4] = {25165824, 16777216, 117440512, 58720256};
+	const int NK = 4, total = n_layers * NK, grid = 256;
+	if (total > DEEP_MAXP) {
+		fprintf(stderr, "exp_deep: at most %d phases\n", DEEP_MAXP);
+		return -1;
+	}
+	hipStream_t s;
+	CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	std::vector<void*> w(total);
+	std::vector<Phase> hp(total);
+	for (int i = 0; i < total; ++i) {
+		CK(hipMalloc(&w[i], sizes[i % NK] + 65536));
+		CK(hipMemset(w[i], 0x11 + i / NK + i % NK, sizes[i % NK] + 65536));
+		hp[i].w = w[i];
+		hp[i].ntasks = sizes[i % NK] / 8192;
+	}
+	Phase* dp;
+	CK(hipMalloc(&dp, sizeof(Phase) * total));
+	CK(hipMemcpy(dp, hp.data(), sizeof(Phase) * total, hipMemcpyHostToDevice));
+	float* xbuf[2];
+	CK(hipMalloc(&xbuf[0], VEC * 4 + 65536));
+	CK(hipMalloc(&xbuf[1], VEC * 4 + 65536));
+	std::vector<float> x0(VEC);
+	for (int i = 0; i < VEC; ++i) {
+		x0[i] = 0.001f * (i % 97) + 0.5f;
+	}
+	unsigned *done, *timeout;
+	CK(hipMalloc(&done, 4 * (total + 1)));
+	CK(hipMalloc(&timeout, 4));
+	CK(hipMemset(timeout, 0, 4));
+	auto run = [&]() {
+		CK(hipMemcpyAsync(xbuf[0], x0.data(), VEC * 4, hipMemcpyHostToDevice, s));
+		CK(hipMemsetAsync(done, 0, 4 * (total + 1), s));
+		switch (depth) {
+		case 2:
+			hipLaunchKernelGGL(k_deep<2>, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout);
+			break;
+		case 4:
+			hipLaunchKernelGGL(k_deep<4>, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout);
+			break;
+		default:
+			hipLaunchKernelGGL(k_deep<6>, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout);
+		}
+	};
+	run();
+	CK(hipDeviceSynchronize());
+	hipEvent_t e0, e1;
+	CK(hipEventCreate(&e0));
+	CK(hipEventCreate(&e1));
+	CK(hipEventRecord(e0, s));
+	for (int i = 0; i < iters; ++i) {
+		run();
+	}
+	CK(hipEventRecord(e1, s));
+	CK(hipDeviceSynchronize());
+	float ms = 0;
+	CK(hipEventElapsedTime(&ms, e0, e1));
+	std::vector<float> xf(VEC);
+	CK(hipMemcpy(xf.data(), xbuf[total & 1], VEC * 4, hipMemcpyDeviceToHost));
+	double cs = 0;
+	for (int i = 0; i < VEC; ++i) {
+		cs += xf[i] * (1 + i % 5);
+	}
+	*checksum = cs;
+	unsigned to = 0;
+	CK(hipMemcpy(&to, timeout, 4, hipMemcpyDeviceToHost));
+	if (to) {
+		printf("  !! a bounded spin timed out (deep, depth %d, code %u)\n", depth, to);
+		fflush(stdout);
 	}
 	for (void* p : w) {
 		CK(hipFree(p));

@@ -19,6 +19,19 @@ lib.exp_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_doub
 lib.exp_concurrency_anyorder.restype = C.c_int
 lib.exp_set_depth.argtypes = [C.c_int]
 L = 8
+if "deep" in sys.argv:
+    # round-2 opener (exp_overlap.hip: k_deep): one persistent launch, coordinator wave + 7 streamer waves per CU holding
+    # DEPTH x 8 KiB each in registers across phase boundaries, against the launch-per-kernel chain.  The checksums must match.
+    lib.exp_deep.restype = C.c_double
+    lib.exp_deep.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
+    cs = C.c_double(0)
+    us = lib.exp_chain(0, 1, L, 10, C.byref(cs), 256)
+    print(f"launch per kernel (graph)          : {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+    for depth in (2, 4, 6):
+        cs = C.c_double(0)
+        us = lib.exp_deep(depth, L, 10, C.byref(cs))
+        print(f"persistent, {depth} x 8 KiB per streamer  : {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+    sys.exit(0)
 if "anyorder" in sys.argv:
     # same-stream overlap through hipExtAnyOrderLaunch (exp_overlap.hip modes 3 / 4); eager launches only
     seen = lib.exp_concurrency_anyorder(256)
