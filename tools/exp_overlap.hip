@@ -423,6 +423,7 @@ __global__ __launch_bounds__(BLOCK) void k_deep(const Phase* __restrict__ ph_glo
 						break;
 					}
 				}
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); // the streamers' outn / outv
 				float* xout = ((p - 1) & 1) ? x0 : x1;
 				for (int i = lane; i < DEEP_STREAMERS * DEEP_MAXT; i += 64) {
 					const int s = i / DEEP_MAXT, k = i % DEEP_MAXT;
@@ -454,16 +455,20 @@ __global__ __launch_bounds__(BLOCK) void k_deep(const Phase* __restrict__ ph_glo
 				}
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 			}
-			// stage the vector of phase p: 4096 floats by 64 lanes, sum of squares on the way
-			float ss = 0.f;
-			for (int i = lane; i < VEC / 4; i += 64) {
-				const float4 v = ((const float4*)xin)[i];
-				((float4*)xs[p & 1])[i] = v;
-				ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+			// stage the vector of phase p: 4096 floats by 64 lanes.  The sum of squares is taken in k_stream's order -- lane l
+			// plays threads l, l + 64, ... of its 512-thread block, one butterfly per emulated wave, the eight wave totals
+			// added in wave order -- so that the scale, and with it the final vector, equals mode 0's bit for bit.
+			float tot = 0.f;
+			for (int wv = 0; wv < NW; ++wv) {
+				const int tid = wv * 64 + lane;
+				const float4 a = ((const float4*)xin)[tid], b = ((const float4*)xin)[tid + BLOCK];
+				((float4*)xs[p & 1])[tid] = a;
+				((float4*)xs[p & 1])[tid + BLOCK] = b;
+				float ss = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w;
+				tot += wave_sum(ss);
 			}
-			ss = wave_sum(ss);
 			if (lane == 0) {
-				sc[p & 1] = 1.0f / sqrtf(ss / VEC + 1e-5f);
+				sc[p & 1] = 1.0f / sqrtf(tot / VEC + 1e-5f);
 			}
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 			if (lane == 0) {
