@@ -41,6 +41,11 @@
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4* gptr16;
 
+static int g_real = 0; // 1: every tile goes through the fp8 decode step's inner loop (tile_value<1>) in exp_chain / exp_deep
+extern "C" void exp_set_real(int real) {
+	g_real = real;
+}
+
 constexpr int BLOCK = 512;
 constexpr int NW = BLOCK / 64;
 constexpr int VEC = 4096; // floats in the activation vector
@@ -65,6 +70,38 @@ __device__ __forceinline__ float wave_sum(float v) {
 	return v;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// What a wave does with one 8-KiB tile.  REAL = 0: a token xor-sum (the kernels are pure streaming: how fast can the
+// launch structure possibly go).  REAL = 1: the fp8 decode step's inner loop -- every 16-byte lane-load is 16 e5m2 weights,
+// converted in pairs (v_cvt_pk_f32_bf8) and multiplied into the staged vector read from LDS as float4s (v_pk_fma_f32), one
+// VALU op and 4 LDS bytes per weight -- so that the consumers' duty cycle shows up in the measurement.
+template <int REAL>
+__device__ __forceinline__ float tile_value(const u32x4 (&t)[8], const float* xs, int lane) {
+	if constexpr (REAL == 0) {
+		unsigned acc = 0;
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			acc += (t[u][0] ^ t[u][1]) + (t[u][2] ^ t[u][3]);
+		}
+		return (float)((acc & 0xff) + 1) * (1.0f / 4096.0f);
+	} else {
+		f32x2 a0 = {0.f, 0.f}, a1 = {0.f, 0.f};
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+#pragma unroll
+			for (int i = 0; i < 4; ++i) {
+				const f32x4 xv = ((const f32x4*)xs)[((u * 4 + i) * 64 + lane) & (VEC / 4 - 1)];
+				a0 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_bf8((int)t[u][i], false), xv.lo, a0);
+				a1 = __builtin_elementwise_fma(__builtin_amdgcn_cvt_pk_f32_bf8((int)t[u][i], true), xv.hi, a1);
+			}
+		}
+		return ((a0[0] + a0[1]) + (a1[0] + a1[1])) * (1.0f / 4096.0f) + 1.0f / 4096.0f;
+	}
+}
+
+template <int REAL>
 __global__ __launch_bounds__(BLOCK) void k_stream(KArgs a) {
 	__shared__ float red[NW];
 	__shared__ float xs[VEC];
@@ -138,18 +175,14 @@ __global__ __launch_bounds__(BLOCK) void k_stream(KArgs a) {
 			if (t >= a.ntasks) {
 				goto finish;
 			}
-			unsigned acc = 0;
-#pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				acc += (tile[ph][u][0] ^ tile[ph][u][1]) + (tile[ph][u][2] ^ tile[ph][u][3]);
-			}
+			const float tv = tile_value<REAL>(tile[ph], xs, lane);
 			size_t t2 = t + 2 * W;
 			size_t tl = t2 < a.ntasks ? t2 : 0;
 #pragma unroll
 			for (int u = 0; u < 8; ++u) {
 				tile[ph][u] = __builtin_nontemporal_load((gptr16)a.w + tl * 512 + u * 64 + lane);
 			}
-			float v = wave_sum((float)((acc & 0xff) + 1) * (1.0f / 4096.0f)) * scale * xs[(t * 7) % VEC];
+			float v = wave_sum(tv) * scale * xs[(t * 7) % VEC];
 			if (lane == 0 && t < VEC) { // one writer per slot: the result is independent of timing
 				float r = v + (float)(t % 13);
 				if (a.chained == 2) {
@@ -384,7 +417,7 @@ constexpr int DEEP_STREAMERS = NW - 1;
 constexpr int DEEP_MAXT = 16; // tasks of one phase per streamer (14336 tasks / 1792 streamers = 8)
 constexpr int DEEP_MAXP = 136; // phases per launch (a 32-layer token = 128 + classifier)
 
-template <int DEPTH>
+template <int DEPTH, int REAL>
 __global__ __launch_bounds__(BLOCK) void k_deep(const Phase* __restrict__ ph_global, int nphases, float* x0, float* x1, unsigned* done, unsigned* timeout) {
 	// the phase table lives in LDS: a streamer may touch global memory with weight loads ONLY (a table lookup compiled to a
 	// vector load inside its cursor loops turns every counted s_waitcnt vmcnt(N) into vmcnt(0) -- seen in the first build)
@@ -553,13 +586,9 @@ __global__ __launch_bounds__(BLOCK) void k_deep(const Phase* __restrict__ ph_glo
 				}
 				cur = cp;
 			}
-			unsigned acc = 0;
-#pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				acc += (tile[k][u][0] ^ tile[k][u][1]) + (tile[k][u][2] ^ tile[k][u][3]);
-			}
+			const float tv = tile_value<REAL>(tile[k], xs[cp & 1], lane);
 			issue(K); // the slot is free again: DEPTH tasks ahead, whatever phase that is
-			const float v = wave_sum((float)((acc & 0xff) + 1) * (1.0f / 4096.0f)) * sc[cp & 1] * xs[cp & 1][(ct * 7) % VEC];
+			const float v = wave_sum(tv) * sc[cp & 1] * xs[cp & 1][(ct * 7) % VEC];
 			if (lane == 0 && nout < DEEP_MAXT) {
 				outv[cp & 1][s][nout] = v + (float)(ct % 13);
 			}
@@ -606,16 +635,31 @@ extern "C" double exp_deep(int depth, int n_layers, int iters, double* checksum)
 	auto run = [&]() {
 		CK(hipMemcpyAsync(xbuf[0], x0.data(), VEC * 4, hipMemcpyHostToDevice, s));
 		CK(hipMemsetAsync(done, 0, 4 * (total + 1), s));
-		switch (depth) {
-		case 2:
-			hipLaunchKernelGGL(k_deep<2>, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout);
-			break;
+#define DEEP(d, r) hipLaunchKernelGGL((k_deep<d, r>), dim3(grid), dim3(BLOCK), 0, s, (const Phase*)dp, total, xbuf[0], xbuf[1], done, timeout)
+		switch (depth * 2 + (g_real ? 1 : 0)) {
 		case 4:
-			hipLaunchKernelGGL(k_deep<4>, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout);
+			DEEP(2, 0);
+			break;
+		case 5:
+			DEEP(2, 1);
+			break;
+		case 8:
+			DEEP(4, 0);
+			break;
+		case 9:
+			DEEP(4, 1);
+			break;
+		case 10:
+			DEEP(5, 0);
+			break;
+		case 11:
+		case 13: // 6 tiles + the decode loop's registers spill (256 VGPRs at two waves per SIMD): 5 is the deepest REAL variant
+			DEEP(5, 1);
 			break;
 		default:
-			hipLaunchKernelGGL(k_deep<6>, dim3(grid), dim3(BLOCK), 0, s, dp, total, xbuf[0], xbuf[1], done, timeout);
+			DEEP(6, 0);
 		}
+#undef DEEP
 	};
 	run();
 	CK(hipDeviceSynchronize());
@@ -807,9 +851,12 @@ extern "C" double exp_chain(int mode, int use_graph, int n_layers, int iters, do
 			if (mode >= 3) {
 				void* args[1] = {&a};
 				const bool barrier = g_depth > 0 ? (i % g_depth == 0) : (i == 0);
-				CK(hipExtLaunchKernel((const void*)k_stream, dim3(grid), dim3(BLOCK), args, 0, s[0], nullptr, nullptr, barrier ? 0 : hipExtAnyOrderLaunch));
+				CK(hipExtLaunchKernel(g_real ? (const void*)k_stream<1> : (const void*)k_stream<0>, dim3(grid), dim3(BLOCK), args, 0, s[0], nullptr, nullptr,
+				                      barrier ? 0 : hipExtAnyOrderLaunch));
+			} else if (g_real) {
+				hipLaunchKernelGGL(k_stream<1>, dim3(grid), dim3(BLOCK), 0, s[mode >= 1 ? (i & 1) : 0], a);
 			} else {
-				hipLaunchKernelGGL(k_stream, dim3(grid), dim3(BLOCK), 0, s[mode >= 1 ? (i & 1) : 0], a);
+				hipLaunchKernelGGL(k_stream<0>, dim3(grid), dim3(BLOCK), 0, s[mode >= 1 ? (i & 1) : 0], a);
 			}
 		}
 		if (mode == 1 || mode == 2) {

@@ -24,13 +24,18 @@ if "deep" in sys.argv:
     # DEPTH x 8 KiB each in registers across phase boundaries, against the launch-per-kernel chain.  The checksums must match.
     lib.exp_deep.restype = C.c_double
     lib.exp_deep.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
-    cs = C.c_double(0)
-    us = lib.exp_chain(0, 1, L, 10, C.byref(cs), 256)
-    print(f"launch per kernel (graph)          : {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
-    for depth in (2, 4, 6):
+    lib.exp_set_real.argtypes = [C.c_int]
+    for real in (0, 1):  # 0: tiles are only touched (pure streaming); 1: every tile goes through the fp8 decode inner loop
+        lib.exp_set_real(real)
+        what = "fp8 decode loop per tile" if real else "tiles only touched"
         cs = C.c_double(0)
-        us = lib.exp_deep(depth, L, 10, C.byref(cs))
-        print(f"persistent, {depth} x 8 KiB per streamer  : {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+        us = lib.exp_chain(0, 1, L, 10, C.byref(cs), 256)
+        print(f"[{what}] launch per kernel (graph)         : {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+        for depth in ((2, 4, 5) if real else (2, 4, 6)):
+            cs = C.c_double(0)
+            us = lib.exp_deep(depth, L, 10, C.byref(cs))
+            print(f"[{what}] persistent, {depth} x 8 KiB per streamer : {us:8.2f} us/layer  ({218.1/us:6.2f} TB/s)  checksum {cs.value:.6f}", flush=True)
+    lib.exp_set_real(0)
     sys.exit(0)
 if "anyorder" in sys.argv:
     # same-stream overlap through hipExtAnyOrderLaunch (exp_overlap.hip modes 3 / 4); eager launches only
