@@ -112,3 +112,19 @@ def test_moe_gate_ties_and_weights():
 def test_argmax_is_first_strict_maximum():
     assert oracle.argmax(np.array([1.0, 3.0, 3.0, 2.0], dtype=np.float32)) == 1
     assert oracle.argmax(np.array([np.nan, -1.0, -1.0], dtype=np.float32)) == 1
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built on this box")
+@pytest.mark.parametrize("name,dtype", [("tinyllama-1.1b", "fp16"), ("mistral-7b", "fp8"), ("llama-3-8b", "gf4")])
+def test_oracle_matches_reference_at_full_width(name, dtype):
+    """the pin at BASELINE widths and vocabularies (one layer): dot products of 2048 .. 14336 terms, 32k .. 128k logits"""
+    tensors, md = cf.synth_model_big(cf.SPECS[name], dtype, seed=3, n_layers=1)
+    m = HostModel(tensors, md, context=32)
+    o, r = oracle.OracleBackend(m), oracle.RefBackend(m)
+    tok = 11
+    for pos in range(4):
+        lo, lr = o.forward(tok, pos), r.forward(tok, pos)
+        assert rel_err(lo, lr) < ORACLE_TOL
+        assert oracle.argmax(lo) == int(np.argmax(lr)) or np.partition(lr, -2)[-1] - np.partition(lr, -2)[-2] < 1e-3
+        tok = int(np.argmax(lr))
+    o.close()
