@@ -62,12 +62,19 @@ struct KArgs {
 	int chained;
 };
 
+// sum over the 64 lanes, VALU only (DPP row operations; the total lands in lane 63 and is broadcast with one v_readlane).
+// (Round 2: the ds_bpermute butterfly this replaces cost ~0.3 us of dependent LDS round trips per task -- with one wave per
+// SIMD that serial tail, not HBM, paced the persistent variants' catch-up after an edge.)
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) {
-		v += __shfl_xor(v, o);
-	}
-	return v;
+#define EXP_DPP(x, ctrl, rmask) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, rmask, 0xf, true))
+	v += EXP_DPP(v, 0xb1, 0xf);  // quad_perm [1,0,3,2]
+	v += EXP_DPP(v, 0x4e, 0xf);  // quad_perm [2,3,0,1]
+	v += EXP_DPP(v, 0x114, 0xf); // row_shr:4
+	v += EXP_DPP(v, 0x118, 0xf); // row_shr:8
+	v += EXP_DPP(v, 0x142, 0xa); // row_bcast:15
+	v += EXP_DPP(v, 0x143, 0xc); // row_bcast:31
+#undef EXP_DPP
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
