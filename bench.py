@@ -13,6 +13,7 @@ independent replicas (DESIGN.md section "multi-GPU"); value = tokens of all rank
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -24,55 +25,45 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured copy ceiling there: 6290
+HBM_NT_CEILING_GBPS = 6700.0  # this repo's own non-temporal streaming-read membench (profiles/r01_membench.txt)
 
 
-def cpu_baseline(spec, dtype, seed, n_tokens, first_token):
-    """the reference CPU path (oracle/_ref, the untouched src/infer.c) -- or our C restatement if that
-    binary is absent -- timed on this host on a bounded sample: layer-reduced models of the same shapes
-    (L = 2 and L = 6, same width / vocab), n_tokens greedy steps each; the per-layer and per-token-fixed
-    costs are solved from the two runs and extrapolated to the full depth."""
-    from calm_amd import calmfile as cf
-    from calm_amd.host import HostModel
-    from oracle import oracle  # test infrastructure used as the reported CPU baseline only
+def cpu_baseline(model, n_tokens, first_token, budget_s):
+    """the reference CPU path (oracle/_ref = the untouched src/infer.c; our C restatement if that binary is absent) timed on
+    this host on THE SAME model -- same depth, width, vocabulary and seeded weights as the GPU run -- decoding greedily from the
+    same first token like src/run.c:167-256 does: up to n_tokens positions, cut short once budget_s seconds of CPU work are
+    spent (the sample says how many were timed).  No extrapolation: value = timed positions / their wall time.
+    Returns (record, reference tokens, reference logits of the first positions)."""
+    from oracle import oracle  # test infrastructure: the reported CPU baseline and the parity checker, nothing else
 
-    # thread count: the reference's own default is half the logical CPUs (src/infer.c:171-176); on the
-    # 256-thread GPU hosts that many threads over a 1-2 GB sample measured erratic (0.7-2.3 tok/s run to
-    # run: one OpenMP region per matmul, first-touch placement), so the sample is capped at 32 threads
-    # unless OMP_NUM_THREADS is set by the caller
+    # thread count: the reference's own default is half the logical CPUs (src/infer.c:171-176); on the 256-thread GPU hosts
+    # that many threads measured erratic (one OpenMP region per matmul), so the run is capped at 32 unless the caller says
     cores = int(os.environ.get("OMP_NUM_THREADS", max(min((os.cpu_count() or 2) // 2, 32), 1)))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     kind = "reference" if oracle.have_ref() else "port"
-    times = {}
-    logits_ref = None
-    for L in (2, 6):  # sample sizes: 0.57 GB and 1.44 GB of weights per token
-        tensors, md = cf.synth_model_big(spec, dtype, seed, n_layers=L)
-        model = HostModel(tensors, md)
-        be = oracle.RefBackend(model) if kind == "reference" else oracle.OracleBackend(model)
-        tok = first_token
-        be.forward(tok, 0, 0)  # warm-up: pages in the weights (src/run.c:609-612)
-        per_tok = []
-        for pos in range(n_tokens):
-            t0 = time.perf_counter()
-            lg = be.forward(tok, pos, 0)
-            tok = int(np.argmax(lg))
-            per_tok.append(time.perf_counter() - t0)
-        times[L] = float(np.median(per_tok))  # shared-host VMs are noisy: median over the sample's tokens
-        if L == 2:
-            logits_ref = (tensors, md)
-        del be, model
-    per_layer = (times[6] - times[2]) / 4.0
-    if per_layer <= 0:  # timing noise swamped the difference: fall back to proportional scaling of the L=6 run
-        per_layer = times[6] / 6.5
-    fixed = max(times[2] - 2 * per_layer, 0.0)
-    full = fixed + spec.n_layers * per_layer
+    be = oracle.RefBackend(model) if kind == "reference" else oracle.OracleBackend(model)
+    be.forward(first_token, 0, 0)  # warm-up: pages in the weights (src/run.c:609-612)
+    toks, keep, tok = [], [], first_token
+    t0 = time.perf_counter()
+    for pos in range(n_tokens):
+        lg = be.forward(tok, pos, 0)
+        if pos < 32:
+            keep.append(lg.copy())
+        tok = int(np.argmax(lg))
+        toks.append(tok)
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    be.close()
+    n = len(toks)
     return {
-        "value": round(1.0 / full, 3),
+        "value": round(n / dt, 3),
         "unit": "tok/s",
-        "cores": int(os.environ["OMP_NUM_THREADS"]),
+        "cores": cores,
         "kind": kind,
-        "sample": f"layer-reduced L=2 and L=6 models of the same width/vocab, {n_tokens} greedy tokens each "
-                  f"(median {times[2]*1e3:.0f} / {times[6]*1e3:.0f} ms per token), extrapolated linearly to L={spec.n_layers}",
-    }, logits_ref
+        "sample": f"the same {model.config.n_layers}-layer model and weights as the GPU run, greedy decode of its first {n} positions "
+                  f"({dt:.1f} s of CPU, {dt / n * 1e3:.1f} ms per token)",
+    }, toks, keep
 
 
 def main():
@@ -83,7 +74,7 @@ def main():
     ap.add_argument("--model", default="mistral-7b")
     ap.add_argument("--dtype", default="fp8")
     ap.add_argument("--layers", type=int, default=0, help="override depth (debug only; invalidates the metric)")
-    ap.add_argument("--cpu-tokens", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="cap on the CPU baseline's timed region")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-device-greedy", action="store_true", help="skip the extra device-side greedy decode leg (rocprofv3 7.2 crashes in it)")
     ap.add_argument("--seed", type=int, default=1)
@@ -111,9 +102,16 @@ def main():
 
     spec = cf.SPECS[args.model]
     n_layers = args.layers or spec.n_layers
-    model = HostModel(cf.stub_tensors(spec, args.dtype, n_layers), (cf.dataclasses.replace(spec, n_layers=n_layers)).metadata(args.dtype))
+    want_cpu = not args.no_cpu and world == 1  # the CPU baseline is an N = 1 measurement (rank 0 would otherwise hold the others up)
     t0 = time.perf_counter()
-    be = HipBackend(model, stream=cf.synth_stream_big(spec, args.dtype, args.seed, n_layers))
+    if want_cpu:
+        # the CPU leg reads the same weights: hold the model on the host (every tensor its own array) and upload from there
+        tensors, md = cf.synth_model_big(spec, args.dtype, args.seed, n_layers)
+        model = HostModel(tensors, md)
+        be = HipBackend(model)
+    else:
+        model = HostModel(cf.stub_tensors(spec, args.dtype, n_layers), (cf.dataclasses.replace(spec, n_layers=n_layers)).metadata(args.dtype))
+        be = HipBackend(model, stream=cf.synth_stream_big(spec, args.dtype, args.seed, n_layers))
     load_s = time.perf_counter() - t0
     first_token = 17
 
@@ -156,13 +154,20 @@ def main():
     dom = stage_report["ffn_up"]
     # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own
     # run, x1024 x2 per MI355X_MICROARCH.md; tools/prof_summary.py) -- only for the shape it was measured on
-    traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc.json")
-    if os.path.exists(pmc_file) and args.model == "mistral-7b" and args.dtype == "fp8":
+    traffic, traffic_source = None, None
+    from calm_amd.build import csrc_sha
+
+    for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
         pmc = json.load(open(pmc_file))
+        # a PMC pass describes the kernels it was taken on: used only when it carries the hash of the CURRENT kernel sources
+        # and was taken on this shape; otherwise traffic is null rather than stale
+        if pmc.get("_csrc_sha") != csrc_sha() or pmc.get("_workload") != f"{args.model} {args.dtype}":
+            continue
         for k, v in pmc.items():
-            if k.startswith("k_ffn_up<8"):
+            if k.startswith("k_ffn_up<"):
                 traffic = int(v["hbm_read_bytes_per_launch_corrected"])
+                traffic_source = f"profiles/{os.path.basename(pmc_file)} (separate rocprofv3 --pmc FETCH_SIZE pass over the same kernel sources, x1024 x2)"
+        break
     roofline = {
         "bound": "hbm",
         "kernel": "k_ffn_up",
@@ -171,6 +176,8 @@ def main():
         "unit": "GB/s",
         "frac": round(dom["GBps"] / HBM_PEAK_GBPS, 4),
         "traffic": traffic,
+        "traffic_source": traffic_source,
+        "frac_of_measured_ceiling": round(dom["GBps"] / HBM_NT_CEILING_GBPS, 4),
         "bytes_per_launch": dom["bytes"],
         "us_per_launch": dom["us"],
     }
@@ -202,25 +209,23 @@ def main():
 
     cpu = None
     parity = None
-    if not args.no_cpu and world == 1:  # the CPU baseline is an N = 1 measurement (rank 0 would otherwise hold the others up)
-        cpu, (rt, rmd) = cpu_baseline(spec, args.dtype, args.seed, args.cpu_tokens, first_token)
-        # parity spot check on the L=2 sample: HIP vs the CPU reference, teacher-forced
-        from oracle import oracle
-
-        rm = HostModel(rt, rmd)
-        cb = oracle.RefBackend(rm) if oracle.have_ref() else oracle.OracleBackend(rm)
-        gb = HipBackend(rm)
+    if want_cpu:
+        cpu, ref_toks, ref_logits = cpu_baseline(model, args.steps, first_token, args.cpu_seconds)
+        # parity on the benchmark's own model at its full depth: the HIP logits teacher-forced along the reference's greedy
+        # stream (first positions), and the two greedy streams side by side over every position the CPU leg decoded
         worst, tok = 0.0, first_token
-        for pos in range(8):
-            lc = cb.forward(tok, pos, 0)
-            lg = gb.forward(tok, pos, 0)
+        for pos, lc in enumerate(ref_logits):
+            lg = be.forward(tok, pos, 0)
             worst = max(worst, float(np.abs(lg - lc).max() / np.abs(lc).max()))
-            tok = int(np.argmax(lc))
-        gb.close()
-        parity = {"sample": "L=2 model of the same width, 8 teacher-forced tokens", "max_rel_err": float(f"{worst:.3e}"), "tol": 1e-3}
+            tok = ref_toks[pos]
+        n_cmp = min(len(ref_toks), len(toks))
+        first_diff = next((i for i in range(n_cmp) if toks[i] != ref_toks[i]), None)
+        parity = {"sample": f"this run's {model.config.n_layers}-layer model: {len(ref_logits)} teacher-forced positions vs the CPU reference, "
+                            f"greedy streams compared over {n_cmp} positions",
+                  "max_rel_err": float(f"{worst:.3e}"), "tol": 1e-3, "greedy_identical": first_diff is None, "first_difference_at": first_diff}
 
     out = {
-        "metric": "decode tok/s (batch=1, 256 tok)",
+        "metric": f"decode tok/s (batch=1, {args.steps} tok)",
         "value": round(tok_s, 2),
         "unit": "tok/s",
         "n_gpus": world,
@@ -241,6 +246,7 @@ def main():
         },
         "achieved_GBps": round(achieved, 1),
         "hbm_frac_of_spec": round(achieved / HBM_PEAK_GBPS, 4),
+        "hbm_frac_of_measured_ceiling": round(achieved / HBM_NT_CEILING_GBPS, 4),
         "bytes_per_step": int(step_bytes),
         "roofline": roofline,
         "stages": stage_report,

@@ -40,6 +40,16 @@ def hip_sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(inc, f) for f in sorted(os.listdir(inc))]
 
 
+def csrc_sha() -> str:
+    """hash of the kernel and ABI sources: stamps a profile so that a stale one is recognised (no .git on the GPU box)"""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in hip_sources():
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_hip(force: bool = False) -> str:
     """compile every HIP translation unit for gfx950 into libcalm_hip.so"""
     srcs = hip_sources()

@@ -875,6 +875,15 @@ extern "C" void prepare_hip(struct Transformer* t) {
 	CALM_REQUIRE(p->n_heads % p->n_kv_heads == 0, "n_heads must be a multiple of n_kv_heads");
 	CALM_REQUIRE(p->seq_len > CALM_KV_SINKS, "seq_len too small");
 	CALM_REQUIRE(!p->n_experts || (p->n_experts_ac > 0 && p->n_experts_ac <= p->n_experts), "bad MoE configuration");
+	{
+		// every matvec kernel keeps its whole input vector in LDS as fp32 (gf4: plus one word sum per 8 columns): the largest
+		// of dim, n_heads*head_dim and hidden_dim must fit the CU's 160 KiB (~40K floats at fp16 / fp8, ~36K at gf4);
+		// documented in include/calm_hip.h -- wider models need a K-chunked staging this backend does not have yet
+		int widest = c->hidden > c->dim ? c->hidden : c->dim;
+		widest = c->q_dim > widest ? c->q_dim : widest;
+		size_t need = c->dbits == 16 ? lds_bytes<16>(widest) : (c->dbits == 8 ? lds_bytes<8>(widest) : lds_bytes<4>(widest));
+		CALM_REQUIRE(need <= 160 * 1024, "dim / hidden_dim too wide: the activation vector must fit the 160 KiB LDS (about 40K floats)");
+	}
 	c->lpr = 4;
 	while (c->lpr * 8 < c->head_dim) {
 		c->lpr *= 2;
@@ -1032,8 +1041,11 @@ extern "C" float* forward_stage_hip(struct Transformer* t, int token, int pos, u
 
 extern "C" void copy_hip(void* dst, const void* src, size_t size) {
 	init_hip();
+	// on the decode stream, then drained: ordered behind the step that produced `src` and ahead of the one that reads `dst`
+	// whatever the pointer kinds are (a device-to-device hipMemcpy on the null stream is neither: g_stream is non-blocking
+	// and a D2D copy is not host-synchronous)
+	HIP_CHECK(hipMemcpyAsync(dst, src, size, hipMemcpyDefault, g_stream));
 	HIP_CHECK(hipStreamSynchronize(g_stream));
-	HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyDefault));
 }
 
 namespace {
@@ -1334,13 +1346,23 @@ extern "C" int calm_hip_test_argmax(const float* logits, int n) {
 }
 
 extern "C" void calm_hip_read_kv(struct Transformer* t, int layer, int which, uint16_t* host) {
+	// the backend-private cache [kv_head][seq_len][head_dim] back in the reference's [seq_len][kv_dim] order, as binary16
+	// patterns: an fp8 cache's e5m2 bytes are widened (byte << 8 is the binary16 of the same value, src/infer.c:28-35)
 	Ctx* c = ctx_of(t);
-	CALM_REQUIRE(c->kvbits == 16 && layer >= 0 && layer < c->n_layers, "calm_hip_read_kv: fp16 cache only");
-	std::vector<uint16_t> tmp(c->kv_layer_bytes / 2);
+	CALM_REQUIRE(layer >= 0 && layer < c->n_layers, "calm_hip_read_kv: no such layer");
+	std::vector<unsigned char> tmp(c->kv_layer_bytes);
 	download_hip(tmp.data(), (char*)(which ? c->vc : c->kc) + (size_t)layer * c->kv_layer_bytes, c->kv_layer_bytes);
 	for (int h = 0; h < c->n_kv_heads; ++h) {
 		for (int p = 0; p < c->seq_len; ++p) {
-			memcpy(host + (size_t)p * c->kv_dim + h * c->head_dim, tmp.data() + ((size_t)h * c->seq_len + p) * c->head_dim, c->head_dim * 2);
+			uint16_t* dst = host + (size_t)p * c->kv_dim + h * c->head_dim;
+			const size_t src = ((size_t)h * c->seq_len + p) * c->head_dim;
+			if (c->kvbits == 16) {
+				memcpy(dst, tmp.data() + src * 2, c->head_dim * 2);
+			} else {
+				for (int i = 0; i < c->head_dim; ++i) {
+					dst[i] = (uint16_t)((uint16_t)tmp[src + i] << 8);
+				}
+			}
 		}
 	}
 }

@@ -131,6 +131,15 @@ __device__ __forceinline__ float bf8_byte0(unsigned w) {
 	return __builtin_amdgcn_cvt_f32_bf8((int)w, 0);
 }
 
+// two fp32 values -> two fp8 e5m2 bytes (low byte = a), one round-to-nearest-even step each, overflow and infinity saturating
+// to the largest finite code (57344): what `__nv_fp8_e5m2(float)` does for the reference's fp8 KV rows (src/infer.cu:473-482)
+// and what oracle_float_to_e5m2 restates.
+__device__ __forceinline__ unsigned short e5m2x2_sat(float a, float b) {
+	a = a > 57344.0f ? 57344.0f : (a < -57344.0f ? -57344.0f : a); // unordered compares are false: NaN stays NaN
+	b = b > 57344.0f ? 57344.0f : (b < -57344.0f ? -57344.0f : b);
+	return (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false) & 0xffff);
+}
+
 __device__ __forceinline__ float half_bits_to_float(unsigned short h) {
 	return __half2float(__ushort_as_half(h));
 }
@@ -656,7 +665,7 @@ __global__ void k_rotate_sink(void* kc, const float2* rope_cs1, int n_kv_heads, 
 		unsigned short b = *p;
 		f32x2 v = bf8x2_lo(b);
 		float a = v[0] * cs.x - v[1] * cs.y, c = v[0] * cs.y + v[1] * cs.x;
-		*p = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(a, c, 0, false) & 0xffff);
+		*p = e5m2x2_sat(a, c);
 	}
 }
 
@@ -751,7 +760,7 @@ __global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
 				if constexpr (KVB == 16) {
 					*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // RNE, as (half)x: src/infer.c:378-381
 				} else {
-					*(unsigned short*)((unsigned char*)cache + off) = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff);
+					*(unsigned short*)((unsigned char*)cache + off) = e5m2x2_sat(v0, v1);
 				}
 			}
 		}
@@ -1440,6 +1449,9 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
 // single workgroup of 1024 threads; writes *next and, if trace, appends to trace[(*trace_count)++]
 __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int n, int* next, int* trace, int* trace_count) {
+	// The reference scans from (max = -FLT_MAX, index = -1) taking every strictly greater value (src/sampler.c:34-42): NaNs and
+	// values <= -FLT_MAX never win.  With nothing to pick it returns -1 and its caller indexes the embedding table with that;
+	// here the degenerate case yields token 0 instead (the chained decode gathers embedding row `*next` on the device).
 	__shared__ float sv[16];
 	__shared__ int si[16];
 	float best = -3.402823466e+38f; // -FLT_MAX: values must be strictly greater to be picked
@@ -1472,6 +1484,9 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int n, int
 				best = sv[w];
 				bi = si[w];
 			}
+		}
+		if (bi < 0) {
+			bi = 0;
 		}
 		*next = bi;
 		if (trace) {

@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 							if constexpr (KVB == 16) {
 								*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // src/infer.c:378-381
 							} else {
-								*(unsigned short*)((unsigned char*)cache + off) = (unsigned short)(__builtin_amdgcn_cvt_pk_bf8_f32(v0, v1, 0, false) & 0xffff);
+								*(unsigned short*)((unsigned char*)cache + off) = e5m2x2_sat(v0, v1);
 							}
 						}
 					}

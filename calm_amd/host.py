@@ -197,6 +197,7 @@ class HipBackend:
         if self.lib.calm_hip_device_count() <= 0:
             raise RuntimeError("no HIP device visible: the calm_amd backend has no CPU fallback")
         self.model = model
+        self.kvbits = kvbits
         self.t = abi.Transformer()
         self._dev: Dict[str, int] = {}
         self.lib.init_hip()
@@ -287,7 +288,7 @@ def argmax_first(logits: np.ndarray) -> int:
     return int(logits.argmax())
 
 
-def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int, pos_offset: int = 0, kvbits: int = 16, batched_prompt: bool = False):
+def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int, pos_offset: int = 0, kvbits: Optional[int] = None, batched_prompt: bool = False):
     """greedy decode loop of src/run.c:167-256 (temperature 0): returns (tokens, stats).
 
     The first len(prompt)-1 positions are KV-only prompt steps; timing covers the whole loop, and
@@ -296,6 +297,7 @@ def generate(backend, model: HostModel, prompt_tokens: Sequence[int], steps: int
     same tokens out.
     """
     FF = abi.FF_UPDATE_KV_ONLY
+    kvbits = kvbits or getattr(backend, "kvbits", 16)  # the accounting follows the cache the backend really keeps (run.c:161-165)
     n_prompt = len(prompt_tokens)
     token = int(prompt_tokens[0])
     pos = 0

@@ -34,10 +34,12 @@ def layer_split(n_layers: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def stage_tensors(tensors: Dict[str, np.ndarray], l0: int, l1: int, first: bool, last: bool) -> Dict[str, np.ndarray]:
-    """the tensors stage [l0, l1) needs, layers renumbered from 0"""
+def stage_tensors(tensors: Dict[str, np.ndarray], l0: int, l1: int, first: bool, last: bool, tied: Optional[bool] = None) -> Dict[str, np.ndarray]:
+    """the tensors stage [l0, l1) needs, layers renumbered from 0.  tied: the classifier shares the embedding table
+    (src/run.c:112-116) -- derived from `tensors` when that is the WHOLE model, passed in when it is a slice of it"""
     out: Dict[str, np.ndarray] = {}
-    tied = "model.output.weight" not in tensors
+    if tied is None:
+        tied = "model.output.weight" not in tensors
     for name, a in tensors.items():
         if name.startswith("model.layers."):
             l = int(name.split(".")[2])
@@ -143,7 +145,7 @@ def main():
 
     def stream():  # this stage's share of the (deterministic) synthetic tensor stream, renumbered
         for name, a in cf.synth_stream_big(spec, args.dtype, args.seed, L):
-            got = stage_tensors({name: a}, l0, l1, rank == 0, rank == world - 1)
+            got = stage_tensors({name: a}, l0, l1, rank == 0, rank == world - 1, tied=spec.tied)
             for n2, a2 in got.items():
                 yield n2, a2
 

@@ -41,7 +41,11 @@ void* upload_hip(void* host, size_t size);
 
 /* replaces prepare_cuda (src/run.c:23,580; src/infer.cu:73-131): allocates activations, the KV
  * cache (state.kvbits must already be 8 or 16) and the host-visible logits buffer, and snapshots
- * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits. */
+ * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits.
+ * Aborts (like every error here) on shapes outside the backend's limits: dbits 4/8/16; dim, hidden_dim and
+ * n_heads*head_dim multiples of 128/dbits; head_dim a multiple of 8, at most 512; and -- the one limit the reference's
+ * backends do not have -- the widest of dim / hidden_dim / n_heads*head_dim must fit one CU's 160 KiB LDS as an fp32
+ * vector (about 40K elements at fp16 / fp8, 36K at gf4): every matvec kernel stages its whole input vector there. */
 void prepare_hip(struct Transformer* transformer);
 
 /* replaces forward_cuda (src/run.c:24,581; src/infer.cu:743-759): one decode step for `token`

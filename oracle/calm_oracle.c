@@ -101,6 +101,53 @@ static inline float fp8_to_float(uint8_t v) {
 	return oracle_half_to_float((uint16_t)((uint16_t)v << 8));
 }
 
+/* binary32 -> fp8 e5m2, ONE round-to-nearest-even step from the fp32 value, saturating to the largest finite code
+ * (0x7b = 57344) on overflow and infinity, NaN kept: `__nv_fp8_e5m2(float)` of the reference's CUDA backend
+ * (__NV_SATFINITE), which is how it stores K/V rows when kvbits == 8 (src/infer.cu:473-482, sink keys :150-180).
+ * The reference's CPU backend has no fp8 cache (src/infer.c:161 asserts kvbits == 16): this mode restates the CUDA
+ * path's STORAGE on top of the CPU path's arithmetic so that the HIP backend's fp8 cache has something to answer to. */
+uint8_t oracle_float_to_e5m2(float f) {
+	uint32_t x;
+	memcpy(&x, &f, 4);
+	uint32_t sign = (x >> 24) & 0x80u;
+	uint32_t absx = x & 0x7fffffffu;
+	if (absx > 0x7f800000u) {
+		return (uint8_t)(sign | 0x7fu);
+	}
+	if (absx >= 0x47600000u) { /* >= 57344: every such value rounds to or beyond the largest finite code */
+		return (uint8_t)(sign | 0x7bu);
+	}
+	int e = (int)(absx >> 23) - 127;
+	if (e < -18) { /* below half of the smallest subnormal (2^-16): zero */
+		return (uint8_t)sign;
+	}
+	uint32_t man = (absx & 0x7fffffu) | 0x800000u;
+	int shift;
+	uint32_t base;
+	if (e < -14) { /* subnormal e5m2 */
+		shift = 21 + (-14 - e);
+		base = 0;
+	} else {
+		shift = 21;
+		base = (uint32_t)(e + 15) << 2;
+		man &= 0x7fffffu;
+	}
+	uint32_t q = man >> shift;
+	uint32_t rem = man & ((1u << shift) - 1);
+	uint32_t half = 1u << (shift - 1);
+	if (rem > half || (rem == half && (q & 1))) {
+		q++;
+	}
+	uint32_t r = base + q; /* a carry out of the mantissa bumps the exponent */
+	return (uint8_t)(sign | (r > 0x7bu ? 0x7bu : r));
+}
+
+/* what a K/V element becomes in the cache: binary16 RNE (src/infer.c:378-381), or -- kvbits == 8 -- e5m2, kept in the same
+ * 16-bit slot as the binary16 pattern of the e5m2 value (byte << 8), so every reader below is unchanged */
+static inline uint16_t kv_store(float f, int kvbits) {
+	return kvbits == 8 ? (uint16_t)((uint16_t)oracle_float_to_e5m2(f) << 8) : oracle_float_to_half(f);
+}
+
 /* gf4: 32-bit word = fp8 scale in bits 0-7 and eight 3-bit codes; w_k = (code_k - 4) * scale / -4
  * (src/infer.c:37-40) */
 static inline float gf4_to_float(uint32_t word, int k) {
@@ -299,7 +346,7 @@ void oracle_prepare(struct Transformer* t) {
 	int kv_dim = p->head_dim * p->n_kv_heads;
 	int nact = p->n_experts_ac ? p->n_experts_ac : 1;
 
-	assert(s->kvbits == 16); /* the CPU path only has an fp16 cache (src/infer.c:26,161) */
+	assert(s->kvbits == 16 || s->kvbits == 8); /* 16: the CPU path's cache (src/infer.c:26,161); 8: the CUDA path's e5m2 rows, see kv_store */
 	s->x = calloc(p->dim, sizeof(float));
 	s->xb = calloc(p->dim, sizeof(float));
 	s->xb2 = calloc(q_dim > p->dim ? q_dim : p->dim, sizeof(float));
@@ -380,8 +427,8 @@ float* oracle_forward_stage(struct Transformer* t, int token, int pos, unsigned 
 
 		/* :378-381 */
 		for (int i = 0; i < kv_dim; i++) {
-			kb[(size_t)kv_pos * kv_dim + i] = oracle_float_to_half(s->k[i]);
-			vb[(size_t)kv_pos * kv_dim + i] = oracle_float_to_half(s->v[i]);
+			kb[(size_t)kv_pos * kv_dim + i] = kv_store(s->k[i], s->kvbits);
+			vb[(size_t)kv_pos * kv_dim + i] = kv_store(s->v[i], s->kvbits);
 		}
 
 		/* sink keys advance one position per step (fp16 round trip each time); :384-394 */
@@ -391,7 +438,7 @@ float* oracle_forward_stage(struct Transformer* t, int token, int pos, unsigned 
 			}
 			oracle_rope(s->k, kv_dim, p->head_dim, 1, p->rope_theta, p->rotary_dim);
 			for (int i = 0; i < kv_dim; i++) {
-				kb[(size_t)r * kv_dim + i] = oracle_float_to_half(s->k[i]);
+				kb[(size_t)r * kv_dim + i] = kv_store(s->k[i], s->kvbits);
 			}
 		}
 

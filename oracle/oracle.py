@@ -51,6 +51,8 @@ def lib() -> C.CDLL:
         L.oracle_half_to_float.argtypes = [C.c_uint16]
         L.oracle_float_to_half.restype = C.c_uint16
         L.oracle_float_to_half.argtypes = [C.c_float]
+        L.oracle_float_to_e5m2.restype = C.c_uint8
+        L.oracle_float_to_e5m2.argtypes = [C.c_float]
         L.oracle_decode_weight.restype = C.c_float
         L.oracle_decode_weight.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
         L.oracle_matvec.restype = None
@@ -136,11 +138,12 @@ def argmax(logits: np.ndarray) -> int:
 # ---- whole-model backends ----------------------------------------------------------------------
 
 class _CpuBackend:
-    def __init__(self, model: HostModel, prepare, forward, release=None):
+    def __init__(self, model: HostModel, prepare, forward, release=None, kvbits: int = 16):
         self.model = model
+        self.kvbits = kvbits
         self.t = abi.Transformer()
         self._keep = {n: np.ascontiguousarray(a) for n, a in model.tensors.items() if n.startswith("model.")}
-        model.fill_transformer(self.t, lambda n: self._keep[n].ctypes.data, 16)
+        model.fill_transformer(self.t, lambda n: self._keep[n].ctypes.data, kvbits)
         self._forward = forward
         self._release = release
         prepare(C.byref(self.t))
@@ -187,9 +190,11 @@ class _CpuBackend:
 class OracleBackend(_CpuBackend):
     """our C restatement (liboracle.so)"""
 
-    def __init__(self, model: HostModel):
+    def __init__(self, model: HostModel, kvbits: int = 16):
+        """kvbits = 8: K/V rows (and the re-rotated sink keys) are rounded to fp8 e5m2 as the reference's CUDA backend stores
+        them (src/infer.cu:473-482,150-180; calm_oracle.c: kv_store) -- the checker of the HIP backend's fp8 cache"""
         L = lib()
-        super().__init__(model, L.oracle_prepare, L.oracle_forward, L.oracle_release)
+        super().__init__(model, L.oracle_prepare, L.oracle_forward, L.oracle_release, kvbits)
 
     # the pipeline-stage surface of calm_amd.host.HipBackend, on host memory (tests of the stage protocol)
     def forward_stage(self, token: int, pos: int, flags: int, stage_flags: int):

@@ -1,0 +1,115 @@
+"""Full-DEPTH parity of the BASELINE configurations (north_star's own clause): the whole synthetic model -- every layer, full
+width, full vocabulary -- on the HIP backend against the reference CPU path (oracle/_ref = the untouched src/infer.c:311-472,
+driven like src/run.c:167-256 drives it; our C restatement if that binary is absent), same seeded weights on both sides:
+
+  (i)  logits of every decoded position, teacher-forced along the reference's own greedy stream:
+       max|delta| / max|logit| <= 1e-3 per token (fp16 AND fp8 / gf4: weights decode exactly, activations stay fp32);
+  (ii) the greedy stream itself: the HIP argmax equals the reference's next token at every position -- which makes the
+       free-running 256-token streams identical, both sides being deterministic -- or, where it does not, the reference's own
+       top-2 margin at that position is below 4 x tol x max|logit| (random-weight logits are near-tied now and then:
+       SURVEY.md section 7.3 #2) and the test says where.
+
+Error grows ~sqrt(L), so the layer-reduced tests elsewhere do not cover this.
+Needs the host copy of the model for the CPU side (7.2 GB for Mistral-7B fp8) and ~40 ms of CPU per reference token.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_err
+from calm_amd import calmfile as cf
+from calm_amd.host import HipBackend, HostModel
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-3
+
+
+@pytest.fixture(autouse=True)
+def more_cpu_threads():
+    """the CPU reference walks 2-8 GB of weights per token here: give it half the cores (its own default, src/infer.c:171-176;
+    conftest pins 8 for the tiny models) -- through the OpenMP runtime, the environment having been read already"""
+    import ctypes
+    import os
+
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(max(8, min(32, (os.cpu_count() or 16) // 2)))
+        yield
+        gomp.omp_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
+    except OSError:
+        yield
+
+
+def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
+    """-> dict(worst relative error, positions where argmax differed, reference tokens, hip tokens)"""
+    spec = cf.SPECS[name]
+    tensors, md = cf.synth_model_big(spec, dtype, seed)  # the real depth: n_layers is not overridden
+    model = HostModel(tensors, md)
+    assert model.config.n_layers == spec.n_layers
+    ref = oracle.RefBackend(model) if oracle.have_ref() else oracle.OracleBackend(model)
+    hip = HipBackend(model)
+    try:
+        # the reference's free-running greedy decode (run.c's loop), keeping every position's logits
+        ref_tokens, ref_logits, tok = [], [], first_token
+        for pos in range(n_tokens):
+            lg = ref.forward(tok, pos, 0)
+            ref_logits.append(lg.copy())
+            tok = oracle.argmax(lg)
+            ref_tokens.append(tok)
+        # HIP along the same stream
+        worst, diverged, hip_tokens, tok = 0.0, [], [], first_token
+        for pos in range(n_tokens):
+            lg = hip.forward(tok, pos, 0)
+            lr = ref_logits[pos]
+            assert np.isfinite(lg).all(), pos
+            e = rel_err(lg, lr)
+            worst = max(worst, e)
+            assert e <= TOL, f"{name} {dtype}: position {pos}: max|delta|/max|logit| = {e:.3e} > {TOL}"
+            h = int(lg.argmax())
+            hip_tokens.append(h)
+            if h != ref_tokens[pos]:
+                top2 = np.partition(lr, -2)[-2:]
+                margin = float(top2[1] - top2[0])
+                diverged.append((pos, h, ref_tokens[pos], margin, float(np.abs(lr).max())))
+            tok = ref_tokens[pos]
+        return {"worst": worst, "diverged": diverged, "ref_tokens": ref_tokens, "hip_tokens": hip_tokens}
+    finally:
+        hip.close()
+        ref.close()
+
+
+@pytest.mark.parametrize("name,dtype,n_tokens", [("mistral-7b", "fp8", 256), ("llama-3-8b", "gf4", 64), ("tinyllama-1.1b", "fp16", 64)])
+def test_full_depth_logits_and_greedy_stream_match_the_reference(hiplib, name, dtype, n_tokens):
+    r = full_depth_check(name, dtype, n_tokens)
+    print(f"{name} {dtype} full depth, {n_tokens} positions: worst max|d|/max|logit| = {r['worst']:.3e}; argmax differences: {r['diverged']}")
+    for pos, h, t, margin, lmax in r["diverged"]:
+        # a different pick is only acceptable at a near-tie of the REFERENCE's own logits
+        assert margin < 4 * TOL * lmax, f"{name} {dtype}: greedy streams part at position {pos} (hip {h}, reference {t}) with a reference top-2 margin of {margin:.3e}"
+    if not r["diverged"]:
+        assert r["hip_tokens"] == r["ref_tokens"]
+
+
+def test_full_depth_free_running_stream_mistral7b(hiplib):
+    """the headline configuration decoded FREE-RUNNING on both sides (each feeds on its own picks), 64 tokens: identical, or the
+    first difference sits on a reference near-tie (then the test reports it and stops comparing there)"""
+    spec = cf.SPECS["mistral-7b"]
+    tensors, md = cf.synth_model_big(spec, "fp8", 7)
+    model = HostModel(tensors, md)
+    ref = oracle.RefBackend(model) if oracle.have_ref() else oracle.OracleBackend(model)
+    hip = HipBackend(model)
+    try:
+        n = 64
+        dev, _ = hip.decode_greedy(23, 0, n)  # device-side loop: forward + on-device argmax, n tokens, no host in between
+        tok = 23
+        for pos in range(n):
+            lr = ref.forward(tok, pos, 0)
+            tok = oracle.argmax(lr)
+            if int(dev[pos]) != tok:
+                top2 = np.partition(lr, -2)[-2:]
+                assert top2[1] - top2[0] < 4 * TOL * np.abs(lr).max(), (pos, int(dev[pos]), tok)
+                print(f"free-running streams part at position {pos} on a reference near-tie (margin {top2[1] - top2[0]:.2e})")
+                break
+    finally:
+        hip.close()
+        ref.close()

@@ -142,6 +142,11 @@ def test_device_argmax_is_first_strict_maximum(hiplib):
         assert hiplib.calm_hip_test_argmax(fptr(lg), n) == oracle.argmax(lg)
     lg = np.array([np.nan, -3.0, np.nan, -3.0], dtype=np.float32)
     assert hiplib.calm_hip_test_argmax(fptr(lg), 4) == oracle.argmax(lg) == 1
+    # nothing to pick (all NaN / all <= -FLT_MAX): the reference returns -1 and would index the embedding table with it;
+    # the device sampler feeds its pick straight back into the next step, so it answers 0 there
+    for lg in (np.full(7, np.nan, dtype=np.float32), np.full(70, -np.inf, dtype=np.float32)):
+        assert oracle.argmax(lg) == -1
+        assert hiplib.calm_hip_test_argmax(fptr(lg), lg.size) == 0
 
 
 # ---------------------------------------------------------------- whole decode steps ------------

@@ -58,7 +58,7 @@ def pmc_fetch(d):
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith("--") and sys.argv[i] not in ("--tag", "--workload")]
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r01"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
@@ -75,7 +75,13 @@ def main():
         res = {}
         for k, v in fetch.items():
             res[k] = {"launches": len(v), "FETCH_SIZE_KiB_avg": sum(v) / len(v), "hbm_read_bytes_per_launch_corrected": sum(v) / len(v) * 1024 * 2}
+        sys.path.insert(0, root)
+        from calm_amd.build import csrc_sha
+
+        res["_csrc_sha"] = csrc_sha()  # bench.py reports `traffic` from this file only while the kernel sources are these
+        res["_workload"] = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "mistral-7b fp8"
         json.dump(res, open(os.path.join(root, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+        res = {k: v for k, v in res.items() if not k.startswith("_")}
         for k, r in sorted(res.items(), key=lambda kv: -kv[1]["hbm_read_bytes_per_launch_corrected"]):
             print(f"{k:40s} FETCH_SIZE avg {r['FETCH_SIZE_KiB_avg']:12.1f} KiB  -> {r['hbm_read_bytes_per_launch_corrected']/1e6:9.2f} MB/launch (x2 gfx950 correction)")
 
