@@ -16,6 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "calm_amd", "csrc")
 LIB_HIP = os.path.join(ROOT, "calm_amd", "libcalm_hip.so")
+LIB_HIP_TEST = os.path.join(ROOT, "calm_amd", "libcalm_hip_test.so")  # unit-test hooks: tests/ and tools/ only
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 REFERENCE = os.environ.get("CALM_REFERENCE", "/root/reference")
 
@@ -55,6 +56,8 @@ def build_hip(force: bool = False) -> str:
     srcs = hip_sources()
     if force or not _newer(LIB_HIP, srcs):
         _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP, os.path.join(CSRC, "infer_hip.hip")])
+    if force or not _newer(LIB_HIP_TEST, srcs):
+        _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP_TEST, os.path.join(CSRC, "test_hooks.hip")])
     return LIB_HIP
 
 

@@ -511,6 +511,47 @@ def _fill_codes(out: np.ndarray, dtype: str, sigma: float, seed: int) -> None:
             flat[a:b] = lut[u]
 
 
+def _synth_walk(spec: "ModelSpec", dtype: str, seed: int, n_layers: Optional[int], W, F, with_tokenizer: bool = True):
+    """the tensor sequence of a synthetic model in file order: W(shape, sigma, fill_seed) makes a weight tensor, F(array) passes
+    a small fp32 one on.  One walk serves the host filler (synth_stream_big) and the device filler (synth_device): same names,
+    same order, same per-tensor seeds -- the two produce the same bytes."""
+    s = dataclasses.replace(spec, n_layers=n_layers if n_layers is not None else spec.n_layers)
+    E = s.n_experts
+    lead = (E,) if E else ()
+    rng = np.random.default_rng(seed)
+    counter = [0]
+
+    def WW(shape, fan_in, scale=1.0):
+        counter[0] += 1
+        return W(shape, scale / math.sqrt(fan_in), seed * 100003 + counter[0])
+
+    def norm_w():
+        return F((1 + 0.1 * rng.standard_normal(s.dim)).astype(np.float32))
+
+    yield "model.embed.weight", WW((s.vocab_size, s.dim), 1.0)
+    for l in range(s.n_layers):
+        p = f"model.layers.{l}."
+        yield p + "attn.norm.weight", norm_w()
+        yield p + "attn.wq.weight", WW((s.q_dim, s.dim), s.dim)
+        yield p + "attn.wk.weight", WW((s.kv_dim, s.dim), s.dim)
+        yield p + "attn.wv.weight", WW((s.kv_dim, s.dim), s.dim)
+        yield p + "attn.wo.weight", WW((s.dim, s.q_dim), s.q_dim)
+        if s.norm_type != "layernorm_par":
+            yield p + "mlp.norm.weight", norm_w()
+        if E:
+            yield p + "moegate.weight", WW((E, s.dim), s.dim, scale=4.0)
+        yield p + "mlp.w1.weight", WW(lead + (s.hidden_dim, s.dim), s.dim)
+        yield p + "mlp.w2.weight", WW(lead + (s.dim, s.hidden_dim), s.hidden_dim)
+        yield p + "mlp.w3.weight", WW(lead + (s.hidden_dim, s.dim), s.dim)
+    yield "model.norm.weight", norm_w()
+    if not s.tied:
+        yield "model.output.weight", WW((s.vocab_size, s.dim), s.dim)
+    if with_tokenizer:
+        toks, scores = _toy_tokenizer(s.vocab_size)
+        yield "tokenizer.tokens", toks
+        yield "tokenizer.scores", scores
+
+
 def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None, reuse: bool = True):
     """Yield (name, array) for every tensor of a full-size synthetic model, in file order, in seconds.
 
@@ -525,16 +566,9 @@ def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optio
     runs at ~90 MB/s inside these VMs, so a 7 GB model held on the host costs 80 s, streamed 3 s.
     n_layers overrides spec.n_layers (layer-reduced models for CPU-affordable parity runs).
     """
-    s = dataclasses.replace(spec, n_layers=n_layers if n_layers is not None else spec.n_layers)
-    E = s.n_experts
-    lead = (E,) if E else ()
-    rng = np.random.default_rng(seed)
-    counter = [0]
     pool: Dict[Tuple, np.ndarray] = {}
 
-    def W(shape, fan_in, scale=1.0):
-        counter[0] += 1
-        sigma = scale / math.sqrt(fan_in)
+    def W(shape, sigma, fill_seed):
         store = {"fp16": np.uint16, "fp8": np.uint8, "gf4": np.uint32}[dtype]
         sshape = shape if dtype != "gf4" else shape[:-1] + (shape[-1] // 8,)
         key = (sshape, store)
@@ -542,30 +576,60 @@ def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optio
         if a is None:
             a = np.zeros(sshape, dtype=store)
             pool[key] = a
-        _fill_codes(a, dtype, sigma, seed * 100003 + counter[0])
+        _fill_codes(a, dtype, sigma, fill_seed)
         return a.view(np.float16) if dtype == "fp16" else (as_fp8(a) if dtype == "fp8" else a.view(np.int32))
 
-    yield "model.embed.weight", W((s.vocab_size, s.dim), 1.0)
-    for l in range(s.n_layers):
-        p = f"model.layers.{l}."
-        yield p + "attn.norm.weight", (1 + 0.1 * rng.standard_normal(s.dim)).astype(np.float32)
-        yield p + "attn.wq.weight", W((s.q_dim, s.dim), s.dim)
-        yield p + "attn.wk.weight", W((s.kv_dim, s.dim), s.dim)
-        yield p + "attn.wv.weight", W((s.kv_dim, s.dim), s.dim)
-        yield p + "attn.wo.weight", W((s.dim, s.q_dim), s.q_dim)
-        if s.norm_type != "layernorm_par":
-            yield p + "mlp.norm.weight", (1 + 0.1 * rng.standard_normal(s.dim)).astype(np.float32)
-        if E:
-            yield p + "moegate.weight", W((E, s.dim), s.dim, scale=4.0)
-        yield p + "mlp.w1.weight", W(lead + (s.hidden_dim, s.dim), s.dim)
-        yield p + "mlp.w2.weight", W(lead + (s.dim, s.hidden_dim), s.hidden_dim)
-        yield p + "mlp.w3.weight", W(lead + (s.hidden_dim, s.dim), s.dim)
-    yield "model.norm.weight", (1 + 0.1 * rng.standard_normal(s.dim)).astype(np.float32)
-    if not s.tied:
-        yield "model.output.weight", W((s.vocab_size, s.dim), s.dim)
-    toks, scores = _toy_tokenizer(s.vocab_size)
-    yield "tokenizer.tokens", toks
-    yield "tokenizer.scores", scores
+    return _synth_walk(spec, dtype, seed, n_layers, W, lambda a: a)
+
+
+_DEV_SYNTH_LIB = None
+
+
+def _dev_synth_lib():
+    """tools/libsynth_fill_hip.so: the device-side filler / gf4 quantiser (fixture tooling; hipcc --offload-arch=gfx950)"""
+    global _DEV_SYNTH_LIB
+    if _DEV_SYNTH_LIB is None:
+        import ctypes
+        import os
+        import subprocess
+
+        tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+        so, src = os.path.join(tools, "libsynth_fill_hip.so"), os.path.join(tools, "synth_fill_hip.hip")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", so, src],
+                           check=True, capture_output=True)
+        lib = ctypes.CDLL(so)
+        lib.synth_fill_hip.restype = None
+        lib.synth_fill_hip.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint64]
+        lib.quantize_gf4_hip.restype = None
+        lib.quantize_gf4_hip.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        _DEV_SYNTH_LIB = lib
+    return _DEV_SYNTH_LIB
+
+
+def synth_device(spec: ModelSpec, dtype: str, seed: int, n_layers: Optional[int], alloc, upload):
+    """Yield (name, DEVICE pointer) for every `model.*` tensor of the synthetic model synth_stream_big describes -- the same
+    bytes, produced on the GPU (tools/synth_fill_hip.hip): Mixtral-8x7B fp8 (46.7 GB) and DBRX-132B fp8 (131.6 GB) appear in
+    HBM in seconds.  alloc(nbytes) -> device pointer with the backend's slack (alloc_hip); upload(array) -> device pointer
+    (upload_hip; used for the small fp32 tensors and the code tables)."""
+    lib = _dev_synth_lib()
+    luts: Dict[Tuple[str, float], int] = {}
+    kind = {"fp8": 0, "fp16": 1, "gf4": 2}[dtype]
+    esize = {"fp8": 1, "fp16": 2, "gf4": 4}[dtype]
+
+    def W(shape, sigma, fill_seed):
+        n = int(np.prod(shape)) // (8 if dtype == "gf4" else 1)
+        key = (dtype, float(sigma))
+        if key not in luts:
+            luts[key] = upload(np.ascontiguousarray(_gf4_scale_lut(sigma) if dtype == "gf4" else _code_lut(dtype, sigma)))
+        ptr = alloc(n * esize)
+        lib.synth_fill_hip(ptr, n, kind, luts[key], fill_seed)
+        return ptr
+
+    for name, v in _synth_walk(spec, dtype, seed, n_layers, W, lambda a: upload(np.ascontiguousarray(a)), with_tokenizer=False):
+        yield name, v
+    for ptr in luts.values():  # handed back so that the caller can free them with the tensors
+        yield "", ptr
 
 
 def stub_tensors(spec: ModelSpec, dtype: str, n_layers: Optional[int] = None) -> Dict[str, np.ndarray]:

@@ -1304,53 +1304,113 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 		return;
 	}
 
-	// MoE: the routing decides which rows to stream, so it has to come first.  Every workgroup
-	// recomputes the gate (n_experts short rows, L2-resident) -- no cross-workgroup hand-off.
+	// MoE: the routing decides which rows to stream, so it has to come first.  Every workgroup recomputes the gate
+	// (n_experts short rows, L2-resident after the first workgroup) -- no cross-workgroup hand-off.  What does NOT depend
+	// on the routing is asked for up front: the vector and its norm weight, then the gate rows themselves (they are weights),
+	// so that the norm prologue runs while they fly.  Wave w owns experts w, w + 4, ...; its loads are numbered
+	// j = (expert slot i) * chunks + (1-KiB chunk k of the row); the first GP of them are prefetched into registers.
+	constexpr int GP = 16;
+	const int nl = a.dim / Fmt<DB>::G;          // 16-byte lane-loads per row
+	const int chunks = (nl + 63) >> 6;          // wave-loads per row
+	const int per_wave = (a.n_experts + 3) >> 2; // expert slots of a wave
+	const int total = per_wave * chunks;
+	auto gate_src = [&](int j, int& e, int& k) -> gptr16 {
+		const int i = j / chunks;
+		k = j - i * chunks;
+		e = wave + 4 * i;
+		const int ec = min(e, a.n_experts - 1), li = min(k * 64 + lane, nl - 1); // always in bounds; masked at use
+		return (gptr16)((const unsigned char*)a.moegate + (size_t)ec * row_bytes) + li;
+	};
 	stage_load<256>(sr, a.x, a.norm_w);
+	u32x4 gw[GP];
+#pragma unroll
+	for (int j = 0; j < GP; ++j) {
+		int e, k;
+		gw[j] = *gate_src(min(j, total - 1), e, k);
+	}
 	stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr);
 	{
-		const int nl = a.dim / Fmt<DB>::G;
-		for (int e = wave; e < a.n_experts; e += 4) {
-			const unsigned char* row = (const unsigned char*)a.moegate + (size_t)e * row_bytes;
-			f32x2 acc2 = {0.f, 0.f};
-			for (int k = 0; k * 64 < nl; ++k) {
-				int li = k * 64 + lane;
-				u32x4 w = li < nl ? *((const u32x4*)row + li) : (u32x4){0u, 0u, 0u, 0u};
-				acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
+		f32x2 acc2 = {0.f, 0.f};
+		auto gate_step = [&](u32x4 w, int j) { // multiply-add load j; a row's last chunk reduces and files the logit
+			int e, k;
+			(void)gate_src(j, e, k);
+			const bool live = k * 64 + lane < nl;
+			w = live ? w : (u32x4){0u, 0u, 0u, 0u};
+			if (k == 0) {
+				acc2 = (f32x2){0.f, 0.f};
 			}
-			float acc = wave_sum(acc2[0] + acc2[1]);
-			if (lane == 0) {
-				gate[e] = acc;
+			acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
+			if (k == chunks - 1) {
+				const float logit = wave_sum63(acc2[0] + acc2[1]);
+				if (lane == RED_LANE && e < a.n_experts) {
+					gate[e] = logit;
+				}
+			}
+		};
+#pragma unroll
+		for (int j = 0; j < GP; ++j) {
+			if (j < total) { // wave-uniform
+				gate_step(gw[j], j);
 			}
 		}
+		for (int j = GP; j < total; ++j) { // more gate rows than the prefetch holds (16 experts x 6 KiB rows: 24 loads per wave)
+			int e, k;
+			const u32x4 w = *gate_src(j, e, k);
+			gate_step(w, j);
+		}
 		__syncthreads();
-		if (threadIdx.x == 0) {
-			// top-k by logit, first maximum wins ties; weights = softmax over the selected logits
-			// (src/infer.c:277-305)
-			float max_val = -3.402823466e+38f;
-			for (int j = 0; j < a.n_experts; ++j) {
-				max_val = max_val < gate[j] ? gate[j] : max_val;
-			}
-			unsigned long long mask = 0;
-			float wsum = 0.f;
-			for (int k = 0; k < a.n_active; ++k) {
-				int best = -1;
-				for (int j = 0; j < a.n_experts; ++j) {
-					if ((mask & (1ull << j)) == 0 && (best == -1 || gate[j] > gate[best])) {
-						best = j;
+		if (wave == 0) {
+			// Routing, one expert per lane (n_experts <= 64): n_active rounds of a wave-wide arg-max over the logits not yet
+			// taken -- larger logit wins, equal logits go to the lower expert index -- then the softmax over the winners only,
+			// their exponentials summed in rank order (the semantics of src/infer.c:277-305; rank k ends up in lane k).
+			const bool valid = lane < a.n_experts;
+			const float logit = valid ? gate[valid ? lane : 0] : 0.f;
+			float top = logit; // the largest logit overall: the softmax's reference point
+			{
+				bool ok = valid;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) {
+					const float v2 = __shfl_xor(top, o);
+					const bool ok2 = __shfl_xor((int)ok, o) != 0;
+					if (ok2 && (!ok || v2 > top)) {
+						top = v2;
+						ok = true;
 					}
 				}
-				sel_e[k] = best;
-				wsum += expf(gate[best] - max_val);
-				mask |= 1ull << best;
 			}
+			bool open = valid; // this lane's expert can still be picked
+			float rank_logit = 0.f;
+			int rank_expert = 0;
 			for (int k = 0; k < a.n_active; ++k) {
-				sel_w[k] = expf(gate[sel_e[k]] - max_val) / wsum;
+				float bv = logit;
+				int bi = lane;
+				bool ok = open;
+#pragma unroll
+				for (int o = 32; o > 0; o >>= 1) {
+					const float v2 = __shfl_xor(bv, o);
+					const int i2 = __shfl_xor(bi, o);
+					const bool ok2 = __shfl_xor((int)ok, o) != 0;
+					if (ok2 && (!ok || v2 > bv || (v2 == bv && i2 < bi))) {
+						bv = v2, bi = i2, ok = true;
+					}
+				}
+				open = open && lane != bi;
+				if (lane == k) {
+					rank_logit = bv;
+					rank_expert = bi;
+				}
 			}
-			if (blockIdx.x == 0) {
-				for (int k = 0; k < a.n_active; ++k) {
-					a.moe_w[k] = sel_w[k];
-					a.moe_e[k] = sel_e[k];
+			const float ex = lane < a.n_active ? expf(rank_logit - top) : 0.f;
+			float denom = 0.f;
+			for (int k = 0; k < a.n_active; ++k) {
+				denom += __shfl(ex, k);
+			}
+			if (lane < a.n_active) {
+				sel_e[lane] = rank_expert;
+				sel_w[lane] = ex / denom;
+				if (blockIdx.x == 0) {
+					a.moe_w[lane] = ex / denom;
+					a.moe_e[lane] = rank_expert;
 				}
 			}
 		}

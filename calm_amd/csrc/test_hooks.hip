@@ -1,0 +1,253 @@
+// test_hooks.hip -- libcalm_hip_test.so: unit-level entry points for tests/ and tools/ (include/calm_hip_test.h).
+//
+// NOT part of the drop-in library: libcalm_hip.so exports the backend ABI of include/calm_hip.h and nothing else.  This
+// translation unit compiles the product's kernels and launch helpers a second time (it includes the product source, whose
+// helpers are file-local) and adds hooks that run single kernels on caller-provided buffers, reach into a prepared
+// transformer's KV cache through the fields struct Transformer shows, and a streaming-read micro-benchmark.
+#include "infer_hip.hip"
+
+#include "../../include/calm_hip_test.h"
+
+// ================================================================ test hooks ==================
+
+namespace {
+
+template <class F>
+void by_dbits(int dbits, F f) {
+	switch (dbits) {
+	case 16:
+		f(std::integral_constant<int, 16>());
+		break;
+	case 8:
+		f(std::integral_constant<int, 8>());
+		break;
+	case 4:
+		f(std::integral_constant<int, 4>());
+		break;
+	default:
+		CALM_REQUIRE(false, "dbits must be 4, 8 or 16");
+	}
+}
+
+} // namespace
+
+extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, float* out, int n, int d) {
+	init_hip();
+	CALM_REQUIRE(n % (128 / dbits) == 0 && d % 4 == 0, "n must be a multiple of 128/dbits and d of 4");
+	size_t wbytes = (size_t)n * d * dbits / 8;
+	void* dw = upload_hip((void*)w, wbytes);
+	float* dx = (float*)upload_hip((void*)x, n * sizeof(float));
+	float* dout = (float*)dev_alloc(d * sizeof(float));
+	HIP_CHECK(hipMemset(dout, 0, d * sizeof(float)));
+	by_dbits(dbits, [&](auto DBT) {
+		constexpr int DB = decltype(DBT)::value;
+		by_bool(stage_v4(n, 256), [&](auto V4) {
+			by_bool(rows_full<DB>(n), [&](auto FULL) {
+				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
+				allow_lds(k, lds_bytes<DB>(n));
+				hipLaunchKernelGGL(k, dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+			});
+		});
+	});
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, dout, d * sizeof(float));
+	free_hip(dw), free_hip(dx), free_hip(dout);
+}
+
+extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float* x, const float* nw, float* out, int n, int d, float eps, int ln) {
+	init_hip();
+	CALM_REQUIRE(n % (128 / dbits) == 0, "n must be a multiple of 128/dbits");
+	size_t wbytes = (size_t)n * d * dbits / 8;
+	void* dw = upload_hip((void*)w, wbytes);
+	float* dx = (float*)upload_hip((void*)x, n * sizeof(float));
+	float* dnw = (float*)upload_hip((void*)nw, n * sizeof(float));
+	float* dout = (float*)dev_alloc(d * sizeof(float));
+	by_dbits(dbits, [&](auto DBT) {
+		constexpr int DB = decltype(DBT)::value;
+		int ntasks = (d + Shape<DB>::NR - 1) / Shape<DB>::NR;
+		by_bool(stage_v4(n, 256), [&](auto V4) {
+			by_bool(rows_full<DB>(n), [&](auto FULL) {
+				auto k = k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
+				allow_lds(k, lds_bytes<DB>(n));
+				hipLaunchKernelGGL(k, dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+			});
+		});
+	});
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, dout, d * sizeof(float));
+	free_hip(dw), free_hip(dx), free_hip(dnw), free_hip(dout);
+}
+
+extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const uint16_t* vcache, float* out, int n_heads, int n_kv_heads, int head_dim,
+                                   int seq_len, int kv_len, int n_split) {
+	init_hip();
+	CALM_REQUIRE(head_dim % 8 == 0 && n_heads % n_kv_heads == 0 && n_split >= 1 && n_split <= MAX_SPLIT, "bad attention test shape");
+	int kv_dim = n_kv_heads * head_dim, q_dim = n_heads * head_dim;
+	// oracle layout [seq_len][kv_dim] -> backend layout [kv_head][seq_len][head_dim]
+	std::vector<uint16_t> kk((size_t)seq_len * kv_dim), vv((size_t)seq_len * kv_dim);
+	for (int t = 0; t < seq_len; ++t) {
+		for (int h = 0; h < n_kv_heads; ++h) {
+			for (int d = 0; d < head_dim; ++d) {
+				kk[((size_t)h * seq_len + t) * head_dim + d] = kcache[(size_t)t * kv_dim + h * head_dim + d];
+				vv[((size_t)h * seq_len + t) * head_dim + d] = vcache[(size_t)t * kv_dim + h * head_dim + d];
+			}
+		}
+	}
+	Ctx c;
+	c.head_dim = head_dim, c.n_heads = n_heads, c.n_kv_heads = n_kv_heads, c.kv_mul = n_heads / n_kv_heads, c.seq_len = seq_len;
+	c.kv_layer_bytes = kk.size() * 2;
+	c.kc = upload_hip(kk.data(), kk.size() * 2);
+	c.vc = upload_hip(vv.data(), vv.size() * 2);
+	c.q = (float*)upload_hip((void*)q, q_dim * sizeof(float));
+	c.att = (float*)dev_alloc(q_dim * sizeof(float));
+	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 2) * sizeof(float));
+	TokState ts = {};
+	ts.kv_len = kv_len;
+	c.ts = (TokState*)upload_hip(&ts, sizeof(ts));
+	c.lpr = 4;
+	while (c.lpr * 8 < head_dim) {
+		c.lpr *= 2;
+	}
+	launch_attn<16>(&c, 0, n_split);
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, c.att, q_dim * sizeof(float));
+	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts);
+}
+
+extern "C" int calm_hip_test_argmax(const float* logits, int n) {
+	init_hip();
+	float* dl = (float*)upload_hip((void*)logits, n * sizeof(float));
+	int* dn = (int*)dev_alloc(2 * sizeof(int));
+	HIP_CHECK(hipMemset(dn, 0, 2 * sizeof(int)));
+	hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, g_stream, dl, n, dn, (int*)nullptr, dn + 1);
+	HIP_CHECK(hipGetLastError());
+	int r = -2;
+	download_hip(&r, dn, sizeof(int));
+	free_hip(dl), free_hip(dn);
+	return r;
+}
+
+namespace {
+
+// the backend's private cache layout, from what struct Transformer shows: [layer][kv_head][seq_len][head_dim], 2 or 1 bytes
+struct KvGeom {
+	int n_kv_heads, head_dim, seq_len, kv_dim, ebytes;
+	size_t layer_bytes;
+};
+KvGeom kv_geom(struct Transformer* t) {
+	KvGeom g;
+	g.n_kv_heads = t->config.n_kv_heads, g.head_dim = t->config.head_dim, g.seq_len = t->config.seq_len;
+	g.kv_dim = g.n_kv_heads * g.head_dim;
+	g.ebytes = t->state.kvbits / 8;
+	g.layer_bytes = (size_t)g.kv_dim * g.seq_len * g.ebytes;
+	CALM_REQUIRE(t->state.key_cache && (g.ebytes == 1 || g.ebytes == 2), "transformer not prepared by the hip backend");
+	return g;
+}
+
+} // namespace
+
+extern "C" void calm_hip_read_kv(struct Transformer* t, int layer, int which, uint16_t* host) {
+	// back in the reference's [seq_len][kv_dim] order, as binary16 patterns: an fp8 cache's e5m2 bytes are widened
+	// (byte << 8 is the binary16 of the same value, src/infer.c:28-35)
+	const KvGeom g = kv_geom(t);
+	CALM_REQUIRE(layer >= 0 && layer < t->config.n_layers, "calm_hip_read_kv: no such layer");
+	std::vector<unsigned char> tmp(g.layer_bytes);
+	HIP_CHECK(hipDeviceSynchronize());
+	HIP_CHECK(hipMemcpy(tmp.data(), (char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, g.layer_bytes, hipMemcpyDeviceToHost));
+	for (int h = 0; h < g.n_kv_heads; ++h) {
+		for (int p = 0; p < g.seq_len; ++p) {
+			uint16_t* dst = host + (size_t)p * g.kv_dim + h * g.head_dim;
+			const size_t src = ((size_t)h * g.seq_len + p) * g.head_dim;
+			if (g.ebytes == 2) {
+				memcpy(dst, tmp.data() + src * 2, g.head_dim * 2);
+			} else {
+				for (int i = 0; i < g.head_dim; ++i) {
+					dst[i] = (uint16_t)((uint16_t)tmp[src + i] << 8);
+				}
+			}
+		}
+	}
+}
+
+extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, const uint16_t* host) {
+	// the inverse: a [seq_len][kv_dim] array of binary16 patterns into the backend's cache (an fp8 cache keeps the top byte:
+	// the caller passes values that are exact in e5m2) -- lets a test start deep inside a long context without decoding its
+	// way there
+	const KvGeom g = kv_geom(t);
+	CALM_REQUIRE(layer >= 0 && layer < t->config.n_layers, "calm_hip_write_kv: no such layer");
+	std::vector<unsigned char> tmp(g.layer_bytes);
+	for (int h = 0; h < g.n_kv_heads; ++h) {
+		for (int p = 0; p < g.seq_len; ++p) {
+			const uint16_t* src = host + (size_t)p * g.kv_dim + h * g.head_dim;
+			const size_t dst = ((size_t)h * g.seq_len + p) * g.head_dim;
+			if (g.ebytes == 2) {
+				memcpy(tmp.data() + dst * 2, src, g.head_dim * 2);
+			} else {
+				for (int i = 0; i < g.head_dim; ++i) {
+					tmp[dst + i] = (unsigned char)(src[i] >> 8);
+				}
+			}
+		}
+	}
+	HIP_CHECK(hipDeviceSynchronize());
+	HIP_CHECK(hipMemcpy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+}
+
+namespace {
+template <bool NT>
+__global__ __launch_bounds__(256) void k_membench(const u32x4* src, size_t n16, unsigned* sink) {
+	unsigned acc = 0;
+	size_t stride = (size_t)gridDim.x * 256 * 8;
+	for (size_t i = (size_t)blockIdx.x * 256 * 8 + threadIdx.x; i < n16; i += stride) {
+		u32x4 v[8];
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			size_t j = i + (size_t)u * 256;
+			if (j < n16) {
+				v[u] = NT ? __builtin_nontemporal_load(src + j) : src[j];
+			} else {
+				v[u] = (u32x4){0u, 0u, 0u, 0u};
+			}
+		}
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			acc += v[u][0] ^ v[u][1] ^ v[u][2] ^ v[u][3];
+		}
+	}
+	if (acc == 0x9e3779b9u) {
+		*sink = acc; // never true in practice; keeps the loads alive
+	}
+}
+} // namespace
+
+extern "C" double calm_hip_membench(size_t bytes, int nt, int iters) {
+	init_hip();
+	size_t n16 = bytes / 16;
+	u32x4* buf = (u32x4*)dev_alloc(n16 * 16);
+	unsigned* sink = (unsigned*)dev_alloc(4);
+	HIP_CHECK(hipMemset(buf, 0x5a, n16 * 16));
+	int blocks = g_ncu * 8;
+	auto go = [&]() {
+		if (nt) {
+			hipLaunchKernelGGL(k_membench<true>, dim3(blocks), dim3(256), 0, g_stream, buf, n16, sink);
+		} else {
+			hipLaunchKernelGGL(k_membench<false>, dim3(blocks), dim3(256), 0, g_stream, buf, n16, sink);
+		}
+	};
+	go();
+	hipEvent_t e0, e1;
+	HIP_CHECK(hipEventCreate(&e0));
+	HIP_CHECK(hipEventCreate(&e1));
+	HIP_CHECK(hipEventRecord(e0, g_stream));
+	for (int i = 0; i < iters; ++i) {
+		go();
+	}
+	HIP_CHECK(hipEventRecord(e1, g_stream));
+	HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	HIP_CHECK(hipEventDestroy(e0));
+	HIP_CHECK(hipEventDestroy(e1));
+	free_hip(buf), free_hip(sink);
+	return (double)n16 * 16 * iters / 1e9 / ((double)ms / 1e3);
+}

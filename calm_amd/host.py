@@ -24,10 +24,58 @@ from .calmfile import DBITS, CalmFile
 
 _LIB = None
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcalm_hip.so")
+TEST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcalm_hip_test.so")
+
+# include/calm_hip.h: the drop-in library
+EXPORTS = [
+    "init_hip", "upload_hip", "alloc_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
+    "free_hip", "download_hip", "decode_greedy_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip",
+]
+# include/calm_hip_test.h: libcalm_hip_test.so, tests and tools only
+TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_membench"]
 
 
-def load_lib() -> C.CDLL:
-    """dlopen libcalm_hip.so and declare the prototypes of include/calm_hip.h + calm_hip_test.h"""
+class _Libs:
+    """the drop-in library, plus -- looked up lazily, only when a test hook is asked for -- libcalm_hip_test.so"""
+
+    def __init__(self, product: C.CDLL):
+        self._product = product
+        self._test = None
+
+    def __getattr__(self, name):
+        if name.startswith("_"):
+            raise AttributeError(name)
+        try:
+            return getattr(self._product, name)
+        except AttributeError:
+            if name not in TEST_EXPORTS:
+                raise
+        if self._test is None:
+            if not os.path.exists(TEST_LIB_PATH):
+                raise RuntimeError(f"{TEST_LIB_PATH} is missing: run `python -m calm_amd.build`")
+            t = C.CDLL(TEST_LIB_PATH)
+            T = C.POINTER(abi.Transformer)
+            fp = C.POINTER(C.c_float)
+            protos = {
+                "calm_hip_test_matvec": (None, [C.c_int, C.c_void_p, fp, fp, C.c_int, C.c_int]),
+                "calm_hip_test_norm_matvec": (None, [C.c_int, C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int]),
+                "calm_hip_test_attn": (None, [fp, C.c_void_p, C.c_void_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+                "calm_hip_test_argmax": (C.c_int, [fp, C.c_int]),
+                "calm_hip_read_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
+                "calm_hip_write_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
+                "calm_hip_membench": (C.c_double, [C.c_size_t, C.c_int, C.c_int]),
+            }
+            for n, (res, args) in protos.items():
+                fn = getattr(t, n)
+                fn.restype = res
+                fn.argtypes = args
+            self._test = t
+        return getattr(self._test, name)
+
+
+def load_lib() -> "_Libs":
+    """dlopen libcalm_hip.so and declare the prototypes of include/calm_hip.h; the hooks of calm_hip_test.h resolve through the
+    same object from libcalm_hip_test.so"""
     global _LIB
     if _LIB is not None:
         return _LIB
@@ -39,6 +87,7 @@ def load_lib() -> C.CDLL:
     protos = {
         "init_hip": (None, []),
         "upload_hip": (C.c_void_p, [C.c_void_p, C.c_size_t]),
+        "alloc_hip": (C.c_void_p, [C.c_size_t]),
         "prepare_hip": (None, [T]),
         "forward_hip": (fp, [T, C.c_int, C.c_int, C.c_uint]),
         "perf_hip": (None, []),
@@ -47,33 +96,21 @@ def load_lib() -> C.CDLL:
         "calm_hip_configure": (C.c_int, [C.c_char_p, C.c_int]),
         "release_hip": (None, [T]),
         "free_hip": (None, [C.c_void_p]),
+        "download_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "decode_greedy_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
         "prefill_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int]),
         "prefill_logprobs_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int, fp]),
         "forward_stage_hip": (fp, [T, C.c_int, C.c_int, C.c_uint, C.c_uint]),
         "copy_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "perf_stage_hip": (C.c_double, [T, C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
-        "calm_hip_test_matvec": (None, [C.c_int, C.c_void_p, fp, fp, C.c_int, C.c_int]),
-        "calm_hip_test_norm_matvec": (None, [C.c_int, C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int]),
-        "calm_hip_test_attn": (None, [fp, C.c_void_p, C.c_void_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-        "calm_hip_test_argmax": (C.c_int, [fp, C.c_int]),
-        "download_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
-        "calm_hip_read_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
-        "calm_hip_membench": (C.c_double, [C.c_size_t, C.c_int, C.c_int]),
     }
     for name, (res, args) in protos.items():
         fn = getattr(lib, name)  # raises AttributeError if the library does not export it
         fn.restype = res
         fn.argtypes = args
-    _LIB = lib
-    return lib
+    _LIB = _Libs(lib)
+    return _LIB
 
-
-EXPORTS = [
-    "init_hip", "upload_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
-    "free_hip", "decode_greedy_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip", "calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn",
-    "calm_hip_test_argmax", "download_hip", "calm_hip_read_kv", "calm_hip_membench",
-]
 
 STAGES = ["qkv", "attn", "attn_out", "ffn_up", "ffn_down", "output"]
 
@@ -189,10 +226,12 @@ class HostModel:
 class HipBackend:
     """binds a HostModel to libcalm_hip.so exactly the way src/run.c:550-596 binds a GPU backend"""
 
-    def __init__(self, model: HostModel, kvbits: int = 16, stream=None):
+    def __init__(self, model: HostModel, kvbits: int = 16, stream=None, device_synth=None):
         """stream: optional iterable of (name, array) supplying the tensor bytes one at a time (buffers
         may be reused between items -- each is uploaded before the next is drawn); model.tensors then
-        only needs shape/dtype placeholders (calmfile.stub_tensors)"""
+        only needs shape/dtype placeholders (calmfile.stub_tensors).
+        device_synth: (spec, dtype, seed, n_layers) -- the synthetic model of calmfile.synth_stream_big with those
+        arguments, generated in device memory instead (calmfile.synth_device): nothing crosses PCIe but the small tensors"""
         self.lib = load_lib()
         if self.lib.calm_hip_device_count() <= 0:
             raise RuntimeError("no HIP device visible: the calm_amd backend has no CPU fallback")
@@ -200,11 +239,28 @@ class HipBackend:
         self.kvbits = kvbits
         self.t = abi.Transformer()
         self._dev: Dict[str, int] = {}
+        self._extra: List[int] = []
         self.lib.init_hip()
-        for name, a in (stream if stream is not None else model.tensors.items()):
-            if name.startswith("model."):  # run.c:556-558
-                a = np.ascontiguousarray(a)
-                self._dev[name] = self.lib.upload_hip(a.ctypes.data, a.nbytes)
+        if device_synth is not None:
+            from .calmfile import synth_device
+
+            self._keep_host = []  # host arrays must outlive the (synchronous) upload call only; kept until prepare anyway
+
+            def upload(a):
+                self._keep_host.append(a)
+                return self.lib.upload_hip(a.ctypes.data, a.nbytes)
+
+            for name, ptr in synth_device(*device_synth, alloc=self.lib.alloc_hip, upload=upload):
+                if name:
+                    self._dev[name] = ptr
+                else:
+                    self._extra.append(ptr)
+            self._keep_host = []
+        else:
+            for name, a in (stream if stream is not None else model.tensors.items()):
+                if name.startswith("model."):  # run.c:556-558
+                    a = np.ascontiguousarray(a)
+                    self._dev[name] = self.lib.upload_hip(a.ctypes.data, a.nbytes)
         model.fill_transformer(self.t, lambda n: self._dev[n], kvbits)
         self.lib.prepare_hip(C.byref(self.t))
         self.vocab = model.config.vocab_size
@@ -268,12 +324,20 @@ class HipBackend:
         self.lib.calm_hip_read_kv(C.byref(self.t), layer, which, out.ctypes.data)
         return out.view(np.float16)
 
+    def write_kv(self, layer: int, which: int, rows: np.ndarray) -> None:
+        """rows: (seq_len, kv_dim) float16 -> this layer's K (0) or V (1) cache (test hook)"""
+        rows = np.ascontiguousarray(rows, dtype=np.float16)
+        c = self.model.config
+        assert rows.shape == (c.seq_len, c.head_dim * c.n_kv_heads)
+        self.lib.calm_hip_write_kv(C.byref(self.t), layer, which, rows.ctypes.data)
+
     def close(self):
         if self.t is not None:
             self.lib.release_hip(C.byref(self.t))
-            for d in self._dev.values():
+            for d in list(self._dev.values()) + self._extra:
                 self.lib.free_hip(d)
             self._dev.clear()
+            self._extra = []
             self.t = None
 
     def __del__(self):

@@ -39,6 +39,12 @@ void init_hip(void);
  * synchronises; the mmap must stay mapped until then (it does: src/run.c:515,637). */
 void* upload_hip(void* host, size_t size);
 
+/* extension (no reference counterpart): `size` bytes of device memory with the slack behind it that this backend's kernels
+ * rely on (their 16-byte loads are unclamped at the end of a row or vector) -- for hosts that PRODUCE a tensor on the device
+ * instead of uploading it (tools/synth_fill_hip.hip: synthetic fixtures, an on-device gf4 quantiser).  A pointer from
+ * upload_hip or alloc_hip is what struct Weights may point at; plain hipMalloc'ed memory is not.  Freed with free_hip. */
+void* alloc_hip(size_t size);
+
 /* replaces prepare_cuda (src/run.c:23,580; src/infer.cu:73-131): allocates activations, the KV
  * cache (state.kvbits must already be 8 or 16) and the host-visible logits buffer, and snapshots
  * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits.
@@ -70,6 +76,10 @@ void release_hip(struct Transformer* transformer);
 
 /* frees one buffer returned by upload_hip */
 void free_hip(void* device);
+
+/* extension: copy `size` bytes of device memory (e.g. state.x, an uploaded tensor) back to the host, after draining the
+ * backend's stream */
+void download_hip(void* host, const void* device, size_t size);
 
 /* Greedy decode of n_steps tokens entirely on the device (argmax on the GPU, next token fed
  * back without a host round trip); equals n_steps calls of forward_hip + sample_argmax

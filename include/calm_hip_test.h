@@ -1,8 +1,9 @@
 /*
- * calm_hip_test.h -- unit-level entry points of libcalm_hip.so used by tests/ and bench.py.
+ * calm_hip_test.h -- unit-level entry points of libcalm_hip_test.so (calm_amd/csrc/test_hooks.hip), used by tests/ and
+ * tools/.  The drop-in library libcalm_hip.so does not export them.
  *
- * They run the SAME device kernels as forward_hip on caller-provided host buffers (uploaded
- * internally), so a parity failure of a whole decode step can be localised to one kernel.  The
+ * They run the SAME device kernels as forward_hip (the product source compiled a second time) on caller-provided host
+ * buffers (uploaded internally), so a parity failure of a whole decode step can be localised to one kernel.  The
  * reference has no counterpart (it has no tests); semantics cite src/infer.c.
  */
 #ifndef CALM_HIP_TEST_H
@@ -35,12 +36,13 @@ void calm_hip_test_attn(const float* q, const uint16_t* kcache, const uint16_t* 
 /* first index of the strict maximum (reference src/sampler.c:34-42), computed on the device */
 int calm_hip_test_argmax(const float* logits, int n);
 
-/* copy `size` bytes of device memory (e.g. t->state.x, a KV cache) back to the host */
-void download_hip(void* host, const void* device, size_t size);
-
-/* Re-layout helper: reads this backend's K or V cache of one layer into the oracle's
- * [seq_len][kv_dim] fp16 layout (host).  which: 0 = K, 1 = V.  Only for kvbits == 16. */
+/* Re-layout helper: reads the K or V cache of one layer of a transformer prepared by libcalm_hip.so into the oracle's
+ * [seq_len][kv_dim] layout (host) as binary16 patterns -- an fp8 cache's e5m2 bytes widened (byte << 8).  which: 0 = K, 1 = V. */
 void calm_hip_read_kv(struct Transformer* transformer, int layer, int which, uint16_t* host);
+
+/* the inverse: fills that layer's cache from a [seq_len][kv_dim] array of binary16 patterns (an fp8 cache keeps the top
+ * byte), so that a test can start deep inside a long context */
+void calm_hip_write_kv(struct Transformer* transformer, int layer, int which, const uint16_t* host);
 
 /* Streaming-read micro-benchmark: sums `bytes` of device memory with 16-byte loads
  * (nt != 0: non-temporal) `iters` times; returns GB/s.  bytes <= 128 MiB stays in the 256 MiB

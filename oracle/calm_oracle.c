@@ -96,9 +96,21 @@ uint16_t oracle_float_to_half(float f) {
 	return (uint16_t)(sign | (base + q)); /* a carry out of the mantissa correctly bumps the exponent */
 }
 
+/* the same mapping as a table, filled from the function above when the library is loaded: the hot loops below convert a
+ * binary16 per multiply-add, and 4096-8192-position attention tests spent minutes in the branches of the written-out form */
+static float h2f_table[65536];
+__attribute__((constructor)) static void h2f_init(void) {
+	for (uint32_t i = 0; i < 65536; ++i) {
+		h2f_table[i] = oracle_half_to_float((uint16_t)i);
+	}
+}
+static inline float h2f(uint16_t h) {
+	return h2f_table[h];
+}
+
 /* fp8 e5m2 is the top byte of the binary16 pattern (src/infer.c:28-35) */
 static inline float fp8_to_float(uint8_t v) {
-	return oracle_half_to_float((uint16_t)((uint16_t)v << 8));
+	return h2f((uint16_t)((uint16_t)v << 8));
 }
 
 /* binary32 -> fp8 e5m2, ONE round-to-nearest-even step from the fp32 value, saturating to the largest finite code
@@ -158,7 +170,7 @@ static inline float gf4_to_float(uint32_t word, int k) {
 float oracle_decode_weight(const void* w, int dbits, size_t idx) {
 	switch (dbits) {
 	case 16:
-		return oracle_half_to_float(((const uint16_t*)w)[idx]);
+		return h2f(((const uint16_t*)w)[idx]);
 	case 8:
 		return fp8_to_float(((const uint8_t*)w)[idx]);
 	case 4:
@@ -176,7 +188,7 @@ static float dot_fp16(const void* w, int n, int i, const float* x) {
 	const uint16_t* r = (const uint16_t*)w + (size_t)i * n;
 	float val = 0.0f;
 	for (int j = 0; j < n; j++) {
-		val += oracle_half_to_float(r[j]) * x[j];
+		val += h2f(r[j]) * x[j];
 	}
 	return val;
 }
@@ -269,7 +281,7 @@ void oracle_attn_head(float* xout, float* atth, const float* qh, const uint16_t*
 	for (int t = 0; t < kv_len; ++t) {
 		float score = 0.0f;
 		for (int j = 0; j < head_dim; ++j) {
-			score += qh[j] * oracle_half_to_float(kh[(size_t)t * kv_dim + j]);
+			score += qh[j] * h2f(kh[(size_t)t * kv_dim + j]);
 		}
 		score /= sqrtf((float)head_dim);
 		score_max = (score_max < score) ? score : score_max;
@@ -283,7 +295,7 @@ void oracle_attn_head(float* xout, float* atth, const float* qh, const uint16_t*
 	for (int j = 0; j < head_dim; ++j) {
 		float res = 0.f;
 		for (int t = 0; t < kv_len; ++t) {
-			res += (atth[t] / score_sum) * oracle_half_to_float(vh[(size_t)t * kv_dim + j]);
+			res += (atth[t] / score_sum) * h2f(vh[(size_t)t * kv_dim + j]);
 		}
 		xout[j] = res;
 	}
@@ -434,7 +446,7 @@ float* oracle_forward_stage(struct Transformer* t, int token, int pos, unsigned 
 		/* sink keys advance one position per step (fp16 round trip each time); :384-394 */
 		for (int r = 0; r < kv_sink; r++) {
 			for (int i = 0; i < kv_dim; i++) {
-				s->k[i] = oracle_half_to_float(kb[(size_t)r * kv_dim + i]);
+				s->k[i] = h2f(kb[(size_t)r * kv_dim + i]);
 			}
 			oracle_rope(s->k, kv_dim, p->head_dim, 1, p->rope_theta, p->rotary_dim);
 			for (int i = 0; i < kv_dim; i++) {

@@ -61,15 +61,25 @@ def _declared_functions(header):
 
 
 def test_library_exports_every_declared_symbol(hiplib):
-    """libcalm_hip.so loads (no GPU needed) and exports everything include/*.h declares"""
-    from calm_amd.host import EXPORTS
+    """libcalm_hip.so loads (no GPU needed) and exports exactly what include/calm_hip.h declares -- the drop-in library carries
+    no test hooks; those (include/calm_hip_test.h) live in libcalm_hip_test.so"""
+    import ctypes
 
-    declared = _declared_functions(os.path.join(ROOT, "include", "calm_hip.h")) | _declared_functions(os.path.join(ROOT, "include", "calm_hip_test.h"))
+    from calm_amd.host import EXPORTS, LIB_PATH, TEST_EXPORTS, TEST_LIB_PATH
+
+    declared = _declared_functions(os.path.join(ROOT, "include", "calm_hip.h"))
     declared.discard("forward")  # the function-pointer member of struct Transformer
-    assert declared, "no declarations parsed"
+    assert declared and declared == set(EXPORTS), (declared ^ set(EXPORTS))
+    product = ctypes.CDLL(LIB_PATH)
     for name in sorted(declared):
-        assert hasattr(hiplib, name), f"libcalm_hip.so does not export {name}"
-    assert declared == set(EXPORTS), (declared ^ set(EXPORTS))
+        assert hasattr(product, name), f"libcalm_hip.so does not export {name}"
+    hooks = _declared_functions(os.path.join(ROOT, "include", "calm_hip_test.h"))
+    assert hooks == set(TEST_EXPORTS), (hooks ^ set(TEST_EXPORTS))
+    testlib = ctypes.CDLL(TEST_LIB_PATH)
+    for name in sorted(hooks):
+        assert hasattr(testlib, name), f"libcalm_hip_test.so does not export {name}"
+        assert not hasattr(product, name), f"the drop-in library exports the test hook {name}"
+        assert hasattr(hiplib, name)
 
 
 def test_device_count_is_safe_without_gpu(hiplib):

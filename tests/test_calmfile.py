@@ -154,3 +154,29 @@ def test_reference_cli_decodes_a_streamed_file(tmp_path):
     r = subprocess.run([oracle.RUN_CPU, path, "-i", "ab", "-t", "0", "-n", "12"], env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "tok/s" in r.stderr
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/tools/convert.py"), reason="reference converter not present on this box")
+def test_quantize_gf4_is_the_reference_converters_gf4():
+    """calmfile.quantize_gf4 against the reference's own gf4() (tools/convert.py:247-268), EXECUTED from the reference tree:
+    bit-equal words on random tensors of several scales and on the edge rows (clamp at code 7, zero and overflowing scales)"""
+    import torch
+
+    src = open("/root/reference/tools/convert.py").read().splitlines()
+    a = next(i for i, l in enumerate(src) if l.startswith("def gf4(t):"))
+    b = next(i for i in range(a, len(src)) if src[i].strip() == "return gtr.cpu()")
+    ns = {"torch": torch}
+    exec("\n".join(src[a : b + 1]), ns)
+    rng = np.random.default_rng(11)
+    parts = [rng.standard_normal((512, 64)).astype(np.float32) * s for s in (0.02, 1.0, 300.0, 1e-6)]
+    edge = np.zeros((8, 64), dtype=np.float32)
+    edge[1, :8] = [1, -1, 0.5, -0.5, 0.25, -0.25, 0.874, -0.876]
+    edge[2, :8] = [-2, 2, 1, -1, 0.24, 0.26, 1.74, 1.76]
+    edge[3, :8] = 1e-30
+    edge[4, :8] = [70000, 1, 2, 3, 4, 5, 6, 7]
+    w = np.concatenate(parts + [edge])
+    want = ns["gf4"](torch.from_numpy(w.copy())).numpy().astype(np.int32)
+    got = cf.quantize_gf4(w)
+    assert got.shape == want.shape
+    bad = np.nonzero(got != want)
+    assert bad[0].size == 0, (bad[0][:5], bad[1][:5])

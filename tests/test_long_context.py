@@ -1,0 +1,189 @@
+"""Long contexts and the fp8 KV cache, whole decode steps against the CPU checker.
+
+* RoPE at thousands of radians, the split-KV attention kernels (k_attn_gqa + k_attn_merge) at their real split counts, the
+  rolling buffer and the attention sinks (src/infer.c:329-332,383-394) at the REAL context sizes: a model with Mistral-7B's
+  attention geometry (dim 4096, 32 query / 8 kv heads of 128, rope_theta 1e6; FFN and vocabulary cut down so the CPU side
+  stays affordable) is driven token by token to pos = seq_len + 64, at seq_len = 4096 with the fp16 cache and at
+  seq_len = 8192 with the fp8 cache (what src/run.c:536-540 selects beyond 4096), logits compared at checkpoints on the way.
+* kvbits = 8 has no counterpart in the reference's CPU backend (src/infer.c:161); its CUDA backend stores K/V rows (and the
+  re-rotated sink keys) as `__nv_fp8_e5m2(float)` (src/infer.cu:473-482,150-180).  The oracle's kvbits = 8 mode restates
+  exactly that storage on top of the CPU arithmetic (oracle/calm_oracle.c: kv_store, oracle_float_to_e5m2 -- pinned against
+  torch.float8_e5m2 in tests/test_oracle.py), and the HIP backend answers to it: same logits tolerance as everywhere else,
+  cache bytes equal except where an fp32 sum that differs in its last bits straddles an e5m2 rounding boundary.
+"""
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from calm_amd import abi
+from calm_amd import calmfile as cf
+from calm_amd.host import HipBackend, HostModel
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_TOL = 1e-3
+FF = abi.FF_UPDATE_KV_ONLY
+
+
+@pytest.mark.parametrize("case", ["tiny_fp16", "tiny_fp8", "bias_tied_gf4", "sink_fp16", "hd256_sink_fp8", "mqa_hd96_fp16", "moe_fp8"])
+def test_fp8_kv_cache_matches_the_oracle(hiplib, case):
+    """golden models with an fp8 (e5m2) KV cache on both sides, teacher-forced along the golden token stream -- through the
+    rolling buffer and the sink re-rotation where the model has them: logits within LOGIT_TOL at every position, and the
+    cached K / V rows byte-equal up to rare one-code differences"""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    o = oracle.OracleBackend(model, kvbits=8)
+    b = HipBackend(model, kvbits=8)
+    try:
+        worst = 0.0
+        for pos, tok in enumerate(toks):
+            lo = o.forward(tok, pos, 0)
+            lg = b.forward(tok, pos, 0)
+            worst = max(worst, rel_err(lg, lo))
+        assert worst < LOGIT_TOL, worst
+        c = model.config
+        n = min(len(toks), c.seq_len)
+        for layer in range(c.n_layers):
+            for which in (0, 1):
+                want = o.kv(layer, which)[:n].view(np.uint16) >> 8  # the e5m2 codes
+                got = b.read_kv(layer, which)[:n].view(np.uint16) >> 8
+                diff = want != got
+                # a differing code must be the neighbouring one (same sign, magnitude code +-1), and rare
+                assert diff.mean() < 2e-3, (layer, which, diff.mean())
+                if diff.any():
+                    assert (np.abs(want[diff].astype(int) - got[diff].astype(int)) <= 1).all()
+        # the fp8 cache really is in use: its rows carry 2-bit mantissas
+        assert (b.read_kv(0, 0)[:n].view(np.uint16) & 0xFF).max() == 0
+    finally:
+        b.close()
+        o.close()
+
+
+def attention_true_spec(seq_len):
+    """Mistral-7B's attention geometry and RoPE base; 2 layers; FFN width and vocabulary reduced (the CPU checker walks every
+    weight once per token, 4-8 thousand tokens).  hidden_dim stays >= dim: the reference's CPU path parks wo's dim-sized
+    result in its hidden_dim-sized buffer (src/infer.c:152-153,410) and overruns its heap on narrower FFNs."""
+    m = cf.SPECS["mistral-7b"]
+    return dataclasses.replace(m, name="mistral-attn", hidden_dim=4096, vocab_size=4096, n_layers=2, max_seq_len=seq_len)
+
+
+def drive(hip, ref, seq_len, n_past, seed):
+    """teacher-force a random token stream through both backends from position 0 to pos = seq_len + n_past; logits at
+    checkpoints.  -> (worst relative error, position of the worst, number of checkpoints).  Minutes of CPU: CALM_TEST_SLOW=1"""
+    rng = np.random.default_rng(seed)
+    vocab = hip.model.config.vocab_size
+    toks = rng.integers(0, vocab, size=seq_len + n_past)
+    check = {0, 1, 63, 383, 384, 385, 512, 1000, 2047, 2048, seq_len // 2 + 1, seq_len - 130, seq_len - 2, seq_len - 1}
+    check |= set(range(seq_len, seq_len + n_past, 7)) | {seq_len + 1, seq_len + 2, seq_len + n_past - 1}
+    worst, where = 0.0, -1
+    for pos, tok in enumerate(toks):
+        tok = int(tok)
+        if pos in check:
+            lr = ref.forward(tok, pos, 0)
+            lg = hip.forward(tok, pos, 0)
+            assert np.isfinite(lg).all(), pos
+            e = rel_err(lg, lr)
+            if e > worst:
+                worst, where = e, pos
+        else:
+            ref.forward(tok, pos, FF)
+            hip.forward(tok, pos, FF)
+    return worst, where, len([p for p in check if p < len(toks)])
+
+
+def prefill_caches_with_noise(hip, ref, kvbits, seed):
+    """the same random K / V rows (unit scale, exact in the cache's format) into every layer's cache of both backends: what a
+    long decode would have left there as far as the attention kernels are concerned, without the minutes of CPU it takes"""
+    rng = np.random.default_rng(seed)
+    c = hip.model.config
+    kv_dim = c.head_dim * c.n_kv_heads
+    for layer in range(c.n_layers):
+        for which in (0, 1):
+            rows = rng.standard_normal((c.seq_len, kv_dim)).astype(np.float32).astype(np.float16)
+            if kvbits == 8:
+                rows = (rows.view(np.uint16) & np.uint16(0xFF00)).view(np.float16)  # truncated to e5m2 patterns
+            ref.kv(layer, which)[:] = rows
+            hip.write_kv(layer, which, rows)
+
+
+def finish_context(hip, ref, seq_len, n_before, n_past, seed):
+    """decode positions seq_len - n_before .. seq_len + n_past - 1 on top of pre-filled caches, every logits vector compared"""
+    rng = np.random.default_rng(seed)
+    vocab = hip.model.config.vocab_size
+    worst, where = 0.0, -1
+    for pos in range(seq_len - n_before, seq_len + n_past):
+        tok = int(rng.integers(0, vocab))
+        lr = ref.forward(tok, pos, 0)
+        lg = hip.forward(tok, pos, 0)
+        assert np.isfinite(lg).all(), pos
+        e = rel_err(lg, lr)
+        if e > worst:
+            worst, where = e, pos
+    return worst, where, n_before + n_past
+
+
+@pytest.fixture
+def more_cpu_threads():
+    import ctypes
+    import os
+
+    try:
+        gomp = ctypes.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(max(8, min(32, (os.cpu_count() or 16) // 2)))
+        yield
+        gomp.omp_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "8")))
+    except OSError:
+        yield
+
+
+SLOW = os.environ.get("CALM_TEST_SLOW", "0") not in ("", "0")
+
+
+def test_fp16_cache_to_the_end_of_a_4096_context_and_past_it(hiplib, more_cpu_threads):
+    """seq_len = 4096, fp16 cache, against the reference CPU path itself (oracle/_ref) when it is there: RoPE angles up to
+    4127 rad, attention over 4000-4096 cached rows in 32 splits, then the wrapped buffer with its two sink keys advancing one
+    RoPE step per token.  The cache below position 4056 is pre-filled (CALM_TEST_SLOW=1: decoded from position 0 instead --
+    4160 steps on both sides; measured once per round, profiles/)."""
+    seq_len = 4096
+    spec = attention_true_spec(seq_len)
+    tensors, md = cf.synth_model_big(spec, "fp8", 21)
+    model = HostModel(tensors, md, context=seq_len)
+    ref = oracle.RefBackend(model) if oracle.have_ref() else oracle.OracleBackend(model)
+    hip = HipBackend(model)
+    try:
+        if SLOW:
+            worst, where, n = drive(hip, ref, seq_len, 64, seed=5)
+        else:
+            prefill_caches_with_noise(hip, ref, 16, seed=5)
+            worst, where, n = finish_context(hip, ref, seq_len, 40, 32, seed=5)
+        print(f"fp16 cache, seq_len {seq_len}: worst max|d|/max|logit| = {worst:.3e} at position {where} over {n} compared positions")
+        assert worst < LOGIT_TOL, (worst, where)
+    finally:
+        hip.close()
+        ref.close()
+
+
+def test_fp8_cache_to_the_end_of_an_8192_context_and_past_it(hiplib, more_cpu_threads):
+    """seq_len = 8192 with the fp8 (e5m2) cache on both sides -- the configuration src/run.c:536-540 picks for contexts beyond
+    4096 on a GPU backend; same protocol as above"""
+    seq_len = 8192
+    spec = attention_true_spec(seq_len)
+    tensors, md = cf.synth_model_big(spec, "fp8", 22)
+    model = HostModel(tensors, md, context=seq_len)
+    ref = oracle.OracleBackend(model, kvbits=8)
+    hip = HipBackend(model, kvbits=8)
+    try:
+        if SLOW:
+            worst, where, n = drive(hip, ref, seq_len, 64, seed=6)
+        else:
+            prefill_caches_with_noise(hip, ref, 8, seed=6)
+            worst, where, n = finish_context(hip, ref, seq_len, 40, 32, seed=6)
+        print(f"fp8 cache, seq_len {seq_len}: worst max|d|/max|logit| = {worst:.3e} at position {where} over {n} compared positions")
+        assert worst < LOGIT_TOL, (worst, where)
+    finally:
+        hip.close()
+        ref.close()

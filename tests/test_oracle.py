@@ -128,3 +128,33 @@ def test_oracle_matches_reference_at_full_width(name, dtype):
         assert oracle.argmax(lo) == int(np.argmax(lr)) or np.partition(lr, -2)[-1] - np.partition(lr, -2)[-2] < 1e-3
         tok = int(np.argmax(lr))
     o.close()
+
+
+def test_oracle_e5m2_rounding_is_torchs_float8_e5m2():
+    """oracle_float_to_e5m2 (the fp8 KV cache's store, `__nv_fp8_e5m2(float)` in the reference's CUDA backend) against torch's
+    float8_e5m2 conversion -- one round-to-nearest-even step from fp32 -- over the finite range, subnormals and ties included;
+    beyond it the oracle saturates to the largest finite code as the CUDA type does (torch goes to infinity there)"""
+    import torch
+
+    L = oracle.lib()
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.standard_normal(20000).astype(np.float32) * s for s in (1e-6, 1e-4, 1e-2, 1, 100, 3e4)]
+                       + [np.array([0, -0.0, 2.0**-17, 2.0**-17 * 1.0001, 2.0**-16, 1.5 * 2.0**-16, 57344, 61439, -61439, 1.125, 1.375, -1.125], dtype=np.float32)])
+    want = torch.from_numpy(x).to(torch.float8_e5m2).view(torch.uint8).numpy()
+    got = np.array([L.oracle_float_to_e5m2(float(v)) for v in x], dtype=np.uint8)
+    fin = np.abs(x) < 61440
+    assert np.array_equal(want[fin], got[fin])
+    assert [L.oracle_float_to_e5m2(v) for v in (61440.0, 1e9, float("inf"), float("-inf"))] == [0x7B, 0x7B, 0x7B, 0xFB]
+    assert L.oracle_float_to_e5m2(float("nan")) & 0x7F == 0x7F
+
+
+def test_oracle_fp8_kv_mode_stays_close_to_the_fp16_cache_and_stores_e5m2():
+    model, z = load_golden("sink_fp16")
+    toks = [int(t) for t in z["tokens"]]
+    o16, o8 = oracle.OracleBackend(model), oracle.OracleBackend(model, kvbits=8)
+    worst = 0.0
+    for pos, tok in enumerate(toks):
+        worst = max(worst, rel_err(o8.forward(tok, pos, 0), o16.forward(tok, pos, 0)))
+    assert 0 < worst < 0.2  # 2-bit mantissas in K and V: percent-level drift
+    assert (o8.kv(0, 0).view(np.uint16) & 0xFF).max() == 0 and (o16.kv(0, 0).view(np.uint16) & 0xFF).max() > 0
+    o16.close(), o8.close()

@@ -1,0 +1,64 @@
+"""The profiling surface: perf_hip's per-stage breakdown -- the table the reference prints from
+perf_cuda (src/infer.cu:761-801), reached through the reference's own CLI -- and the per-kernel algorithmic-byte account
+(CALM_HIP_PROF_JSON) that tools/hipprof.sh joins with the rocprofv3 kernel trace, the way the reference's PROF_TOKEN feeds
+tools/cudaprof.cu:85-100."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from calm_amd import calmfile as cf
+from calm_amd.host import STAGES, HipBackend, HostModel
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+ROW = re.compile(r"\[(\d+)\]\s+(\w+):\s+([\d.]+)%;\s+([\d.]+) usec/run,\s+([\d.]+) GB/s")
+
+
+@pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip (reference CLI linked to libcalm_hip.so) not built")
+def test_perf_hip_breakdown_through_the_reference_cli(hiplib, tmp_path):
+    path = str(tmp_path / "mistral_l4_fp8.calm")
+    spec, L, n = cf.SPECS["mistral-7b"], 4, 48
+    cf.write_synth_big(path, spec, "fp8", seed=1, n_layers=L)
+    acct = str(tmp_path / "kernel_bytes.json")
+    env = dict(os.environ, CALM_HIP_PROF="1", CUDA_INJECTION64_PATH="1", CALM_HIP_PROF_JSON=acct)  # run.c:630 gates perf_*() on the injection variable
+    env.pop("CALM_CPU", None)
+    r = subprocess.run([oracle.RUN_HIP, path, "-i", "abc", "-t", "0", "-n", str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "forward_hip breakdown" in r.stdout
+    rows = {m.group(2): (float(m.group(3)), float(m.group(4)), float(m.group(5))) for m in ROW.finditer(r.stdout)}
+    assert set(rows) == {"matmul_qkv", "attn", "matmul_attn", "matmul_ffn_up", "matmul_ffn_down", "output"}, r.stdout[-1500:]
+    assert abs(sum(v[0] for v in rows.values()) - 100.0) < 0.5
+    # the same stages timed back to back by perf_stage_hip on the same file
+    model = HostModel.from_file(path)
+    b = HipBackend(model)
+    try:
+        for pos in range(8):
+            b.forward(3 + pos, pos, 0)
+        names = {"qkv": "matmul_qkv", "attn_out": "matmul_attn", "ffn_up": "matmul_ffn_up", "ffn_down": "matmul_ffn_down", "output": "output"}
+        for i, st in enumerate(STAGES):
+            if st not in names:
+                continue
+            us, nbytes = b.stage_us(i, 8 if st != "output" else 2)
+            gbps = nbytes / us / 1e3
+            table = rows[names[st]][2]
+            assert abs(table - gbps) <= 0.2 * gbps, (st, table, gbps)
+    finally:
+        b.close()
+    # the byte account: launches and bytes of every decode kernel of the run (warm-up step + n - 1 decode steps + prompt steps)
+    a = json.load(open(acct))
+    assert set(a) >= {"k_qkv", "k_attn", "k_attn_out", "k_ffn_up", "k_ffn_down", "k_output"}
+    per = lambda k: a[k]["algorithmic_bytes"] / a[k]["launches"]
+    assert per("k_ffn_up") == 2 * spec.hidden_dim * spec.dim and per("k_ffn_down") == spec.hidden_dim * spec.dim
+    assert per("k_qkv") == (spec.q_dim + 2 * spec.kv_dim) * spec.dim and per("k_attn_out") == spec.q_dim * spec.dim
+    assert per("k_output") == spec.vocab_size * spec.dim
+    assert a["k_qkv"]["launches"] == a["k_ffn_up"]["launches"] and a["k_qkv"]["launches"] % L == 0
+    steps = a["k_qkv"]["launches"] // L
+    # n_bandwidth of the reference's accounting (src/run.c:523-532) is what one step's weight kernels add up to
+    weights = sum(per(k) for k in ("k_qkv", "k_attn_out", "k_ffn_up", "k_ffn_down")) * L + per("k_output")
+    assert weights == model.accounting()[2] - sum(model.tensors[nm].nbytes for nm in model.tensors if nm.endswith("norm.weight"))
+    assert steps >= n - 1

@@ -8,6 +8,9 @@
 * PMC pass (rocprofv3 --pmc FETCH_SIZE --kernel-trace): average FETCH_SIZE per launch per kernel, converted
   to bytes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE is in KiB and reports exactly
   half of a wide coalesced stream on gfx950: bytes = FETCH_SIZE * 1024 * 2).
+* --bytes <json>: the library's own account of the ALGORITHMIC bytes each kernel was launched over (CALM_HIP_PROF_JSON, the
+  analogue of the reference's PROF_TOKEN kernel argument, src/infer.cu:22,679) -- joined by kernel name into a GB/s column,
+  the way tools/cudaprof.cu:85-100 turns its tokens into "BW (GB/s)"; with a PMC pass also the HBM bytes actually fetched.
 Writes profiles/<tag>_kernel_stats.md and profiles/<tag>_pmc.json.
 """
 import csv
@@ -57,21 +60,38 @@ def pmc_fetch(d):
     return out
 
 
+def base(name):
+    return name.split("<")[0]
+
+
 def main():
-    args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith("--") and sys.argv[i] not in ("--tag", "--workload")]
+    flags = ("--tag", "--workload", "--bytes")
+    args = [a for i, a in enumerate(sys.argv[1:]) if not a.startswith("--") and sys.argv[i] not in flags]
     tag = sys.argv[sys.argv.index("--tag") + 1] if "--tag" in sys.argv else "r01"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     durs = kernel_durations(args[0])
     total = sum(sum(v) for v in durs.values())
-    lines = [f"# rocprofv3 --kernel-trace summary ({tag}); durations in microseconds", "",
-             "| kernel | calls | total us | % | avg us | median us | min us |", "|---|---|---|---|---|---|---|"]
+    alg = json.load(open(sys.argv[sys.argv.index("--bytes") + 1])) if "--bytes" in sys.argv else {}
+    fetch = pmc_fetch(args[1]) if len(args) > 1 else {}
+    fetch_by_base = defaultdict(list)
+    for k, v in fetch.items():
+        fetch_by_base[base(k)].extend(v)
+    lines = [f"# rocprofv3 --kernel-trace summary ({tag}); durations in microseconds" + ("; algorithmic bytes from the library (CALM_HIP_PROF_JSON)" if alg else ""), "",
+             "| kernel | calls | total us | % | avg us | median us | min us | algorithmic MB/launch | GB/s (algorithmic / avg) | HBM MB/launch (PMC, x2) | fetched / algorithmic |",
+             "|---|---|---|---|---|---|---|---|---|---|---|"]
     for k, v in sorted(durs.items(), key=lambda kv: -sum(kv[1])):
-        lines.append(f"| `{k}` | {len(v)} | {sum(v):.0f} | {100*sum(v)/total:.1f} | {sum(v)/len(v):.2f} | {statistics.median(v):.2f} | {min(v):.2f} |")
+        a = alg.get(base(k))
+        mb = a["algorithmic_bytes"] / a["launches"] / 1e6 if a and a["launches"] else None
+        avg = sum(v) / len(v)
+        f = fetch_by_base.get(base(k))
+        fmb = sum(f) / len(f) * 1024 * 2 / 1e6 if f else None
+        lines.append(f"| `{k}` | {len(v)} | {sum(v):.0f} | {100*sum(v)/total:.1f} | {avg:.2f} | {statistics.median(v):.2f} | {min(v):.2f} | "
+                     + (f"{mb:.2f}" if mb is not None else "") + " | " + (f"{mb / avg * 1e3:.0f}" if mb else "") + " | " + (f"{fmb:.2f}" if fmb is not None else "") + " | "
+                     + (f"{fmb / mb:.3f}" if fmb is not None and mb else "") + " |")
     open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
-    if len(args) > 1:
-        fetch = pmc_fetch(args[1])
+    if fetch:
         res = {}
         for k, v in fetch.items():
             res[k] = {"launches": len(v), "FETCH_SIZE_KiB_avg": sum(v) / len(v), "hbm_read_bytes_per_launch_corrected": sum(v) / len(v) * 1024 * 2}
