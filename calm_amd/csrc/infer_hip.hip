@@ -558,8 +558,9 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 	if (g_prof) {
 		// events: per layer [qkv, attn, attn_out, ffn_up, ffn_down], then [end-of-layers, after output].  An event between two
-		// kernels costs the queue a marker packet; what a pair of events costs with NOTHING between them is measured once and
-		// taken off every span (without it the 6-8 us stages read 25-30 % slow against perf_stage_hip's back-to-back launches)
+		// kernels costs the queue a marker packet.  What that adds to a chain of dependent kernels is measured once -- 32 empty
+		// kernels with an event after each against the same 32 with events at the two ends only -- and taken off every span
+		// (without it the 6-8 us stages read ~25 % slow against perf_stage_hip's back-to-back launches)
 		static double marker_us = -1;
 		if (marker_us < 0) {
 			const int n = 32;
@@ -568,13 +569,22 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 				HIP_CHECK(hipEventCreate(&e));
 				c->events.push_back(e);
 			}
-			for (int i = 0; i <= n; ++i) {
-				HIP_CHECK(hipEventRecord(c->events[i], g_stream));
-			}
-			HIP_CHECK(hipStreamSynchronize(g_stream));
-			float ms = 0;
-			HIP_CHECK(hipEventElapsedTime(&ms, c->events[0], c->events[n]));
-			marker_us = ms * 1e3 / n;
+			auto chain = [&](bool between) {
+				HIP_CHECK(hipEventRecord(c->events[0], g_stream));
+				for (int i = 1; i <= n; ++i) {
+					hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, g_stream);
+					if (between || i == n) {
+						HIP_CHECK(hipEventRecord(c->events[between ? i : 1], g_stream));
+					}
+				}
+				HIP_CHECK(hipStreamSynchronize(g_stream));
+				float ms = 0;
+				HIP_CHECK(hipEventElapsedTime(&ms, c->events[0], c->events[between ? n : 1]));
+				return (double)ms * 1e3;
+			};
+			chain(true); // warm
+			const double with = chain(true), without = chain(false);
+			marker_us = with > without ? (with - without) / n : 0.0;
 		}
 		dispatch_step(c, sp, true);
 		HIP_CHECK(hipStreamSynchronize(g_stream));
@@ -1308,3 +1318,31 @@ extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, ui
 	HIP_CHECK(hipEventDestroy(e1));
 	return (double)ms * 1e3 / ((double)iters * c->n_layers);
 }
+
+#ifdef CALM_TIMELINE
+// tools/timeline.py only (a separate build with -DCALM_TIMELINE): arm / read the per-wave stamps of kernels.hip.h
+extern "C" void calm_tl_arm(int waves) {
+	init_hip();
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	static unsigned long long* buf = nullptr;
+	static size_t cap = 0;
+	const size_t need = (size_t)waves * 8 * sizeof(unsigned long long);
+	if (need > cap) {
+		if (buf) {
+			HIP_CHECK(hipFree(buf));
+		}
+		HIP_CHECK(hipMalloc(&buf, need));
+		cap = need;
+	}
+	HIP_CHECK(hipMemset(buf, 0, need));
+	unsigned uw = (unsigned)waves;
+	HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(calm_tl_buf), &buf, sizeof(buf)));
+	HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(calm_tl_waves), &uw, sizeof(uw)));
+}
+extern "C" void calm_tl_read(unsigned long long* host, int waves) {
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	unsigned long long* buf = nullptr;
+	HIP_CHECK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(calm_tl_buf), sizeof(buf)));
+	HIP_CHECK(hipMemcpy(host, buf, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+}
+#endif

@@ -23,7 +23,7 @@ from . import abi
 from .calmfile import DBITS, CalmFile
 
 _LIB = None
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcalm_hip.so")
+LIB_PATH = os.environ.get("CALM_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcalm_hip.so")  # (CALM_HIP_LIB: tools/timeline.py's instrumented build)
 TEST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcalm_hip_test.so")
 
 # include/calm_hip.h: the drop-in library

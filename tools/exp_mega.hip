@@ -18,6 +18,7 @@
 //
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_mega.so tools/exp_mega.hip
 #include "exp_overlap.hip"
+#include <algorithm>
 
 constexpr int MG_MAXP = 136;
 constexpr int MG_MAXT = 16;   // tasks of one phase per streamer
@@ -590,6 +591,137 @@ extern "C" void exp_burst(int depth, int ns) {
 	}
 	fflush(stdout);
 	CK(hipFree(w));
+	CK(hipFree(out));
+	CK(hipFree(sink));
+}
+
+// ---- start-up probe: what delays a streaming kernel's FIRST tile?  Every wave of a 256-thread workgroup (GRIDxWPC) does what the
+// product's row engine does at launch, in variants:  mode 0: tile loads only;  mode 1: first the loads of a shared 16 KiB vector
+// (+ 16 KiB of "norm weights"), then the tile, then the vector is reduced block-wide and written to LDS (two barriers) before the
+// tile is touched;  mode 2: as 1, with a second tile issued before the prologue (the product's order until round 2).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_startup(const void* w, const float* x, unsigned long long* out, unsigned* sink) {
+	__shared__ float xs[8192];
+	__shared__ float red[4];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const size_t wid = (size_t)blockIdx.x * 4 + wave;
+	const unsigned long long t0 = wall_clock64();
+	float4 xv[4], gv[4];
+	if (MODE >= 1) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			xv[i] = ((const float4*)x)[threadIdx.x + i * 256];
+			gv[i] = ((const float4*)x)[4096 + threadIdx.x + i * 256];
+		}
+	}
+	u32x4 tile[2][8];
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {
+		tile[0][u] = __builtin_nontemporal_load((gptr16)w + wid * 1024 + u * 64 + lane);
+	}
+	if (MODE == 2) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			tile[1][u] = __builtin_nontemporal_load((gptr16)w + wid * 1024 + 512 + u * 64 + lane);
+		}
+	}
+	const unsigned long long t1 = wall_clock64(); // loads issued
+	unsigned long long t2 = t1, t3 = t1;
+	float scale = 1.f;
+	if (MODE >= 1) {
+		float ss = 0.f;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			ss += xv[i].x * xv[i].x + xv[i].y * xv[i].y + xv[i].z * xv[i].z + xv[i].w * xv[i].w;
+		}
+		asm volatile("" ::"v"(ss));
+		t2 = wall_clock64(); // vector landed
+		ss = wave_sum(ss);
+		if (lane == 0) {
+			red[wave] = ss;
+		}
+		__syncthreads();
+		scale = 1.0f / sqrtf((red[0] + red[1] + red[2] + red[3]) / 4096.f + 1e-5f);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			((float4*)xs)[threadIdx.x + i * 256] = make_float4(xv[i].x * scale * gv[i].x, xv[i].y * scale * gv[i].y, xv[i].z * scale * gv[i].z, xv[i].w * scale * gv[i].w);
+		}
+		__syncthreads();
+		t3 = wall_clock64(); // image built
+	}
+	unsigned acc = 0;
+#pragma unroll
+	for (int u = 0; u < 8; ++u) {
+		acc += tile[0][u][0] ^ tile[0][u][3];
+	}
+	asm volatile("" ::"v"(acc));
+	const unsigned long long t4 = wall_clock64(); // first tile landed
+	if (MODE == 2) {
+#pragma unroll
+		for (int u = 0; u < 8; ++u) {
+			acc += tile[1][u][1];
+		}
+	}
+	if (acc == 0x12345678u || scale == 12345.f) {
+		*sink = acc + (unsigned)xs[lane];
+	}
+	if (lane == 0 && wid < 4096) {
+		unsigned long long* o = out + wid * 8;
+		o[0] = t0, o[1] = t1, o[2] = t2, o[3] = t3, o[4] = t4;
+	}
+}
+
+extern "C" void exp_startup(int mode, int grid) {
+	const size_t bytes = (size_t)grid * 4 * 16384;
+	void* w;
+	float* x;
+	CK(hipMalloc(&w, bytes * 4 + 65536));
+	CK(hipMemset(w, 0x5a, bytes * 4 + 65536));
+	CK(hipMalloc(&x, 65536 + 65536));
+	CK(hipMemset(x, 0, 65536 + 65536));
+	unsigned long long* out;
+	unsigned* sink;
+	CK(hipMalloc(&out, 4096 * 8 * 8));
+	CK(hipMalloc(&sink, 4));
+	std::vector<unsigned long long> h(4096 * 8);
+	double acc[4] = {0, 0, 0, 0}, mx[4] = {0, 0, 0, 0};
+	const int reps = 4;
+	for (int rep = 0; rep < reps; ++rep) {
+		const void* wr = (const char*)w + rep * bytes;
+		CK(hipMemset(out, 0, 4096 * 8 * 8));
+		CK(hipMemset(x, 0x3c, 65536)); // the vector is freshly written, like a producer kernel's output
+		CK(hipDeviceSynchronize());
+		if (mode == 0) {
+			hipLaunchKernelGGL(k_startup<0>, dim3(grid), dim3(256), 0, 0, wr, x, out, sink);
+		} else if (mode == 1) {
+			hipLaunchKernelGGL(k_startup<1>, dim3(grid), dim3(256), 0, 0, wr, x, out, sink);
+		} else {
+			hipLaunchKernelGGL(k_startup<2>, dim3(grid), dim3(256), 0, 0, wr, x, out, sink);
+		}
+		CK(hipDeviceSynchronize());
+		CK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
+		unsigned long long t0 = ~0ull;
+		const int nw = grid * 4 < 4096 ? grid * 4 : 4096;
+		for (int i = 0; i < nw; ++i) {
+			t0 = h[i * 8] < t0 ? h[i * 8] : t0;
+		}
+		std::vector<double> v[4];
+		for (int i = 0; i < nw; ++i) {
+			for (int k = 0; k < 4; ++k) {
+				v[k].push_back((double)(h[i * 8 + 1 + k] - t0) / 100);
+			}
+		}
+		for (int k = 0; k < 4; ++k) {
+			std::sort(v[k].begin(), v[k].end());
+			acc[k] += v[k][v[k].size() / 2];
+			mx[k] += v[k].back();
+		}
+	}
+	printf("startup mode %d, %d workgroups x 4 waves (%.1f MB per tile round): loads issued p50 %.2f max %.2f | vector landed %.2f / %.2f | image built %.2f / %.2f | first tile landed %.2f / %.2f us\n",
+	       mode, grid, (double)grid * 4 * 8192 / 1e6, acc[0] / reps, mx[0] / reps, acc[1] / reps, mx[1] / reps, acc[2] / reps, mx[2] / reps, acc[3] / reps, mx[3] / reps);
+	fflush(stdout);
+	CK(hipFree(w));
+	CK(hipFree(x));
 	CK(hipFree(out));
 	CK(hipFree(sink));
 }

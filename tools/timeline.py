@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Where does a decode kernel's time go?  Builds the library a second time with -DCALM_TIMELINE (per-wave 100 MHz wall-clock
+stamps inside the row engine: entry / LDS image built / first tile done / exit), launches each matvec stage of a BASELINE shape
+back to back over the layers (perf_stage_hip) and reads the stamps of the LAST launch: when its waves start, how long the
+prologue takes, how the exits are distributed (the tail).  Run on the GPU box:
+
+    python tools/timeline.py [model] [dtype] [layers]
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SO = os.path.join(ROOT, "tools", "libcalm_hip_tl.so")
+src = os.path.join(ROOT, "calm_amd", "csrc", "infer_hip.hip")
+deps = [os.path.join(ROOT, "calm_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "calm_amd", "csrc"))]
+if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCALM_TIMELINE", "-shared", "-o", SO, src], check=True)
+if "--build-only" in sys.argv:
+    sys.exit(0)
+os.environ["CALM_HIP_LIB"] = SO
+
+import numpy as np  # noqa: E402
+
+from calm_amd import calmfile as cf  # noqa: E402
+from calm_amd.host import STAGES, HipBackend, HostModel  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+name = args[0] if len(args) > 0 else "mistral-7b"
+dtype = args[1] if len(args) > 1 else "fp8"
+L = int(args[2]) if len(args) > 2 else 8
+spec = cf.SPECS[name]
+model = HostModel(cf.stub_tensors(spec, dtype, L), cf.dataclasses.replace(spec, n_layers=L).metadata(dtype))
+b = HipBackend(model, device_synth=(spec, dtype, 1, L))
+lib = b.lib._product
+lib.calm_tl_arm.argtypes = [C.c_int]
+lib.calm_tl_read.argtypes = [C.c_void_p, C.c_int]
+for pos in range(64):
+    b.forward(5 + pos, pos, 0)
+waves = 8192
+print(f"{name} {dtype} L={L}; us after the launch's first wave started; stage time = perf_stage_hip of the INSTRUMENTED build")
+print(f"{'kernel':9s} {'us/launch':>9s} {'waves':>6s} | last wave start | image built p50 / max | first tile done p50 / max | exits p1 / p10 / p50 / p90 / p99 / last")
+for i, st in enumerate(STAGES):
+    if st == "attn":
+        continue
+    lib.calm_tl_arm(waves)
+    us, _ = b.stage_us(i, 2)
+    buf = np.zeros((waves, 8), dtype=np.uint64)
+    lib.calm_tl_read(buf.ctypes.data, waves)
+    t = buf.astype(np.int64) * 10
+    a = t[t[:, 3] > 0]
+    t0 = a[:, 0].min()
+    ex = (a[:, 3] - t0) / 1e3
+    ft = (a[:, 2][a[:, 2] > 0] - t0) / 1e3
+    im = (a[:, 1] - t0) / 1e3
+    pc = lambda v, q: float(np.percentile(v, q))
+    print(f"{st:9s} {us:9.2f} {len(a):6d} | {(a[:, 0].max() - t0) / 1e3:6.2f} | {pc(im, 50):6.2f} {im.max():6.2f} | {pc(ft, 50):6.2f} {ft.max():6.2f} | "
+          f"{pc(ex, 1):6.2f} {pc(ex, 10):6.2f} {pc(ex, 50):6.2f} {pc(ex, 90):6.2f} {pc(ex, 99):6.2f} {ex.max():6.2f}")
+    if st in ("ffn_up", "ffn_down"):
+        wpb = 4 if st == "ffn_up" else 8
+        idx = np.nonzero(t[:, 3] > 0)[0]
+        blk = idx // wpb
+        print("          exits by XCD (block % 8), p50 / max: " + "  ".join(f"{x}: {pc(ex[blk % 8 == x], 50):5.1f}/{ex[blk % 8 == x].max():5.1f}" for x in range(8)))
+        # who is late?  by wave slot within the workgroup, by workgroup half (b < 256: first resident round), and how much of
+        # the spread is BETWEEN workgroups (workgroup means) vs WITHIN them
+        wv = idx % wpb
+        print("          exit p50 by wave slot in the workgroup: " + " ".join(f"{w}:{pc(ex[wv == w], 50):5.1f}" for w in range(wpb))
+              + "   by workgroup index range: " + " ".join(f"[{lo},{lo + 128}):{pc(ex[(blk >= lo) & (blk < lo + 128)], 50):5.1f}" for lo in range(0, int(blk.max()) + 1, 128)))
+        nb = int(blk.max()) + 1
+        wg_mean = np.array([ex[blk == g].mean() for g in range(nb)])
+        wg_rng = np.array([ex[blk == g].max() - ex[blk == g].min() for g in range(nb)])
+        print(f"          workgroup mean exit: min {wg_mean.min():.1f} p50 {np.median(wg_mean):.1f} max {wg_mean.max():.1f};  spread inside a workgroup (max - min): p50 {np.median(wg_rng):.2f} max {wg_rng.max():.2f}")
+        hist, edges = np.histogram(ex, bins=10)
+        print("          exit histogram: " + " ".join(f"{edges[k]:.1f}-{edges[k + 1]:.1f}:{hist[k]}" for k in range(len(hist))))
+b.close()
