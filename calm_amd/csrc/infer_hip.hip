@@ -556,38 +556,61 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	c->ba.kv_pos = kv_pos;
 	c->ba.kv_len = kv_len;
 
-	if (g_prof) {
-		// events: per layer [qkv, attn, attn_out, ffn_up, ffn_down], then [end-of-layers, after output].  An event between two
-		// kernels costs the queue a marker packet.  What that adds to a chain of dependent kernels is measured once -- 32 empty
-		// kernels with an event after each against the same 32 with events at the two ends only -- and taken off every span
-		// (without it the 6-8 us stages read ~25 % slow against perf_stage_hip's back-to-back launches)
-		static double marker_us = -1;
-		if (marker_us < 0) {
-			const int n = 32;
-			while (c->events.size() < (size_t)n + 1) {
-				hipEvent_t e;
-				HIP_CHECK(hipEventCreate(&e));
-				c->events.push_back(e);
-			}
-			auto chain = [&](bool between) {
-				HIP_CHECK(hipEventRecord(c->events[0], g_stream));
-				for (int i = 1; i <= n; ++i) {
-					hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, g_stream);
-					if (between || i == n) {
-						HIP_CHECK(hipEventRecord(c->events[between ? i : 1], g_stream));
-					}
-				}
-				HIP_CHECK(hipStreamSynchronize(g_stream));
-				float ms = 0;
-				HIP_CHECK(hipEventElapsedTime(&ms, c->events[0], c->events[between ? n : 1]));
-				return (double)ms * 1e3;
-			};
-			chain(true); // warm
-			const double with = chain(true), without = chain(false);
-			marker_us = with > without ? (with - without) / n : 0.0;
+	auto replay = [&]() { // the step from its hipGraph (captured on first use), begin-token arguments patched
+		auto key = std::make_tuple(sp.n_split, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.argmax * 2 + (int)sp.copy_logits);
+		GraphEntry& ge = c->graphs[key];
+		if (!ge.exec) {
+			HIP_CHECK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
+			dispatch_step(c, sp, false);
+			HIP_CHECK(hipStreamEndCapture(g_stream, &ge.graph));
+			HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
+			// the begin-token kernel is the only root of the (linear) graph
+			size_t nroots = 0;
+			HIP_CHECK(hipGraphGetRootNodes(ge.graph, nullptr, &nroots));
+			CALM_REQUIRE(nroots == 1, "captured decode graph must have exactly one root");
+			HIP_CHECK(hipGraphGetRootNodes(ge.graph, &ge.begin_node, &nroots));
+			hipGraphNodeType ty;
+			HIP_CHECK(hipGraphNodeGetType(ge.begin_node, &ty));
+			CALM_REQUIRE(ty == hipGraphNodeTypeKernel, "root of the decode graph must be the begin-token kernel");
 		}
+		hipKernelNodeParams kp;
+		memset(&kp, 0, sizeof(kp));
+		int n = c->dim > c->head_dim / 2 ? c->dim : c->head_dim / 2;
+		kp.func = begin_func(c);
+		kp.gridDim = dim3((n + 255) / 256);
+		kp.blockDim = dim3(256);
+		kp.sharedMemBytes = 0;
+		kp.kernelParams = c->ba_ptrs;
+		kp.extra = nullptr;
+		HIP_CHECK(hipGraphExecKernelNodeSetParams(ge.exec, ge.begin_node, &kp));
+		HIP_CHECK(hipGraphLaunch(ge.exec, g_stream));
+	};
+
+	if (g_prof) {
+		// Per-stage times from events between the kernels of an eager pass: per layer [qkv, attn, attn_out, ffn_up, ffn_down],
+		// then [end-of-layers, after output].  Every event costs the queue a marker packet (2-5 us, partly hidden behind the
+		// kernel before it), so the same step is first replayed from its graph between two events only: what the marked pass
+		// takes beyond that, spread evenly over its spans, is taken off each of them.  (The step is idempotent: same token, same
+		// position, same cache row written twice.)
+		while (c->events.size() < 2) {
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreate(&e));
+			c->events.push_back(e);
+		}
+		replay(); // (first use of this plan: captures the graph)
+		HIP_CHECK(hipEventRecord(c->events[0], g_stream));
+		replay();
+		HIP_CHECK(hipEventRecord(c->events[1], g_stream));
+		HIP_CHECK(hipStreamSynchronize(g_stream));
+		float plain_ms = 0;
+		HIP_CHECK(hipEventElapsedTime(&plain_ms, c->events[0], c->events[1]));
 		dispatch_step(c, sp, true);
 		HIP_CHECK(hipStreamSynchronize(g_stream));
+		const size_t nspans = (size_t)c->n_layers * 5 + (sp.kv_only ? 0 : 1);
+		float marked_ms = 0;
+		HIP_CHECK(hipEventElapsedTime(&marked_ms, c->events[0], c->events[nspans]));
+		double marker_us = ((double)marked_ms - (double)plain_ms) * 1e3 / (double)nspans;
+		marker_us = marker_us > 0 ? marker_us : 0;
 		size_t ev = 0;
 		auto span = [&](int stage) {
 			float ms = 0;
@@ -611,34 +634,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 		dispatch_step(c, sp, false);
 		return;
 	}
-
-	auto key = std::make_tuple(sp.n_split, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.argmax * 2 + (int)sp.copy_logits);
-	GraphEntry& ge = c->graphs[key];
-	if (!ge.exec) {
-		HIP_CHECK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
-		dispatch_step(c, sp, false);
-		HIP_CHECK(hipStreamEndCapture(g_stream, &ge.graph));
-		HIP_CHECK(hipGraphInstantiate(&ge.exec, ge.graph, nullptr, nullptr, 0));
-		// the begin-token kernel is the only root of the (linear) graph
-		size_t nroots = 0;
-		HIP_CHECK(hipGraphGetRootNodes(ge.graph, nullptr, &nroots));
-		CALM_REQUIRE(nroots == 1, "captured decode graph must have exactly one root");
-		HIP_CHECK(hipGraphGetRootNodes(ge.graph, &ge.begin_node, &nroots));
-		hipGraphNodeType ty;
-		HIP_CHECK(hipGraphNodeGetType(ge.begin_node, &ty));
-		CALM_REQUIRE(ty == hipGraphNodeTypeKernel, "root of the decode graph must be the begin-token kernel");
-	}
-	hipKernelNodeParams kp;
-	memset(&kp, 0, sizeof(kp));
-	int n = c->dim > c->head_dim / 2 ? c->dim : c->head_dim / 2;
-	kp.func = begin_func(c);
-	kp.gridDim = dim3((n + 255) / 256);
-	kp.blockDim = dim3(256);
-	kp.sharedMemBytes = 0;
-	kp.kernelParams = c->ba_ptrs;
-	kp.extra = nullptr;
-	HIP_CHECK(hipGraphExecKernelNodeSetParams(ge.exec, ge.begin_node, &kp));
-	HIP_CHECK(hipGraphLaunch(ge.exec, g_stream));
+	replay();
 }
 
 // ---------------------------------------------------------------- batched prompt ingestion -----

@@ -1541,10 +1541,6 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
-// empty kernel: perf_hip's calibration of what an event marker costs inside a kernel chain (infer_hip.hip)
-__global__ void k_nop() {
-}
-
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
 // single workgroup of 1024 threads; writes *next and, if trace, appends to trace[(*trace_count)++]
 __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int n, int* next, int* trace, int* trace_count) {
