@@ -78,11 +78,16 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-device-greedy", action="store_true", help="skip the extra device-side greedy decode leg (rocprofv3 7.2 crashes in it)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--pipeline", type=int, default=0, help="split the layers over P pipeline stages inside this one process (CALM_HIP_DEVICES=P: stage s on GPU s %% visible GPUs; "
+                    "BASELINE config 5's partitioning) instead of running on one GPU")
     ap.add_argument("--host-synth", action="store_true", help="without a CPU leg: synthesise the weights on the host and upload them (default: on the device)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.pipeline > 1:
+        assert world == 1, "--pipeline is a single-process mode: launch without torchrun"
+        os.environ["CALM_HIP_DEVICES"] = str(args.pipeline)  # read by init_hip
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("CALM_HIP_DEVICE", str(local_rank))
     if world > 1:
@@ -154,10 +159,16 @@ def main():
     # roofline of the dominant kernel (FFN up: 2 x hidden x dim weight bytes per launch), HIP events on
     # the backend's stream, launches cycling over the layers so nothing is served from the Infinity Cache
     stage_report = {}
-    for i, name in enumerate(STAGES):
-        us, b = be.stage_us(i, 8 if i != 5 else 1)
-        stage_report[name] = {"us": round(us, 2), "GBps": round(b / us / 1e3, 1) if us > 0 else None, "bytes": int(b)}
-    dom = stage_report["ffn_up"]
+    if args.pipeline > 1:
+        # a model split over stages is driven through forward_hip only: no per-stage timing; the roofline below is then the
+        # whole step's algorithmic bytes over its time (every stage idles while the others work: one token in flight)
+        args.no_device_greedy = True
+        dom = {"GBps": round(achieved, 1), "bytes": int(step_bytes), "us": round(elapsed / args.steps * 1e6, 2)}
+    else:
+        for i, name in enumerate(STAGES):
+            us, b = be.stage_us(i, 8 if i != 5 else 1)
+            stage_report[name] = {"us": round(us, 2), "GBps": round(b / us / 1e3, 1) if us > 0 else None, "bytes": int(b)}
+        dom = stage_report["ffn_up"]
     # HBM bytes per launch from the PMC pass committed under profiles/ (rocprofv3 --pmc FETCH_SIZE in its own
     # run, x1024 x2 per MI355X_MICROARCH.md; tools/prof_summary.py) -- only for the shape it was measured on
     traffic, traffic_source = None, None
@@ -176,7 +187,7 @@ def main():
         break
     roofline = {
         "bound": "hbm",
-        "kernel": "k_ffn_up",
+        "kernel": "k_ffn_up" if args.pipeline <= 1 else "whole decode step (all stages)",
         "achieved": dom["GBps"],
         "peak": HBM_PEAK_GBPS,
         "unit": "GB/s",
@@ -247,7 +258,8 @@ def main():
             "workload": f"{args.model} {args.dtype} .calm shape, batch 1, greedy {args.steps}-token decode via forward_hip + host argmax (run.c generate loop)",
             "weights": f"{args.dtype} ({cf.DBITS[args.dtype]} bit), fp32 activations/accumulate, fp16 KV cache",
             "n_layers": n_layers, "dim": spec.dim, "hidden_dim": spec.hidden_dim, "vocab": spec.vocab_size, "context": model.config.seq_len,
-            "parallelism": "single GPU" if world == 1 else f"{world} independent replicas",
+            "parallelism": (f"{args.pipeline}-stage layer pipeline in one process over {min(args.pipeline, be.lib.calm_hip_device_count())} GPU(s), one token in flight"
+                            if args.pipeline > 1 else ("single GPU" if world == 1 else f"{world} independent replicas")),
             "device": be.lib.calm_hip_device_name().decode(),
         },
         "achieved_GBps": round(achieved, 1),

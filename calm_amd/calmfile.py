@@ -607,27 +607,39 @@ def _dev_synth_lib():
     return _DEV_SYNTH_LIB
 
 
-def synth_device(spec: ModelSpec, dtype: str, seed: int, n_layers: Optional[int], alloc, upload):
+def synth_device(spec: ModelSpec, dtype: str, seed: int, n_layers: Optional[int], alloc, upload, before=None):
     """Yield (name, DEVICE pointer) for every `model.*` tensor of the synthetic model synth_stream_big describes -- the same
     bytes, produced on the GPU (tools/synth_fill_hip.hip): Mixtral-8x7B fp8 (46.7 GB) and DBRX-132B fp8 (131.6 GB) appear in
     HBM in seconds.  alloc(nbytes) -> device pointer with the backend's slack (alloc_hip); upload(array) -> device pointer
     (upload_hip; used for the small fp32 tensors and the code tables)."""
     lib = _dev_synth_lib()
-    luts: Dict[Tuple[str, float], int] = {}
+    luts: Dict[Tuple, int] = {}
     kind = {"fp8": 0, "fp16": 1, "gf4": 2}[dtype]
     esize = {"fp8": 1, "fp16": 2, "gf4": 4}[dtype]
 
+    where = [None]  # what before() returned for the tensor being made: the device it lives on (code tables are per device)
+
     def W(shape, sigma, fill_seed):
         n = int(np.prod(shape)) // (8 if dtype == "gf4" else 1)
-        key = (dtype, float(sigma))
+        key = (dtype, float(sigma), where[0])
         if key not in luts:
             luts[key] = upload(np.ascontiguousarray(_gf4_scale_lut(sigma) if dtype == "gf4" else _code_lut(dtype, sigma)))
         ptr = alloc(n * esize)
         lib.synth_fill_hip(ptr, n, kind, luts[key], fill_seed)
         return ptr
 
-    for name, v in _synth_walk(spec, dtype, seed, n_layers, W, lambda a: upload(np.ascontiguousarray(a)), with_tokenizer=False):
+    # `before(name)` runs ahead of each tensor's allocation (a multi-device host points the backend at the tensor's stage): the
+    # walk is lazy -- a tensor is made when the loop below asks for it -- so the names are drawn from a dry walk first
+    names = [n for n, _ in _synth_walk(spec, dtype, seed, n_layers, lambda *a: None, lambda a: None, with_tokenizer=False)]
+    it = _synth_walk(spec, dtype, seed, n_layers, W, lambda a: upload(np.ascontiguousarray(a)), with_tokenizer=False)
+    for nm in names:
+        if before is not None:
+            where[0] = before(nm)
+        name, v = next(it)
+        assert name == nm
         yield name, v
+    if before is not None:
+        before("")
     for ptr in luts.values():  # handed back so that the caller can free them with the tensors
         yield "", ptr
 

@@ -48,9 +48,32 @@ namespace {
 constexpr int LDS_EXTRA = 1024; // reduction scratch + MoE routing scratch behind the activation image
 constexpr int MAX_SPLIT = 64;
 
-hipStream_t g_stream;
+hipStream_t g_stream; // the CURRENT device's decode stream (multi-device: switched by use_dev)
 int g_device = -1;
 int g_ncu = 256;
+
+// CALM_HIP_DEVICES=P (P > 1): the layers of every model prepared by this process are split over P pipeline stages, stage s on
+// device (first + s) % visible devices -- one process, the four entry points unchanged, so the reference's CLI drives a sharded
+// model as it drives one GPU (the reference itself pins device 0, src/infer.cu:79).  With fewer physical
+// devices than stages several stages share a device (each on its own stream): the whole path runs, and is tested, on one GPU.
+struct DevSlot {
+	int dev = 0;
+	hipStream_t stream = nullptr;
+	int ncu = 256;
+};
+std::vector<DevSlot> g_devs; // one per stage; size 1 = the single-device backend
+void use_dev(int s) {
+	HIP_CHECK(hipSetDevice(g_devs[s].dev));
+	g_stream = g_devs[s].stream;
+	g_ncu = g_devs[s].ncu;
+}
+// multi-device: upload_hip cannot know which layer (hence which device) a tensor belongs to -- run.c uploads before it resolves
+// names (src/run.c:550-561 then :563-576) -- so it only notes the host range and hands the host pointer back; prepare_hip, which
+// sees struct Weights, uploads every tensor to its stage's device (the mapping stays valid until then: src/run.c:515,637).
+std::map<const void*, size_t> g_pending_uploads;
+// ... unless the host says where it belongs first: calm_hip_configure("stage", s) routes the following upload_hip / alloc_hip
+// calls to stage s's device at once (-1: back to deferring) -- for hosts that know tensor names, or fill tensors on the device
+int g_alloc_stage = -1;
 int g_bpc = 2;       // cap on resident 256-thread workgroups per CU when sizing grids (measured: 2 beats 3 and 4)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
@@ -167,7 +190,7 @@ Ctx* g_prof_ctx = nullptr;
 
 Ctx* ctx_of(struct Transformer* t) {
 	auto it = g_ctx.find(t);
-	CALM_REQUIRE(it != g_ctx.end(), "forward_hip called on a transformer that was not prepared with prepare_hip");
+	CALM_REQUIRE(it != g_ctx.end(), "this transformer was not prepared with prepare_hip -- or it is split over CALM_HIP_DEVICES > 1 stages, which forward_hip drives and this entry point does not");
 	return it->second;
 }
 
@@ -422,6 +445,9 @@ struct StepPlan {
 	bool kv_only, sink, chained, argmax, copy_logits;
 };
 
+struct Ctx;
+void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool embed = true);
+
 template <int DB, int KVB>
 void enqueue_step(Ctx* c, const StepPlan& sp, bool timed) {
 	size_t ev = 0;
@@ -531,7 +557,7 @@ void* begin_func(Ctx* c) {
 	}
 }
 
-void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool embed = true) {
+void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool embed) {
 	struct Config* p = &c->t->config;
 	// rolling KV buffer with attention sinks (src/infer.c:329-332)
 	int kv_sink = pos >= p->seq_len ? CALM_KV_SINKS : 0;
@@ -868,6 +894,13 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_t;
 	} else if (!strcmp(key, "split_min")) {
 		slot = &g_split_min;
+	} else if (!strcmp(key, "stage")) {
+		CALM_REQUIRE(value < (int)g_devs.size(), "calm_hip_configure(\"stage\"): no such stage");
+		int old_stage = g_alloc_stage;
+		g_alloc_stage = value; // (-1 is a value here, not "query")
+		return old_stage;
+	} else if (!strcmp(key, "stages")) {
+		return (int)g_devs.size();
 	} else {
 		return -1;
 	}
@@ -899,6 +932,35 @@ extern "C" void init_hip(void) {
 	snprintf(g_devname, sizeof(g_devname), "%s", prop.name[0] ? prop.name : prop.gcnArchName);
 	HIP_CHECK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
 	g_device = dev;
+	{
+		DevSlot d0;
+		d0.dev = dev, d0.stream = g_stream, d0.ncu = g_ncu;
+		g_devs.push_back(d0);
+		const int stages = env_int("CALM_HIP_DEVICES", 1);
+		CALM_REQUIRE(stages >= 1 && stages <= 64, "CALM_HIP_DEVICES must be between 1 and 64");
+		for (int s_ = 1; s_ < stages; ++s_) {
+			DevSlot d;
+			d.dev = (dev + s_) % n;
+			HIP_CHECK(hipSetDevice(d.dev));
+			hipDeviceProp_t pr;
+			HIP_CHECK(hipGetDeviceProperties(&pr, d.dev));
+			d.ncu = pr.multiProcessorCount;
+			HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+			if (d.dev != dev) {
+				int can = 0;
+				HIP_CHECK(hipDeviceCanAccessPeer(&can, d.dev, g_devs[s_ - 1].dev));
+				if (can && g_devs[s_ - 1].dev != d.dev) {
+					hipError_t e = hipDeviceEnablePeerAccess(g_devs[s_ - 1].dev, 0); // the residual stream arrives from the stage before
+					if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
+						HIP_CHECK(e);
+					}
+					(void)hipGetLastError();
+				}
+			}
+			g_devs.push_back(d);
+		}
+		use_dev(0);
+	}
 	g_bpc = env_int("CALM_HIP_BPC", g_bpc);
 	g_use_graph = env_int("CALM_HIP_GRAPH", 1);
 	g_prof = env_int("CALM_HIP_PROF", 0);
@@ -917,6 +979,13 @@ extern "C" void init_hip(void) {
 
 extern "C" void* upload_hip(void* host, size_t size) {
 	init_hip();
+	if (g_devs.size() > 1) {
+		if (g_alloc_stage < 0) {
+			g_pending_uploads[host] = size; // which device it goes to is known in prepare_hip
+			return host;
+		}
+		use_dev(g_alloc_stage);
+	}
 	void* device = dev_alloc(size);
 	HIP_CHECK(hipMemcpy(device, host, size, hipMemcpyHostToDevice));
 	return device;
@@ -924,13 +993,26 @@ extern "C" void* upload_hip(void* host, size_t size) {
 
 extern "C" void* alloc_hip(size_t size) {
 	init_hip();
+	if (g_devs.size() > 1) {
+		CALM_REQUIRE(g_alloc_stage >= 0, "alloc_hip with CALM_HIP_DEVICES > 1: say which stage first (calm_hip_configure(\"stage\", s))");
+		use_dev(g_alloc_stage);
+	}
 	return dev_alloc(size);
 }
 
 extern "C" void free_hip(void* device) {
-	if (device) {
-		HIP_CHECK(hipFree(device));
+	if (!device) {
+		return;
 	}
+	if (g_pending_uploads.erase(device)) {
+		return; // a deferred upload that never reached a device: the pointer is the host's own
+	}
+	hipPointerAttribute_t attr;
+	if (hipPointerGetAttributes(&attr, device) != hipSuccess || attr.type != hipMemoryTypeDevice) {
+		(void)hipGetLastError();
+		return; // (multi-device: upload_hip handed the host pointer back; prepare_hip's device copies are freed by release_hip)
+	}
+	HIP_CHECK(hipFree(device));
 }
 
 extern "C" void download_hip(void* host, const void* device, size_t size) {
@@ -939,8 +1021,11 @@ extern "C" void download_hip(void* host, const void* device, size_t size) {
 	HIP_CHECK(hipMemcpy(host, device, size, hipMemcpyDeviceToHost));
 }
 
-extern "C" void prepare_hip(struct Transformer* t) {
-	init_hip();
+namespace {
+
+// one device's share of a model: a whole model (the single-device backend) or one pipeline stage (an ordinary struct
+// Transformer holding a contiguous run of layers); everything is allocated on the CURRENT device
+void prepare_ctx(struct Transformer* t) {
 	struct Config* p = &t->config;
 	struct Weights* w = &t->weights;
 	struct RunState* s = &t->state;
@@ -1062,7 +1147,146 @@ extern "C" void prepare_hip(struct Transformer* t) {
 	g_ctx[t] = c;
 }
 
+// ---- the layer pipeline inside the library (CALM_HIP_DEVICES > 1) --------------------------------------------------
+struct MultiCtx {
+	std::vector<struct Transformer*> stage; // one trimmed struct Transformer per stage, each prepared on its own device
+	std::vector<std::vector<void*>> owned;  // the device copies of each stage's tensors
+	std::vector<hipEvent_t> handoff;        // stage s's residual stream has arrived on stage s + 1
+};
+std::map<struct Transformer*, MultiCtx*> g_multi;
+
+void* upload_pending(const void* host, std::vector<void*>& owned) {
+	if (!host) {
+		return nullptr;
+	}
+	auto it = g_pending_uploads.find(host);
+	if (it == g_pending_uploads.end()) {
+		// placed by the host already (calm_hip_configure("stage", s) before upload_hip / alloc_hip): must be device memory
+		hipPointerAttribute_t attr;
+		CALM_REQUIRE(hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeDevice,
+		             "multi-device: a weight pointer that came neither from a deferred upload_hip nor from a staged upload_hip / alloc_hip");
+		return const_cast<void*>(host);
+	}
+	void* d = dev_alloc(it->second);
+	HIP_CHECK(hipMemcpy(d, host, it->second, hipMemcpyHostToDevice));
+	owned.push_back(d);
+	return d;
+}
+
+void prepare_multi(struct Transformer* t) {
+	const int P = (int)g_devs.size(), L = t->config.n_layers;
+	CALM_REQUIRE(L >= P, "CALM_HIP_DEVICES: more pipeline stages than layers");
+	MultiCtx* m = new MultiCtx();
+	m->owned.resize(P);
+	int l0 = 0;
+	for (int s = 0; s < P; ++s) {
+		const int n = L / P + (s < L % P ? 1 : 0); // contiguous, near-equal runs; the earlier stages take the remainder
+		use_dev(s);
+		struct Transformer* st = (struct Transformer*)calloc(1, sizeof(struct Transformer));
+		st->config = t->config;
+		st->config.n_layers = n;
+		st->state.kvbits = t->state.kvbits;
+		struct Weights *w = &st->weights, *W = &t->weights;
+		std::vector<void*>& own = m->owned[s];
+		w->dbits = W->dbits;
+		const bool first = s == 0, last = s == P - 1;
+		if (first) {
+			w->token_embedding_table = upload_pending(W->token_embedding_table, own);
+		}
+		for (int l = 0; l < n; ++l) {
+			const int g = l0 + l;
+			w->rms_att_weight[l] = (float*)upload_pending(W->rms_att_weight[g], own);
+			w->rms_ffn_weight[l] = (float*)upload_pending(W->rms_ffn_weight[g], own);
+			w->wq[l] = upload_pending(W->wq[g], own), w->wk[l] = upload_pending(W->wk[g], own), w->wv[l] = upload_pending(W->wv[g], own);
+			w->wo[l] = upload_pending(W->wo[g], own);
+			w->w1[l] = upload_pending(W->w1[g], own), w->w2[l] = upload_pending(W->w2[g], own), w->w3[l] = upload_pending(W->w3[g], own);
+			w->bqkv[l] = (float*)upload_pending(W->bqkv[g], own);
+			w->moegate[l] = upload_pending(W->moegate[g], own);
+		}
+		if (last) {
+			w->rms_final_weight = (float*)upload_pending(W->rms_final_weight, own);
+			// a tied classifier is the embedding table (src/run.c:112-116): the last stage gets its own copy unless it is also the first
+			w->wcls = (W->wcls == W->token_embedding_table && first) ? w->token_embedding_table : upload_pending(W->wcls, own);
+		}
+		prepare_ctx(st);
+		m->stage.push_back(st);
+		if (s + 1 < P) {
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			m->handoff.push_back(e);
+		}
+		l0 += n;
+	}
+	g_pending_uploads.clear();
+	use_dev(0);
+	// what the host program may look at: the residual stream where it enters, the logits where they leave
+	t->state.x = m->stage[0]->state.x;
+	t->state.logits = m->stage[P - 1]->state.logits;
+	g_multi[t] = m;
+}
+
+// one decode step through every stage: stage s runs on its device's stream, its residual stream crosses to stage s + 1 with a
+// peer copy queued behind it, and stage s + 1's stream waits for that copy's event -- the host only waits for the last stage
+float* forward_multi(MultiCtx* m, int token, int pos, unsigned flags) {
+	const int P = (int)m->stage.size();
+	const bool kv_only = (flags & FF_UPDATE_KV_ONLY) != 0;
+	for (int s = 0; s < P; ++s) {
+		use_dev(s);
+		Ctx* c = ctx_of(m->stage[s]);
+		if (s > 0) {
+			HIP_CHECK(hipStreamWaitEvent(g_stream, m->handoff[s - 1], 0));
+		}
+		StepPlan sp = {};
+		sp.kv_only = kv_only || s + 1 < P; // only the last stage has a final norm and a classifier
+		sp.copy_logits = !sp.kv_only;
+		run_step(c, token, nullptr, pos, sp, s == 0);
+		if (s + 1 < P) {
+			Ctx* nx = ctx_of(m->stage[s + 1]);
+			HIP_CHECK(hipMemcpyPeerAsync(nx->x, g_devs[s + 1].dev, c->x, g_devs[s].dev, (size_t)c->dim * sizeof(float), g_stream));
+			HIP_CHECK(hipEventRecord(m->handoff[s], g_stream));
+		}
+	}
+	float* out = nullptr;
+	if (!kv_only) {
+		HIP_CHECK(hipStreamSynchronize(g_stream)); // the last stage's stream: everything before it is ordered by the events
+		out = ctx_of(m->stage[P - 1])->logits_h;
+	}
+	use_dev(0);
+	return out;
+}
+
+} // namespace
+
+extern "C" void prepare_hip(struct Transformer* t) {
+	init_hip();
+	if (g_devs.size() > 1) {
+		prepare_multi(t);
+	} else {
+		prepare_ctx(t);
+	}
+}
+
 extern "C" void release_hip(struct Transformer* t) {
+	auto mt = g_multi.find(t);
+	if (mt != g_multi.end()) {
+		MultiCtx* m = mt->second;
+		g_multi.erase(mt);
+		for (size_t s = 0; s < m->stage.size(); ++s) {
+			use_dev((int)s);
+			release_hip(m->stage[s]);
+			for (void* d : m->owned[s]) {
+				HIP_CHECK(hipFree(d));
+			}
+			free(m->stage[s]);
+		}
+		for (hipEvent_t e : m->handoff) {
+			HIP_CHECK(hipEventDestroy(e));
+		}
+		use_dev(0);
+		delete m;
+		t->state.x = nullptr, t->state.logits = nullptr;
+		return;
+	}
 	auto it = g_ctx.find(t);
 	if (it == g_ctx.end()) {
 		return;
@@ -1102,6 +1326,10 @@ extern "C" void release_hip(struct Transformer* t) {
 }
 
 extern "C" float* forward_hip(struct Transformer* t, int token, int pos, unsigned flags) {
+	auto mt = g_multi.find(t);
+	if (mt != g_multi.end()) {
+		return forward_multi(mt->second, token, pos, flags);
+	}
 	Ctx* c = ctx_of(t);
 	StepPlan sp = {};
 	sp.kv_only = (flags & FF_UPDATE_KV_ONLY) != 0;

@@ -241,28 +241,60 @@ class HipBackend:
         self._dev: Dict[str, int] = {}
         self._extra: List[int] = []
         self.lib.init_hip()
+        # CALM_HIP_DEVICES=P > 1: the library splits the layers over P pipeline stages (include/calm_hip.h).  A host that knows
+        # tensor names says where each tensor goes before it uploads or generates it; one that does not (run.c) lets upload_hip
+        # defer to prepare_hip, for which the host arrays must stay alive until then.
+        self.stages = self.lib.calm_hip_configure(b"stages", -1)
+        self._keep_host = []
+        L, P = model.config.n_layers, self.stages
+
+        def stage_of(name: str) -> int:
+            if name.startswith("model.layers."):
+                l, s0 = int(name.split(".")[2]), 0
+                for st in range(P):
+                    n = L // P + (1 if st < L % P else 0)
+                    if l < s0 + n:
+                        return st
+                    s0 += n
+            return 0 if name.startswith("model.embed.") else P - 1
+
+        def route(name: str):
+            if P > 1:
+                st = stage_of(name) if name else 0
+                self.lib.calm_hip_configure(b"stage", st)
+                return st
+            return None
+
         if device_synth is not None:
             from .calmfile import synth_device
 
-            self._keep_host = []  # host arrays must outlive the (synchronous) upload call only; kept until prepare anyway
+            assert P == 1 or "model.output.weight" in model.tensors, "a tied classifier needs the embedding on two stages: upload it from the host"
 
             def upload(a):
                 self._keep_host.append(a)
                 return self.lib.upload_hip(a.ctypes.data, a.nbytes)
 
-            for name, ptr in synth_device(*device_synth, alloc=self.lib.alloc_hip, upload=upload):
+            gen = synth_device(*device_synth, alloc=self.lib.alloc_hip, upload=upload, before=route)
+            for name, ptr in gen:
                 if name:
                     self._dev[name] = ptr
                 else:
                     self._extra.append(ptr)
-            self._keep_host = []
         else:
             for name, a in (stream if stream is not None else model.tensors.items()):
                 if name.startswith("model."):  # run.c:556-558
                     a = np.ascontiguousarray(a)
+                    if P > 1:
+                        if stream is not None:
+                            route(name)  # streamed buffers are reused: place each tensor at once
+                        else:
+                            self._keep_host.append(a)  # deferred to prepare_hip, like run.c's mmap
                     self._dev[name] = self.lib.upload_hip(a.ctypes.data, a.nbytes)
+        if P > 1:
+            self.lib.calm_hip_configure(b"stage", -1)
         model.fill_transformer(self.t, lambda n: self._dev[n], kvbits)
         self.lib.prepare_hip(C.byref(self.t))
+        self._keep_host = []
         self.vocab = model.config.vocab_size
         self._logits_addr, self._logits_view = 0, None
 
