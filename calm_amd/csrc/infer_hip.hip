@@ -906,6 +906,20 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 	}
 	int old = *slot;
 	if (value >= 0) {
+		if (*slot != value && slot != &g_use_graph && slot != &g_prof) {
+			// a knob that shapes the launches: the captured graphs of every prepared model are stale
+			for (auto& kv : g_ctx) {
+				for (auto& ge : kv.second->graphs) {
+					if (ge.second.exec) {
+						HIP_CHECK(hipGraphExecDestroy(ge.second.exec));
+					}
+					if (ge.second.graph) {
+						HIP_CHECK(hipGraphDestroy(ge.second.graph));
+					}
+				}
+				kv.second->graphs.clear();
+			}
+		}
 		*slot = value;
 	}
 	return old;

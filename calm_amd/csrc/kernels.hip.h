@@ -556,6 +556,17 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		}
 	};
 #endif
+	if (first >= ntasks) {
+		// a wave without a single task (more waves than tasks) only helps to build the LDS image: none of the always-issued
+		// dummy tile loads below, which would sit in the CU's memory queue ahead of its neighbours' real tiles
+		pre();
+		stage();
+#ifdef CALM_TIMELINE
+		tl[1] = wall_clock64();
+		tl_flush();
+#endif
+		return;
+	}
 	pre(); // the activation vector's loads go first: they must retire before, not behind, the tiles
 	int t = first, k0 = 0;   // step being consumed
 	bool live = t < ntasks;

@@ -1,0 +1,44 @@
+#!/bin/bash
+# Round-2 evidence session on the GPU box (outputs under gpurun_out/final_r02, summaries copied to profiles/ by hand afterwards):
+#  1. the default bench line (CPU reference timed on the same model, full-depth parity inside)
+#  2. tools/hipprof.sh over the bench command: rocprofv3 kernel trace + the library's algorithmic-byte account + FETCH_SIZE pass
+#  3. bench lines of the other BASELINE shapes at full size (device-side weight synthesis), DBRX also as a 4-stage pipeline
+#  4. the reference CLI on this backend, first 32 / last 32 positions of a 4096 context (CALM_POSO), full 32-layer Mistral shape
+#  5. SQ counter tables of the gf4 kernels
+TAG=${1:-r02}
+OUT=gpurun_out/final_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd "$(dirname "$0")/.."
+echo "== 1. bench" | tee $OUT/summary.txt
+( time timeout 600 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
+tail -c 3600 $OUT/bench.json >> $OUT/summary.txt; tail -4 $OUT/bench.err >> $OUT/summary.txt
+echo "== 2. hipprof" | tee -a $OUT/summary.txt
+tools/hipprof.sh -t $TAG -w "mistral-7b fp8" -- python bench.py --no-cpu --no-device-greedy --steps 64 --warmup 8 >> $OUT/summary.txt 2>&1
+cp profiles/${TAG}_kernel_stats.md profiles/${TAG}_pmc.json $OUT/ 2>/dev/null
+echo "== 3. other shapes at full size" | tee -a $OUT/summary.txt
+for cfg in "llama-3-8b gf4" "tinyllama-1.1b fp16" "mixtral-8x7b fp8" "dbrx-132b fp8"; do
+  set -- $cfg
+  timeout 600 python bench.py --model $1 --dtype $2 --no-cpu >> $OUT/other_configs.jsonl 2>> $OUT/other.err; echo "$cfg exit $?" >> $OUT/summary.txt
+done
+timeout 600 python bench.py --model dbrx-132b --dtype fp8 --no-cpu --pipeline 4 >> $OUT/other_configs.jsonl 2>> $OUT/other.err; echo "dbrx pipeline 4 exit $?" >> $OUT/summary.txt
+python - >> $OUT/summary.txt <<'PY'
+import json
+for l in open("gpurun_out/final_r02/other_configs.jsonl"):
+    d = json.loads(l)
+    print(d["config"]["workload"][:40], "|", d["config"]["parallelism"][:40], "|", d["value"], "tok/s", d["achieved_GBps"], "GB/s", d["hbm_frac_of_spec"], "| ffn_up", d["stages"].get("ffn_up"))
+PY
+echo "== 4. reference CLI on the HIP backend: first / last 32 positions of a 4096 context" | tee -a $OUT/summary.txt
+if [ -x oracle/_ref/run_hip ]; then
+  python -m calm_amd.calmfile mistral-7b fp8 /tmp/mistral7b_fp8.calm >> $OUT/summary.txt 2>&1
+  for poso in 0 4064; do
+    echo "-- CALM_POSO=$poso" >> $OUT/summary.txt
+    CALM_POSO=$poso timeout 300 oracle/_ref/run_hip /tmp/mistral7b_fp8.calm -i "abc" -t 0 -n 32 > $OUT/cli_poso_$poso.out 2> $OUT/cli_poso_$poso.err
+    head -c 300 $OUT/cli_poso_$poso.out | head -2 >> $OUT/summary.txt; tail -2 $OUT/cli_poso_$poso.err >> $OUT/summary.txt
+  done
+  rm -f /tmp/mistral7b_fp8.calm
+fi
+echo "== 5. gf4 counters" | tee -a $OUT/summary.txt
+tools/pmc_kernel.sh final_${TAG}_pmc_gf4 llama-3-8b gf4 4 > /dev/null 2>&1
+cat gpurun_out/final_${TAG}_pmc_gf4/summary.txt >> $OUT/summary.txt 2>/dev/null
+cat $OUT/summary.txt
