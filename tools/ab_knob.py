@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""A/B of a launch-shaping knob of the library (calm_hip_configure(key, 0/1)) on a layer-reduced BASELINE shape: per-stage timings
-(index 6 = attention + output projection as short contexts launch them), tok/s over 256 greedy tokens, identical tokens.
-    python tools/ab_knob.py <knob> [model] [dtype] [layers]      e.g.  fuse_attn mistral-7b fp8 8"""
+"""A/B of a launch-shaping knob of the library (calm_hip_configure(key, v); KNOB_VALUES=0,1 by default) on a layer-reduced BASELINE
+shape: per-stage timings, tok/s over 256 greedy tokens, identical tokens.
+    python tools/ab_knob.py <knob> [model] [dtype] [layers]      e.g.  bpc mistral-7b fp8 8"""
 import os
 import sys
 import time
@@ -23,7 +23,7 @@ for rep in range(2):
     for v in [int(x) for x in os.environ.get("KNOB_VALUES", "0,1").split(",")]:
         lib.calm_hip_configure(knob, v)
         generate(be, model, [17], 32)
-        row = " | ".join(f"{st} {be.stage_us(i, 8 if i != 5 else 2)[0]:6.2f}" for i, st in enumerate(STAGES + ["attn+out"]))
+        row = " | ".join(f"{st} {be.stage_us(i, 8 if i != 5 else 2)[0]:6.2f}" for i, st in enumerate(STAGES))
         t0 = time.perf_counter()
         toks, st = generate(be, model, [17], 256)
         dt = time.perf_counter() - t0
