@@ -16,6 +16,7 @@
 #include "exp_overlap.hip"
 
 constexpr int EG_MAXP = 136;
+__device__ int eg_noedge; // diagnostic: 1 = the grid-wide wait at an edge is skipped (wrong results, in-phase rate only)
 constexpr int EG_MAXT = 64;  // tasks of one phase per workgroup
 constexpr int EG_SHARD = 32; // uints between counter shards (128 bytes)
 
@@ -233,7 +234,7 @@ __global__ __launch_bounds__((NC + NL) * 64) void k_engine(const EPhase* __restr
 			return;
 		}
 		if (c == 0) { // the poller
-			const unsigned target = (gridDim.x / 8) * (unsigned)(p + 1);
+			const unsigned target = eg_noedge ? 0u : (gridDim.x / 8) * (unsigned)(p + 1);
 			unsigned spins = 0;
 			for (;;) {
 				unsigned v = target;
@@ -385,6 +386,10 @@ static double engine_run(int n_layers, int iters, double* checksum) {
 }
 
 // config = NL * 100000 + NC * 1000 + R * 10 + D;  flags: bit 0 REAL, bit 1 system-scope vector
+extern "C" void exp_engine_noedge(int v) {
+	CK(hipMemcpyToSymbol(HIP_SYMBOL(eg_noedge), &v, sizeof(v)));
+}
+
 extern "C" double exp_engine(int config, int flags, int n_layers, int iters, double* checksum) {
 #define EG(nl, nc, r, d)                                                        \
 	if (config == nl * 100000 + nc * 1000 + r * 10 + d) {                       \

@@ -22,6 +22,10 @@ lib.exp_engine.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_dou
 lib.exp_set_real.argtypes = [C.c_int]
 L = 8
 cfgs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [104166, 107166, 104084, 204164, 206164, 206163, 404162]
+lib.exp_engine_noedge.argtypes = [C.c_int]
+if "noedge" in sys.argv:
+    # diagnostic: the grid-wide wait skipped (results wrong): what the engine streams at when no edge ever holds it up
+    lib.exp_engine_noedge(1)
 for real in (0, 1):
     lib.exp_set_real(real)
     what = "fp8 loop" if real else "touch   "
