@@ -366,22 +366,42 @@ inline bool ffn_down_u7(int hidden, int dbits) {
 	return dbits == 4 && nl % 64 == 0 && (nl / 64) % 7 == 0;
 }
 
+// columns of w2 one k_ffn_down launch covers: all of hidden_dim while its fp32 image (plus gf4's word sums) fits the LDS,
+// else the smallest number of equal whole-KiB column ranges that do (Qwen1.5-72B's 49152 -> 2 x 24576)
+template <int DB>
+int ffn_down_cols(int hidden) {
+	const int unit = 64 * (128 / DB); // columns of a 1-KiB row chunk: ranges start on chunk boundaries
+	int passes = 1;
+	while (lds_bytes<DB>((hidden + passes - 1) / passes + unit) > 160 * 1024) {
+		++passes;
+	}
+	if (passes == 1) {
+		return hidden;
+	}
+	const int per = (hidden + passes - 1) / passes;
+	return (per + unit - 1) / unit * unit;
+}
+
 template <int DB>
 void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
-	const bool u7 = ffn_down_u7(c->hidden, DB);
-	int ntasks = c->dim / (u7 ? 2 : Shape<DB>::NR);
-	dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
-	size_t lds = lds_bytes<DB>(c->hidden);
 	const void* w2 = c->t->weights.w2[l];
-	by_bool(stage_v4(c->hidden, BLOCK), [&](auto V4) {
-		by_bool(u7, [&](auto U7) {
-			by_bool(rows_full<DB>(c->hidden), [&](auto FULL) {
-				hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->he, w2,
-				                   c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active);
+	const int cols = ffn_down_cols<DB>(c->hidden);
+	for (int k0 = 0; k0 < c->hidden; k0 += cols) {
+		const int kn = c->hidden - k0 < cols ? c->hidden - k0 : cols;
+		const bool u7 = ffn_down_u7(kn, DB);
+		int ntasks = c->dim / (u7 ? 2 : Shape<DB>::NR);
+		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
+		size_t lds = lds_bytes<DB>(kn);
+		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
+			by_bool(u7, [&](auto U7) {
+				by_bool(rows_full<DB>(kn), [&](auto FULL) {
+					hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->he,
+					                   w2, c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active, k0, kn);
+				});
 			});
 		});
-	});
+	}
 }
 
 template <int DB>
@@ -847,7 +867,7 @@ void set_lds_attrs(Ctx* c) {
 	// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
 	// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
 	by_bool(true, [&](auto) {
-		size_t big = lds_bytes<DB>(c->hidden);
+		size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
 		allow_lds(k_ffn_down<DB, 512, 4, false, false>, big);
 		allow_lds(k_ffn_down<DB, 512, 4, false, true>, big);
 		allow_lds(k_ffn_down<DB, 512, 4, true, true>, big);
@@ -1064,13 +1084,12 @@ void prepare_ctx(struct Transformer* t) {
 	CALM_REQUIRE(p->seq_len > CALM_KV_SINKS, "seq_len too small");
 	CALM_REQUIRE(!p->n_experts || (p->n_experts_ac > 0 && p->n_experts_ac <= p->n_experts), "bad MoE configuration");
 	{
-		// every matvec kernel keeps its whole input vector in LDS as fp32 (gf4: plus one word sum per 8 columns): the largest
-		// of dim, n_heads*head_dim and hidden_dim must fit the CU's 160 KiB (~40K floats at fp16 / fp8, ~36K at gf4);
-		// documented in include/calm_hip.h -- wider models need a K-chunked staging this backend does not have yet
-		int widest = c->hidden > c->dim ? c->hidden : c->dim;
-		widest = c->q_dim > widest ? c->q_dim : widest;
+		// the matvec kernels keep their whole input vector in LDS as fp32 (gf4: plus one word sum per 8 columns): dim and
+		// n_heads*head_dim must fit the CU's 160 KiB (~40K floats at fp16 / fp8, ~36K at gf4).  hidden_dim need not:
+		// k_ffn_down covers a wider one in several launches over column ranges (launch_ffn_down).  Documented in calm_hip.h.
+		int widest = c->q_dim > c->dim ? c->q_dim : c->dim;
 		size_t need = c->dbits == 16 ? lds_bytes<16>(widest) : (c->dbits == 8 ? lds_bytes<8>(widest) : lds_bytes<4>(widest));
-		CALM_REQUIRE(need <= 160 * 1024, "dim / hidden_dim too wide: the activation vector must fit the 160 KiB LDS (about 40K floats)");
+		CALM_REQUIRE(need <= 160 * 1024, "dim / n_heads*head_dim too wide: the activation vector must fit the 160 KiB LDS (about 40K floats)");
 	}
 	c->lpr = 4;
 	while (c->lpr * 8 < c->head_dim) {

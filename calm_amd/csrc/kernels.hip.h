@@ -1472,20 +1472,23 @@ __global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
 // U7: rows of 7k KiB (hidden 14336 at fp8 = 14 chunks, fp16 = 28, gf4 = 7): tiles of 2 rows x 7 chunks, so a
 // wave's first two steps -- issued before the prologue -- already cover 28 KiB, the whole task at fp8;
 // the long prologue of this kernel (staging the hidden-sized vector) then hides behind the full stream.
+// k0 / kn: the columns [k0, k0 + kn) of w2 this launch covers.  Normally all of them; a hidden_dim whose fp32 image does not fit
+// the CU's LDS is covered by several launches over whole-KiB column ranges, each adding its partial products onto x.
 template <int DB, int BLOCK, int V, bool U7, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
-                                                    int n_active) {
+                                                    int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = U7 ? 2 : Shape<DB>::NR, U = U7 ? 7 : Shape<DB>::U;
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
-	float* red = (float*)(xs4 + xs_slots<DB>(hidden));
+	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	const size_t row_bytes = (size_t)hidden * DB / 8;
 	const int lane = lane_id();
 	const int nact = n_active > 0 ? n_active : 1;
 	for (int k = 0; k < nact; ++k) {
 		const float wk = moe_w[k];
-		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes;
+		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;
+		const float* hk = he + (size_t)k * hidden + k0;
 		auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
@@ -1493,12 +1496,12 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 			}
 		};
 		StageRegs<V, false> sr;
-		auto pre = [&]() { stage_load<BLOCK>(sr, he + (size_t)k * hidden, nullptr); };
+		auto pre = [&]() { stage_load<BLOCK>(sr, hk, nullptr); };
 		auto stage = [&]() {
 			if (k > 0) {
 				__syncthreads(); // everyone is done reading the previous expert's image
 			}
-			stage_finish<DB, BLOCK>(sr, xs4, red, he + (size_t)k * hidden, nullptr, hidden, 0.f, false, nullptr);
+			stage_finish<DB, BLOCK>(sr, xs4, red, hk, nullptr, kn, 0.f, false, nullptr);
 		};
 		auto aux_of = [&](int t, float(&aux)[NR]) { // residual so far (same lane wrote it for k > 0)
 #pragma unroll
@@ -1514,7 +1517,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 				}
 			}
 		};
-		run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, hidden, xs4, he, rows_of, pre, stage, aux_of, epi);
+		run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, kn, xs4, he, rows_of, pre, stage, aux_of, epi);
 	}
 }
 

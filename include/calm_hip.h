@@ -50,8 +50,9 @@ void* alloc_hip(size_t size);
  * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits.
  * Aborts (like every error here) on shapes outside the backend's limits: dbits 4/8/16; dim, hidden_dim and
  * n_heads*head_dim multiples of 128/dbits; head_dim a multiple of 8, at most 512; and -- the one limit the reference's
- * backends do not have -- the widest of dim / hidden_dim / n_heads*head_dim must fit one CU's 160 KiB LDS as an fp32
- * vector (about 40K elements at fp16 / fp8, 36K at gf4): every matvec kernel stages its whole input vector there. */
+ * backends do not have -- dim and n_heads*head_dim must fit one CU's 160 KiB LDS as an fp32 vector (about 40K elements at
+ * fp16 / fp8, 36K at gf4): the matvec kernels stage their whole input vector there.  hidden_dim may be wider: the FFN
+ * down-projection then runs as several launches over column ranges. */
 void prepare_hip(struct Transformer* transformer);
 
 /* replaces forward_cuda (src/run.c:24,581; src/infer.cu:743-759): one decode step for `token`

@@ -264,6 +264,27 @@ def test_full_width_layer_reduced_models_match_oracle(hiplib, name, dtype, layer
         o.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp8", "fp16", "gf4"])
+def test_hidden_dim_wider_than_the_lds_runs_as_column_ranges(hiplib, dtype):
+    """hidden_dim 49152 (Qwen1.5-72B's): its fp32 image (192 KiB) does not fit a CU's 160 KiB of LDS, so the down-projection runs
+    as two launches over column ranges, each adding onto the residual -- against the oracle, MoE variant included"""
+    for experts in (0, 4):
+        spec = cf.tiny_spec(f"wide_{dtype}_{experts}", hidden_dim=49152, n_layers=1, n_experts=experts, n_experts_active=2 if experts else 0)
+        tensors, md = cf.synth_model(spec, dtype, seed=12 + experts)
+        model = HostModel(tensors, md)
+        o, b = oracle.OracleBackend(model), HipBackend(model)
+        try:
+            tok = 5
+            for pos in range(6):
+                lo = o.forward(tok, pos, 0)
+                lg = b.forward(tok, pos, 0)
+                assert rel_err(lg, lo) < LOGIT_TOL, (dtype, experts, pos, rel_err(lg, lo))
+                tok = oracle.argmax(lo)
+        finally:
+            b.close()
+            o.close()
+
+
 def test_mistral7b_full_depth_properties(hiplib):
     """BASELINE config 2 at full size (32 layers, 7.1 GB fp8, streamed to the GPU): size-independent
     properties -- bitwise determinism, graph == eager, device decode == host-sampled decode,
