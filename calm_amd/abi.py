@@ -82,6 +82,12 @@ class Transformer(C.Structure):
     pass
 
 
+class Sampler(C.Structure):
+    """reference src/sampler.h:3-9 (include/calm_abi.h)"""
+
+    _fields_ = [("vocab_size", C.c_int), ("rng_state", C.c_ulonglong), ("temperature", C.c_float), ("minp", C.c_float)]
+
+
 FORWARD_FN = C.CFUNCTYPE(_fp, C.POINTER(Transformer), C.c_int, C.c_int, C.c_uint)
 
 Transformer._fields_ = [

@@ -145,6 +145,7 @@ struct Ctx {
 	int q_dim = 0, kv_dim = 0, kv_mul = 0, n_experts = 0, n_active = 0, dbits = 0, kvbits = 0, lpr = 0;
 	// device state
 	float *x = nullptr, *xb = nullptr, *q = nullptr, *att = nullptr, *he = nullptr, *partial = nullptr, *logits_d = nullptr;
+	SampleState* sample_st = nullptr;
 	float *moe_w = nullptr, *rope_freq = nullptr;
 	int *moe_e = nullptr, *next_tok = nullptr, *trace = nullptr, *trace_count = nullptr;
 	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
@@ -422,6 +423,10 @@ void launch_argmax(Ctx* c) {
 	hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, g_stream, c->logits_d, c->vocab, c->next_tok, c->trace, c->trace_count);
 }
 
+void launch_sample(Ctx* c) {
+	hipLaunchKernelGGL(k_sample_minp, dim3(1), dim3(1024), 0, g_stream, c->logits_d, c->vocab, c->next_tok, c->trace, c->trace_count, c->sample_st);
+}
+
 int attn_splits(int kv_len) {
 	if (kv_len <= g_split_min) {
 		return 1;
@@ -463,6 +468,7 @@ uint64_t stage_bytes(Ctx* c, int stage, int kv_len) {
 struct StepPlan {
 	int n_split;
 	bool kv_only, sink, chained, argmax, copy_logits;
+	bool sample; // min-p draw on the device (decode_sample_hip) instead of the arg-max
 };
 
 struct Ctx;
@@ -501,7 +507,9 @@ void enqueue_step(Ctx* c, const StepPlan& sp, bool timed) {
 	if (!sp.kv_only) {
 		launch_output<DB>(c);
 		mark();
-		if (sp.argmax) {
+		if (sp.sample) {
+			launch_sample(c);
+		} else if (sp.argmax) {
 			launch_argmax(c);
 		}
 		if (sp.copy_logits) {
@@ -603,7 +611,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	c->ba.kv_len = kv_len;
 
 	auto replay = [&]() { // the step from its hipGraph (captured on first use), begin-token arguments patched
-		auto key = std::make_tuple(sp.n_split, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.argmax * 2 + (int)sp.copy_logits);
+		auto key = std::make_tuple(sp.n_split, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.sample * 4 + (int)sp.argmax * 2 + (int)sp.copy_logits);
 		GraphEntry& ge = c->graphs[key];
 		if (!ge.exec) {
 			HIP_CHECK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
@@ -1107,6 +1115,7 @@ void prepare_ctx(struct Transformer* t) {
 	c->moe_w = (float*)dev_alloc(CALM_MAX_EXPERTS * sizeof(float));
 	c->moe_e = (int*)dev_alloc(CALM_MAX_EXPERTS * sizeof(int));
 	c->next_tok = (int*)dev_alloc(sizeof(int));
+	c->sample_st = (SampleState*)dev_alloc(sizeof(SampleState));
 	c->trace_count = (int*)dev_alloc(sizeof(int));
 	c->trace_cap = 1 << 16;
 	c->trace = (int*)dev_alloc((size_t)c->trace_cap * sizeof(int));
@@ -1337,7 +1346,7 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (hipEvent_t e : c->events) {
 		HIP_CHECK(hipEventDestroy(e));
 	}
-	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->logits_d, c->moe_w,  c->moe_e,
+	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->sample_st, c->logits_d, c->moe_w,  c->moe_e,
 	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc};
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
@@ -1488,6 +1497,34 @@ extern "C" float* decode_greedy_hip(struct Transformer* t, int token, int pos, i
 	}
 	HIP_CHECK(hipMemcpyAsync(out_tokens, c->trace, (size_t)n_steps * sizeof(int), hipMemcpyDeviceToHost, g_stream));
 	HIP_CHECK(hipStreamSynchronize(g_stream));
+	return c->logits_h;
+}
+
+extern "C" float* decode_sample_hip(struct Transformer* t, int token, int pos, int n_steps, int* out_tokens, struct Sampler* sampler) {
+	CALM_REQUIRE(sampler, "decode_sample_hip: no sampler");
+	if (sampler->temperature == 0.0f || sampler->minp >= 1.0f) { // src/sampler.c:81-83: greedy, no coin drawn
+		return decode_greedy_hip(t, token, pos, n_steps, out_tokens);
+	}
+	Ctx* c = ctx_of(t);
+	CALM_REQUIRE(n_steps > 0 && n_steps <= c->trace_cap, "n_steps out of range");
+	CALM_REQUIRE(sampler->vocab_size == c->vocab, "decode_sample_hip: the sampler's vocab_size is not the model's");
+	SampleState st;
+	st.rng = sampler->rng_state;
+	st.temperature = sampler->temperature;
+	st.cutoff_offset = logf(sampler->minp) * sampler->temperature; // src/sampler.c:52
+	HIP_CHECK(hipMemcpyAsync(c->sample_st, &st, sizeof(st), hipMemcpyHostToDevice, g_stream));
+	HIP_CHECK(hipMemsetAsync(c->trace_count, 0, sizeof(int), g_stream));
+	HIP_CHECK(hipStreamSynchronize(g_stream)); // `st` is a stack object
+	for (int i = 0; i < n_steps; ++i) {
+		StepPlan sp = {};
+		sp.sample = true;
+		sp.copy_logits = (i == n_steps - 1);
+		run_step(c, i == 0 ? token : 0, i == 0 ? nullptr : c->next_tok, pos + i, sp);
+	}
+	HIP_CHECK(hipMemcpyAsync(out_tokens, c->trace, (size_t)n_steps * sizeof(int), hipMemcpyDeviceToHost, g_stream));
+	HIP_CHECK(hipMemcpyAsync(&st, c->sample_st, sizeof(st), hipMemcpyDeviceToHost, g_stream));
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	sampler->rng_state = st.rng;
 	return c->logits_h;
 }
 

@@ -1605,4 +1605,111 @@ __global__ __launch_bounds__(1024) void k_argmax(const float* logits, int n, int
 	}
 }
 
+// ---- min-p sampler on the device (src/sampler.c:44-78, driven as src/sampler.c:80-90) ---------------------------------
+// The host sampler keeps every token whose logit is within log(minp) * temperature of the maximum, weighs the survivors by
+// exp((logit - max) / temperature), and walks their running sum in index order up to coin * total.  Here: a workgroup of 1024
+// threads, thread t owning the contiguous slice of indices [t * per, (t + 1) * per) -- so that "index order" survives: partial
+// sums per slice (each in index order), thread 0 walks the 1024 partials in order, then the slice that contains the draw.
+// The coin comes from the sampler's xorshift* state kept on the device (src/sampler.c:7-18), one draw per sampled token.
+// What differs from the host: expf is the device's (<= 1 ulp from libm's) and the running sum is bracketed per slice, so a draw
+// that lands within a few ulps of a boundary between two survivors may pick the neighbour.  (The reference is compiled with
+// -ffast-math: its own summation order is the compiler's choice.)
+struct SampleState {
+	unsigned long long rng; // src/sampler.h:5
+	float temperature;
+	float cutoff_offset; // logf(minp) * temperature, evaluated on the host (src/sampler.c:52)
+};
+
+__global__ __launch_bounds__(1024) void k_sample_minp(const float* logits, int n, int* next, int* trace, int* trace_count, SampleState* st) {
+	__shared__ float red[16];
+	__shared__ float part[1024];
+	__shared__ int last[1024];
+	const int t = threadIdx.x;
+	const int per = (n + 1023) / 1024;
+	const int i0 = min(t * per, n), i1 = min(i0 + per, n);
+
+	float mx = -3.402823466e+38f; // src/sampler.c:46-49
+	for (int i = t; i < n; i += 1024) {
+		const float v = logits[i];
+		mx = v > mx ? v : mx;
+	}
+	mx = wave_max(mx);
+	if (lane_id() == 0) {
+		red[t >> 6] = mx;
+	}
+	__syncthreads();
+	mx = red[0];
+#pragma unroll
+	for (int w = 1; w < 16; ++w) {
+		mx = fmaxf(mx, red[w]);
+	}
+	const float temperature = st->temperature;
+	const float cutoff = mx + st->cutoff_offset; // src/sampler.c:52
+
+	float sum = 0.f;
+	int lst = -1;
+	for (int i = i0; i < i1; ++i) { // src/sampler.c:58-66 over this slice
+		const float v = logits[i];
+		if (v >= cutoff) {
+			sum += expf((v - mx) / temperature);
+			lst = i;
+		}
+	}
+	part[t] = sum;
+	last[t] = lst;
+	__syncthreads();
+	if (t != 0) {
+		return;
+	}
+	// the coin: xorshift* (src/sampler.c:7-18)
+	unsigned long long s = st->rng;
+	s ^= s >> 12;
+	s ^= s << 25;
+	s ^= s >> 27;
+	st->rng = s;
+	const unsigned u = (unsigned)((s * 0x2545F4914F6CDD1Dull) >> 32);
+	const float coin = (float)(u >> 8) / 16777216.0f;
+
+	float total = 0.f;
+	int fallback = 0;
+	for (int k = 0; k < 1024; ++k) {
+		total += part[k];
+		fallback = last[k] >= 0 ? last[k] : fallback; // the last survivor (src/sampler.c:62)
+	}
+	const float r = coin * total; // src/sampler.c:69
+	float cdf = 0.f;
+	int pick = -1;
+	for (int k = 0; k < 1024 && pick < 0; ++k) {
+		if (last[k] < 0) {
+			continue;
+		}
+		if (r < cdf + part[k]) { // the draw falls into slice k: walk it (src/sampler.c:71-76)
+			const int a = min(k * per, n), b = min(a + per, n);
+			for (int i = a; i < b; ++i) {
+				const float v = logits[i];
+				if (v >= cutoff) {
+					cdf += expf((v - mx) / temperature);
+					if (r < cdf) {
+						pick = i;
+						break;
+					}
+				}
+			}
+			if (pick < 0) {
+				pick = last[k]; // rounding between the bracketed and the running sum
+			}
+		} else {
+			cdf += part[k];
+		}
+	}
+	if (pick < 0) {
+		pick = fallback;
+	}
+	*next = pick;
+	if (trace) {
+		const int slot = (*trace_count)++;
+		trace[slot] = pick;
+	}
+}
+
 } // namespace calm

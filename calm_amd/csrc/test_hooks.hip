@@ -127,6 +127,24 @@ extern "C" int calm_hip_test_argmax(const float* logits, int n) {
 	return r;
 }
 
+extern "C" int calm_hip_test_sample(const float* logits, int n, float temperature, float minp, unsigned long long* rng_state) {
+	init_hip();
+	float* dl = (float*)upload_hip((void*)logits, n * sizeof(float));
+	int* dn = (int*)dev_alloc(2 * sizeof(int));
+	HIP_CHECK(hipMemset(dn, 0, 2 * sizeof(int)));
+	SampleState st;
+	st.rng = *rng_state, st.temperature = temperature, st.cutoff_offset = logf(minp) * temperature;
+	SampleState* ds = (SampleState*)upload_hip(&st, sizeof(st));
+	hipLaunchKernelGGL(k_sample_minp, dim3(1), dim3(1024), 0, g_stream, dl, n, dn, (int*)nullptr, dn + 1, ds);
+	HIP_CHECK(hipGetLastError());
+	int r = -2;
+	download_hip(&r, dn, sizeof(int));
+	download_hip(&st, ds, sizeof(st));
+	*rng_state = st.rng;
+	free_hip(dl), free_hip(dn), free_hip(ds);
+	return r;
+}
+
 namespace {
 
 // the backend's private cache layout, from what struct Transformer shows: [layer][kv_head][seq_len][head_dim], 2 or 1 bytes

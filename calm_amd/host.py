@@ -29,10 +29,10 @@ TEST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcal
 # include/calm_hip.h: the drop-in library
 EXPORTS = [
     "init_hip", "upload_hip", "alloc_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
-    "free_hip", "download_hip", "decode_greedy_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip",
+    "free_hip", "download_hip", "decode_greedy_hip", "decode_sample_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip",
 ]
 # include/calm_hip_test.h: libcalm_hip_test.so, tests and tools only
-TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_membench"]
+TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_test_sample", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_membench"]
 
 
 class _Libs:
@@ -61,6 +61,7 @@ class _Libs:
                 "calm_hip_test_norm_matvec": (None, [C.c_int, C.c_void_p, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int]),
                 "calm_hip_test_attn": (None, [fp, C.c_void_p, C.c_void_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
                 "calm_hip_test_argmax": (C.c_int, [fp, C.c_int]),
+                "calm_hip_test_sample": (C.c_int, [fp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_ulonglong)]),
                 "calm_hip_read_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
                 "calm_hip_write_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
                 "calm_hip_membench": (C.c_double, [C.c_size_t, C.c_int, C.c_int]),
@@ -98,6 +99,7 @@ def load_lib() -> "_Libs":
         "free_hip": (None, [C.c_void_p]),
         "download_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
         "decode_greedy_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]),
+        "decode_sample_hip": (fp, [T, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(abi.Sampler)]),
         "prefill_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int]),
         "prefill_logprobs_hip": (None, [T, C.POINTER(C.c_int), C.c_int, C.c_int, fp]),
         "forward_stage_hip": (fp, [T, C.c_int, C.c_int, C.c_uint, C.c_uint]),
@@ -326,6 +328,12 @@ class HipBackend:
     def decode_greedy(self, token: int, pos: int, n_steps: int):
         out = (C.c_int * n_steps)()
         p = self.lib.decode_greedy_hip(C.byref(self.t), token, pos, n_steps, out)
+        return np.array(out[:], dtype=np.int64), np.ctypeslib.as_array(p, shape=(self.vocab,))
+
+    def decode_sample(self, token: int, pos: int, n_steps: int, sampler: "abi.Sampler"):
+        """n_steps tokens drawn on the device as src/sampler.c:80-90 draws them; `sampler.rng_state` is advanced"""
+        out = (C.c_int * n_steps)()
+        p = self.lib.decode_sample_hip(C.byref(self.t), token, pos, n_steps, out, C.byref(sampler))
         return np.array(out[:], dtype=np.int64), np.ctypeslib.as_array(p, shape=(self.vocab,))
 
     def prefill(self, tokens, pos: int) -> None:

@@ -98,6 +98,14 @@ enum ForwardFlags {
 	FF_UPDATE_KV_ONLY = 1 << 0, /* run every layer (KV append included) but skip final norm + classifier; return NULL */
 };
 
+/* reference src/sampler.h:3-9 -- what the host program hands to sample(); decode_sample_hip takes the same object */
+struct Sampler {
+	int vocab_size;
+	unsigned long long rng_state; /* xorshift* state, advanced once per sampled token (src/sampler.c:7-18,84) */
+	float temperature;            /* 0 => greedy */
+	float minp;                   /* >= 1 => greedy */
+};
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,14 @@ void download_hip(void* host, const void* device, size_t size);
  * token ids to out_tokens; returns state.logits of the last step. */
 float* decode_greedy_hip(struct Transformer* transformer, int token, int pos, int n_steps, int* out_tokens);
 
+/* The same with the reference's sampler on the device: n_steps tokens, each drawn as sample(sampler, logits) would draw it
+ * (src/sampler.c:80-90: greedy when temperature == 0 or minp >= 1, else one xorshift* coin and the min-p cut of
+ * src/sampler.c:44-78), the draw fed back as the next token without a host round trip.  sampler->rng_state comes back
+ * advanced by the coins that were drawn, as the host loop would leave it.  Against the host sampler on the same logits the
+ * draw can differ only when the coin lands within rounding of a boundary between two surviving tokens (the device's expf
+ * and a bracketed running sum; the reference's own sum is compiled -ffast-math). */
+float* decode_sample_hip(struct Transformer* transformer, int token, int pos, int n_steps, int* out_tokens, struct Sampler* sampler);
+
 /* Batched prompt ingestion: the KV-cache effect of
  *     for (i = 0; i < n; ++i) forward_hip(transformer, tokens[i], pos + i, FF_UPDATE_KV_ONLY);
  * i.e. of the reference's serial prompt loop (src/run.c:208,216-218; README.md:80 "prompt processing is

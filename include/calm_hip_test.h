@@ -35,6 +35,8 @@ void calm_hip_test_attn(const float* q, const uint16_t* kcache, const uint16_t* 
 
 /* first index of the strict maximum (reference src/sampler.c:34-42), computed on the device */
 int calm_hip_test_argmax(const float* logits, int n);
+/* k_sample_minp alone on n host logits: one draw, *rng_state advanced (sampler as in src/sampler.h) */
+int calm_hip_test_sample(const float* logits, int n, float temperature, float minp, unsigned long long* rng_state);
 
 /* Re-layout helper: reads the K or V cache of one layer of a transformer prepared by libcalm_hip.so into the oracle's
  * [seq_len][kv_dim] layout (host) as binary16 patterns -- an fp8 cache's e5m2 bytes widened (byte << 8).  which: 0 = K, 1 = V. */

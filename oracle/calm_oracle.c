@@ -513,6 +513,56 @@ float* oracle_forward(struct Transformer* t, int token, int pos, unsigned flags)
 	return oracle_forward_stage(t, token, pos, flags, 3u);
 }
 
+/* xorshift* generator and the [0,1) coin; reference src/sampler.c:7-18 */
+static unsigned int oracle_random_u32(unsigned long long* state) {
+	unsigned long long s = *state;
+	s ^= s >> 12;
+	s ^= s << 25;
+	s ^= s >> 27;
+	*state = s;
+	return (unsigned int)((s * 0x2545F4914F6CDD1Dull) >> 32);
+}
+
+/* min-p sampling; reference src/sampler.c:44-78.  Leaves `logits` alone (the reference overwrites it with the unscaled
+ * probabilities, :56) -- the checker's callers compare logits afterwards. */
+static int oracle_sample_minp(const float* logits, int n, float minp, float temperature, float coin) {
+	float max_logit = -FLT_MAX;
+	for (int i = 0; i < n; i++) {
+		max_logit = logits[i] > max_logit ? logits[i] : max_logit;
+	}
+	float logit_cutoff = max_logit + logf(minp) * temperature; /* :52 */
+	int fallback = 0;
+	float cumulative_prob = 0.0f;
+	for (int i = 0; i < n; i++) { /* :58-66 */
+		if (logits[i] >= logit_cutoff) {
+			cumulative_prob += expf((logits[i] - max_logit) / temperature);
+			fallback = i;
+		}
+	}
+	float r = coin * cumulative_prob; /* :69 */
+	float cdf = 0.0f;
+	for (int i = 0; i < n; i++) { /* :71-76 */
+		if (logits[i] >= logit_cutoff) {
+			cdf += expf((logits[i] - max_logit) / temperature);
+			if (r < cdf) {
+				return i;
+			}
+		}
+	}
+	return fallback;
+}
+
+int oracle_argmax(const float* logits, int n);
+
+/* one draw of the host sampler; reference src/sampler.c:80-90.  *rng_state advances only when a coin is drawn. */
+int oracle_sample(const float* logits, int n, float temperature, float minp, unsigned long long* rng_state) {
+	if (temperature == 0.0f || minp >= 1.0f) {
+		return oracle_argmax(logits, n);
+	}
+	float coin = (float)(oracle_random_u32(rng_state) >> 8) / 16777216.0f; /* :16-18 */
+	return oracle_sample_minp(logits, n, minp, temperature, coin);
+}
+
 /* greedy sampler: first index of the strict maximum; reference src/sampler.c:34-42 */
 int oracle_argmax(const float* logits, int n) {
 	int max_i = -1;

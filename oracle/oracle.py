@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
         L.oracle_forward_stage.argtypes = [_T, C.c_int, C.c_int, C.c_uint, C.c_uint]
         L.oracle_argmax.restype = C.c_int
         L.oracle_argmax.argtypes = [_fp, C.c_int]
+        L.oracle_sample.restype = C.c_int
+        L.oracle_sample.argtypes = [_fp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_ulonglong)]
         _lib = L
     return _lib
 
@@ -133,6 +135,14 @@ def moe_gate(logits: np.ndarray, active: int):
 def argmax(logits: np.ndarray) -> int:
     logits = np.ascontiguousarray(logits, dtype=np.float32)
     return lib().oracle_argmax(_f(logits), logits.size)
+
+
+def sample(logits: np.ndarray, temperature: float, minp: float, rng_state: int):
+    """one draw of the host sampler (src/sampler.c:80-90) -> (token, advanced rng state)"""
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    st = C.c_ulonglong(rng_state)
+    tok = lib().oracle_sample(_f(logits), logits.size, temperature, minp, C.byref(st))
+    return tok, st.value
 
 
 # ---- whole-model backends ----------------------------------------------------------------------

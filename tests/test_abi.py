@@ -54,6 +54,35 @@ def test_layout_matches_reference_model_h(tmp_path):
     assert _offsets(os.path.join(REFERENCE, "src", "model.h"), tmp_path, "ref") == abi.FROZEN_LAYOUT
 
 
+SAMPLER_PROG = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include HDR
+int main(void) {
+	printf("%zu %zu %zu %zu %zu\n", sizeof(struct Sampler), offsetof(struct Sampler, vocab_size), offsetof(struct Sampler, rng_state),
+	       offsetof(struct Sampler, temperature), offsetof(struct Sampler, minp));
+	return 0;
+}
+"""
+
+
+def _sampler_layout(header, tmp_path, tag):
+    src = tmp_path / f"smp_{tag}.c"
+    src.write_text(SAMPLER_PROG)
+    exe = tmp_path / f"smp_{tag}"
+    subprocess.run(["gcc", f'-DHDR="{header}"', str(src), "-o", str(exe)], check=True)
+    return [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+
+
+def test_sampler_struct_layout(tmp_path):
+    """struct Sampler (decode_sample_hip's argument): include/calm_abi.h == the ctypes mirror == the reference's src/sampler.h"""
+    ours = _sampler_layout(os.path.join(ROOT, "include", "calm_abi.h"), tmp_path, "ours")
+    S = abi.Sampler
+    assert ours == [C.sizeof(S), S.vocab_size.offset, S.rng_state.offset, S.temperature.offset, S.minp.offset] == [24, 0, 8, 16, 20]
+    if os.path.isdir(REFERENCE):
+        assert _sampler_layout(os.path.join(REFERENCE, "src", "sampler.h"), tmp_path, "ref") == ours
+
+
 def _declared_functions(header):
     text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
