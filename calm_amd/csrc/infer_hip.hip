@@ -697,7 +697,7 @@ void pf_alloc(Ctx* c) {
 	if (c->pf_x) {
 		return;
 	}
-	// fragment-major matrices (prefill.hip.h: pf_idx) are sized in whole 64-column steps and zeroed once:
+	// fragment-major matrices (prefill.hip.h: pf_unit) are sized in whole 64-column steps and zeroed once:
 	// their padding is read as a multiplicand of zero weights and must stay finite
 	auto frag = [&](int n, int rows) {
 		size_t bytes = (size_t)rows * pf_steps(n) * 64 * sizeof(float);

@@ -5,10 +5,13 @@
 // -- the KV cache rows of n consecutive positions -- up to PF_NT tokens at a time, so that every weight byte
 // is streamed once per chunk instead of once per token, and the multiply-adds move to the matrix cores.
 //
-// Numerics stay those of the decode path: fp32 activations, exactly decoded weights, fp32 accumulation.
-// v_mfma_f32_32x32x2_f32 takes f32 A and B operands and is bit-for-bit an fmaf chain (157 TF dense peak
-// on this chip); the activations are NOT narrowed to fp16 / bf16 to reach the 16x faster MFMA forms --
-// that costs 3e-4..2e-3 per matvec and breaks the 1e-3 logits parity with the CPU path.
+// Numerics: exactly decoded weights (all three formats are exact in binary16), fp32 accumulation, and the fp32
+// activations as the SUM OF TWO binary16 numbers, x = hi + lo with hi = half(x), lo = half(x - hi): 22 significand
+// bits, |x - (hi + lo)| <= 2^-22 |x| (2^-25 absolute below 2^-14).  Each weight x activation product is then two
+// v_mfma_f32_32x32x16_f16 products, both exact in fp32 -- 16x the rate of the f32 MFMA form for twice the
+// instructions.  Narrowing the activations to ONE fp16 / bf16 number costs 3e-4..2e-3 per matvec and breaks the
+// 1e-3 logits parity with the CPU path; the split measures 4..8e-7 (tools/hilo_study.py), the same as the f32
+// MFMA form this file used before (bit-for-bit an fmaf chain, 157 TF peak).  Activations beyond +-65504 saturate.
 //
 // GEMM structure (k_pf_gemm).  A wave owns NA x 2 accumulator tiles of 32 units x 32 tokens: NA = 1..3 unit
 // strips (QKV, residual, classifier GEMMs; the count that wastes the fewest workgroup rounds) or the w1 / w3 pair
@@ -17,9 +20,9 @@
 // MFMA peak with the operand fetch in the way).  The four waves of a workgroup split the reduction dimension
 // (wave w takes every 4th sub-step of a row) and add their partial tiles through LDS in a fixed order.
 // Operands go global -> registers:
-//   A  consecutive weights of this lane's row (lane = unit i, k-half kk), decoded to f32;
-//   B  the matching activations of token j (lane = token j, k-half kk) from a FRAGMENT-MAJOR activation
-//      matrix (pf_idx below): a wave's 16-byte loads are 1 KiB contiguous, and the matrix is L2 resident.
+//   A  consecutive weights of this lane's row (lane = unit i, k-half kk), 8 per MFMA, decoded to binary16;
+//   B  the matching activations of token j (lane = token j, k-half kk), hi and lo, from a FRAGMENT-MAJOR activation
+//      matrix (pf_unit below): a wave's 16-byte loads are 1 KiB contiguous, and the matrix is L2 resident.
 // The k order inside the dot product is permuted (both operands agree), which fp32 addition does not mind
 // beyond rounding.  Operands of the next sub-step are loaded (double buffer, scheduling barrier) before the
 // current one's 64..192 MFMAs are issued.  Mixture-of-experts layers run the same kernel as a grouped GEMM
@@ -29,20 +32,55 @@
 namespace calm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
 
 enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3 };
 constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
 
-// Fragment-major activation matrix of n-float rows (GEMM B operand).  The float4 holding columns k..k+3
-// (k % 4 == 0) of token t lives at float4 index
-//     ((t / 32 * nsteps + k / 64) * 8 + k % 32 / 4) * 64 + (k % 64 / 32) * 32 + t % 32,   nsteps = ceil(n / 64)
-// i.e. [token group of 32][step of 64 columns][float4 q of the lane's 32 columns][lane = (k-half, token)]:
-// exactly the order in which a wave's lanes consume it.  Rows are padded to whole steps; the padding is
-// never written and stays zero from the allocation.
-__device__ __forceinline__ size_t pf_idx(int t, int k, int nsteps) {
-	return ((((size_t)(t >> 5) * nsteps + (k >> 6)) * 8 + ((k & 31) >> 2)) << 6) + (((k >> 5) & 1) << 5) + (t & 31);
+// Fragment-major activation matrix of rows of n values (GEMM B operand), every value as two binary16 numbers.
+// The 16-byte unit holding the hi halves of columns k..k+7 (k % 8 == 0) of token t lives at unit index
+//     (((t / 32 * nsteps + k / 64) * 4 + k % 32 / 8) * 2 + 0) * 64 + (k % 64 / 32) * 32 + t % 32,   nsteps = ceil(n / 64)
+// and the unit with their lo halves 64 units further: [token group of 32][step of 64 columns][MFMA m of the lane's 32
+// columns][hi, lo][lane = (k-half, token)] -- exactly the order in which a wave's lanes consume it, 8 KiB per (group,
+// step) like the fp32 values it stands for.  Rows are padded to whole steps; the padding is never written and stays
+// zero from the allocation.
+__device__ __forceinline__ size_t pf_unit(int t, int k, int nsteps) {
+	return ((((size_t)(t >> 5) * nsteps + (k >> 6)) * 4 + ((k & 31) >> 3)) << 7) + (((k >> 5) & 1) << 5) + (t & 31);
+}
+// x = hi + lo, two binary16 numbers each (saturating at the binary16 range)
+__device__ __forceinline__ void pf_split2(float a, float b, unsigned& hi, unsigned& lo) {
+	a = fminf(fmaxf(a, -65504.f), 65504.f);
+	b = fminf(fmaxf(b, -65504.f), 65504.f);
+	const __half2 h = __floats2half2_rn(a, b);
+	const float2 hf = __half22float2(h);
+	const __half2 l = __floats2half2_rn(a - hf.x, b - hf.y);
+	hi = __builtin_bit_cast(unsigned, h);
+	lo = __builtin_bit_cast(unsigned, l);
+}
+// columns k..k+7 of token t <- v[0..7]
+__device__ __forceinline__ void pf_store8(void* m, int t, int k, int nsteps, const float (&v)[8]) {
+	u32x4 hi, lo;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		unsigned h, l;
+		pf_split2(v[2 * i], v[2 * i + 1], h, l);
+		hi[i] = h, lo[i] = l;
+	}
+	u32x4* u = (u32x4*)m + pf_unit(t, k, nsteps);
+	u[0] = hi;
+	u[64] = lo;
+}
+// columns k..k+3 (k % 4 == 0) of token t <- v[0..3]: half a unit
+__device__ __forceinline__ void pf_store4(void* m, int t, int k, int nsteps, const float (&v)[4]) {
+	unsigned h0, l0, h1, l1;
+	pf_split2(v[0], v[1], h0, l0);
+	pf_split2(v[2], v[3], h1, l1);
+	const u32x2 hi = {h0, h1}, lo = {l0, l1};
+	u32x2* u = (u32x2*)((u32x4*)m + pf_unit(t, k & ~7, nsteps)) + ((k >> 2) & 1);
+	u[0] = hi;
+	u[128] = lo;
 }
 __host__ __device__ inline int pf_steps(int n) {
 	return (n + 63) >> 6;
@@ -64,7 +102,7 @@ __global__ void k_pf_begin(const int* tokens, int pos0, float* X, const void* em
 }
 
 // out (fragment-major) = norm(X[b][:]) * normw, one workgroup per token   (src/infer.c:183-207)
-__global__ __launch_bounds__(256) void k_pf_norm(float4* out, const float* X, const float* normw, int n, float eps, int ln) {
+__global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, const float* normw, int n, float eps, int ln) {
 	__shared__ float red[16];
 	const int b = blockIdx.x;
 	const float4* x4 = (const float4*)(X + (size_t)b * n);
@@ -88,13 +126,17 @@ __global__ __launch_bounds__(256) void k_pf_norm(float4* out, const float* X, co
 	float var = block_sum<256>(ss, red) / (float)n;
 	float scale = 1.0f / sqrtf(var + eps);
 	const int nsteps = pf_steps(n);
-	for (int i = threadIdx.x; i < n4; i += 256) {
-		float4 t = x4[i], g = w4[i];
-		t.x = (t.x - mean) * scale * g.x;
-		t.y = (t.y - mean) * scale * g.y;
-		t.z = (t.z - mean) * scale * g.z;
-		t.w = (t.w - mean) * scale * g.w;
-		out[pf_idx(b, 4 * i, nsteps)] = t;
+	for (int i = threadIdx.x; i < (n >> 3); i += 256) { // n is a multiple of 32
+		float v[8];
+#pragma unroll
+		for (int h = 0; h < 2; ++h) {
+			const float4 t = x4[2 * i + h], g = w4[2 * i + h];
+			v[4 * h] = (t.x - mean) * scale * g.x;
+			v[4 * h + 1] = (t.y - mean) * scale * g.y;
+			v[4 * h + 2] = (t.z - mean) * scale * g.z;
+			v[4 * h + 3] = (t.w - mean) * scale * g.w;
+		}
+		pf_store8(out, b, 8 * i, nsteps, v);
 	}
 }
 
@@ -184,8 +226,9 @@ __global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* sr
 	if (t < 0) {
 		return;
 	}
-	for (int k4 = threadIdx.x; k4 < (n >> 2); k4 += 256) {
-		dst[pf_idx(r, 4 * k4, nsteps)] = src[pf_idx(t, 4 * k4, nsteps)];
+	for (int k4 = threadIdx.x; k4 < (n >> 2); k4 += 256) { // the hi units of a row, then its lo units: all of them
+		const int k = (k4 >> 1) * 8, hl = (k4 & 1) * 64;
+		dst[pf_unit(r, k, nsteps) + hl] = src[pf_unit(t, k, nsteps) + hl];
 	}
 }
 
@@ -207,7 +250,7 @@ __global__ __launch_bounds__(256) void k_pf_combine(float* X, const float* Y, co
 // The decode kernel k_attn with a query dimension: one workgroup per (head, group of TQ consecutive tokens).
 // Every cached K / V row is loaded once and used for all TQ queries (per-token launches of k_attn were bound
 // by L2 bandwidth: 256 tokens x 32 heads each streaming the whole context).  Query b attends to rows
-// [0, pf_kv0 + b]; rows past a query's own position are masked.  Output: fragment-major rows (pf_idx).
+// [0, pf_kv0 + b]; rows past a query's own position are masked.  Output: fragment-major rows (pf_unit).
 constexpr int PF_ATTN_BLOCK = 512; // 8 waves: 256 VGPRs per lane for the TQ query states (16 waves spill)
 template <int LPR>
 struct PfAttn {
@@ -371,10 +414,11 @@ __global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
 			sm_merge(mm, ll, oo, sm_m[q][w], sm_l[q][w], o2);
 		}
 		if (dvalid) {
-			const int k = h * a.head_dim + d0, ns = pf_steps(a.pf_stride);
-			float4* out4 = (float4*)a.out;
-			out4[pf_idx(b0 + q, k, ns)] = make_float4(oo[0] / ll, oo[1] / ll, oo[2] / ll, oo[3] / ll);
-			out4[pf_idx(b0 + q, k + 4, ns)] = make_float4(oo[4] / ll, oo[5] / ll, oo[6] / ll, oo[7] / ll);
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				oo[i] /= ll;
+			}
+			pf_store8(a.out, b0 + q, h * a.head_dim + d0, pf_steps(a.pf_stride), oo);
 		}
 	}
 }
@@ -408,7 +452,7 @@ __global__ __launch_bounds__(256) void k_pf_logprob(const float* logits, int voc
 }
 
 struct PfGemmArgs {
-	const float4* xin;   // fragment-major activations (pf_idx), rows of K floats
+	const float4* xin;   // fragment-major activations (pf_unit), rows of K values as hi + lo binary16
 	const void *w0, *w1, *w2; // QKV: wq, wk, wv;  FFN_UP: w1, w3;  RESID: the matrix
 	int K, M, nb;        // reduction length, output units, valid tokens
 	float* out;          // QKV: Q [token][q_dim];  RESID: X [token][M] (accumulated into);  FFN_UP: H, fragment-major rows of M
@@ -424,32 +468,33 @@ struct PfGemmArgs {
 	size_t expert_stride;
 };
 
-// one 16-byte piece of a weight row -> its G weights as f32 (exact in all three formats)
+// operand j of a 16-byte piece of a weight row: 8 consecutive weights as binary16 (exact in all three formats).
+// A piece holds G / 8 operands: one (fp16), two (fp8), four (gf4: one per word).
 template <int DB>
-__device__ __forceinline__ void pf_decode(u32x4 v, float (&wf)[Fmt<DB>::G]) {
+__device__ __forceinline__ f16x8 pf_operand(u32x4 v, int j) {
+	u32x4 r;
 	if constexpr (DB == 16) {
+		r = v;
+	} else if constexpr (DB == 8) { // e5m2 is the upper byte of binary16 (src/infer.c:28-31)
+		const unsigned w0 = v[2 * j], w1 = v[2 * j + 1];
+		r[0] = __builtin_amdgcn_perm(w0, w0, 0x050c040cu);
+		r[1] = __builtin_amdgcn_perm(w0, w0, 0x070c060cu);
+		r[2] = __builtin_amdgcn_perm(w1, w1, 0x050c040cu);
+		r[3] = __builtin_amdgcn_perm(w1, w1, 0x070c060cu);
+	} else { // src/infer.c:33-40: w_k = (code_k - 4) * s, s = fp8(low byte) / -4; both factors and the product are exact in binary16
+		const unsigned w = v[j];
+		const __half sh = __float2half_rn(bf8_byte0(w) * -0.25f);
+		const __half2 s2 = __halves2half2(sh, sh);
+		const __half2 off = __builtin_bit_cast(__half2, 0xe404e404u); // (-1028, -1028)
 #pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			wf[2 * i] = half_bits_to_float((unsigned short)(v[i] & 0xffff));
-			wf[2 * i + 1] = half_bits_to_float((unsigned short)(v[i] >> 16));
-		}
-	} else if constexpr (DB == 8) {
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			f32x2 lo = bf8x2_lo(v[i]), hi = bf8x2_hi(v[i]);
-			wf[4 * i] = lo[0], wf[4 * i + 1] = lo[1], wf[4 * i + 2] = hi[0], wf[4 * i + 3] = hi[1];
-		}
-	} else {
-#pragma unroll
-		for (int i = 0; i < 4; ++i) {
-			float s = bf8_byte0(v[i]) * -0.25f; // src/infer.c:37-40
-#pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				int q = (int)((v[i] >> (8 + 3 * k)) & 7) - 4;
-				wf[8 * i + k] = (float)q * s;
-			}
+		for (int pr = 0; pr < 4; ++pr) {
+			// codes 2pr, 2pr+1 -> the low mantissa bits of (1024, 1024): 1024 + code, an integer
+			const unsigned two = (w >> (8 + 6 * pr)) & 0x3fu;
+			const unsigned h2 = ((two * 0x2001u) & 0x00070007u) | 0x64006400u;
+			r[pr] = __builtin_bit_cast(unsigned, __hmul2(__hadd2(__builtin_bit_cast(__half2, h2), off), s2));
 		}
 	}
+	return __builtin_bit_cast(f16x8, r);
 }
 
 // Weight streams per wave: S strips of 32 units (S = 1..3, whichever wastes the fewest workgroup rounds), except
@@ -465,9 +510,10 @@ template <int DB, int KVB, int EPI, int S>
 __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 	constexpr int G = Fmt<DB>::G;
 	constexpr int P = 32 / G; // 16-byte pieces of a row per lane and 64-column step (32 weights per k-half)
+	constexpr int OPP = G / 8; // MFMA operands (8 weights) per piece
 	// a wave's unit of work is a SUB-step: 1 / HS of a step (16 weights per k-half for fp16 / fp8), which halves
 	// the operand registers in flight so that two workgroups fit a CU (one wave per SIMD left every stall exposed)
-	constexpr int HS = (P >= 2 && S < 3) ? 2 : 1, PH = P / HS, QH = 8 / HS;
+	constexpr int HS = (P >= 2 && S < 3) ? 2 : 1, PH = P / HS, QH = 8 / HS; // QH = 2 (hi, lo) * PH * OPP units of B per token tile
 	constexpr int NA = PfTile<EPI, S>::NA, NC = 2;
 	__shared__ float part[2][NA * NC * 16][64]; // partial tiles in flight during the two-round reduction (16 KiB per stream)
 
@@ -485,7 +531,7 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 	}
 	const size_t row_bytes = (size_t)a.K * DB / 8;
 	const int npieces = a.K / G;      // 16-byte pieces per row
-	const int nsteps = pf_steps(a.K); // a step = 64 weights of a row = 32 MFMAs per accumulator tile
+	const int nsteps = pf_steps(a.K); // a step = 64 weights of a row = 4 (x hi, lo) MFMAs per accumulator tile
 
 	// A: this lane's weight rows.  Row indices are clamped, never branched on: surplus lanes read real data
 	// and their results are dropped in the epilogue.
@@ -509,7 +555,7 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 
 	struct Frag {
 		u32x4 w[NA][PH];
-		f32x4 x[NC][QH];
+		u32x4 x[NC][QH]; // [MFMA of the sub-step][hi, lo]
 	};
 	const int nsub = nsteps * HS;
 	auto load = [&](Frag& f, int u) {
@@ -526,7 +572,7 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 		}
 #pragma unroll
 		for (int c = 0; c < NC; ++c) {
-			const f32x4* xp = (const f32x4*)(xg + ((size_t)c * nsteps + sc) * 512 + h * QH * 64);
+			const u32x4* xp = (const u32x4*)(xg + ((size_t)c * nsteps + sc) * 512 + h * QH * 64);
 #pragma unroll
 			for (int q = 0; q < QH; ++q) {
 				f.x[c][q] = xp[q * 64];
@@ -550,22 +596,29 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 #pragma unroll
 		for (int i = 0; i < PH; ++i) {
 			const bool valid = p0 + i < npieces; // ragged rows: pieces past the row's end multiply as zeros
-			float wf[NA][G];
+			u32x4 v[NA];
 #pragma unroll
 			for (int n = 0; n < NA; ++n) {
-				u32x4 v = f.w[n][i];
+				v[n] = f.w[n][i];
 				if (!valid) {
-					v = (u32x4){0u, 0u, 0u, 0u}; // decodes to zeros in every format
+					v[n] = (u32x4){0u, 0u, 0u, 0u}; // decodes to zeros in every format
 				}
-				pf_decode<DB>(v, wf[n]);
 			}
 #pragma unroll
-			for (int e = 0; e < G; ++e) {
+			for (int j = 0; j < OPP; ++j) {
+				f16x8 wa[NA];
 #pragma unroll
 				for (int n = 0; n < NA; ++n) {
+					wa[n] = pf_operand<DB>(v[n], j);
+				}
 #pragma unroll
-					for (int c = 0; c < NC; ++c) {
-						acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[n][e], f.x[c][(i * G + e) / 4][(i * G + e) % 4], acc[n][c], 0, 0, 0);
+				for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+					for (int n = 0; n < NA; ++n) {
+#pragma unroll
+						for (int c = 0; c < NC; ++c) {
+							acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[n], __builtin_bit_cast(f16x8, f.x[c][(i * OPP + j) * 2 + hl]), acc[n][c], 0, 0, 0);
+						}
 					}
 				}
 			}
@@ -666,7 +719,7 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 						float up = acc[0][c][4 * g + e], gt = acc[1][c][4 * g + e];
 						h[e] = (a.gelu ? act_gelu(up) : act_silu(up)) * gt; // src/infer.c:440-450
 					}
-					((float4*)a.out)[pf_idx(token, ub, pf_steps(a.M))] = make_float4(h[0], h[1], h[2], h[3]);
+					pf_store4(a.out, token, ub, pf_steps(a.M), h);
 				} else {
 #pragma unroll
 					for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
