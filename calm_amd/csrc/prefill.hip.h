@@ -466,6 +466,7 @@ struct PfGemmArgs {
 	// multiplies by the matrices of expert col_expert[c] (w0 / w1 + expert * expert_stride bytes)
 	const int* col_expert;
 	size_t expert_stride;
+	int ncols; // k_pf_gemm_wide: token columns of the launch (its grid is one-dimensional)
 };
 
 // operand j of a 16-byte piece of a weight row: 8 consecutive weights as binary16 (exact in all three formats).
@@ -495,6 +496,85 @@ __device__ __forceinline__ f16x8 pf_operand(u32x4 v, int j) {
 		}
 	}
 	return __builtin_bit_cast(f16x8, r);
+}
+
+// Epilogue of a wave's NA x NC accumulator tiles (32 units x 32 tokens each; FFN-up: NA = 2 are w1 and w3 of one strip).
+// C layout: column (token) = lane & 31, row (unit) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+template <int KVB, int EPI, int NA, int NC>
+__device__ __forceinline__ void pf_epilogue(const PfGemmArgs& a, const f32x16 (&acc)[NA][NC], const int unit0, const int tok0, const int j, const int kk) {
+	const int nb = a.nb;
+#pragma unroll
+	for (int c = 0; c < NC; ++c) {
+		const int token = tok0 + 32 * c + j;
+		if (token >= nb) {
+			continue;
+		}
+#pragma unroll
+		for (int n = 0; n < (EPI == PF_EPI_FFN_UP ? 1 : NA); ++n) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				const int ub = unit0 + 32 * n + 8 * g + 4 * kk; // four consecutive units; M is a multiple of 4
+				if (ub >= a.M) {
+					continue;
+				}
+				if constexpr (EPI == PF_EPI_RESID) {
+					float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
+					float4 t = *p;
+					t.x += acc[n][c][4 * g], t.y += acc[n][c][4 * g + 1], t.z += acc[n][c][4 * g + 2], t.w += acc[n][c][4 * g + 3];
+					*p = t;
+				} else if constexpr (EPI == PF_EPI_STORE) { // M is arbitrary here (a vocabulary): scalar, bounded stores
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						if (ub + e < a.M) {
+							a.out[(size_t)token * a.M + ub + e] = acc[n][c][4 * g + e];
+						}
+					}
+				} else if constexpr (EPI == PF_EPI_FFN_UP) {
+					float h[4];
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						float up = acc[0][c][4 * g + e], gt = acc[1][c][4 * g + e];
+						h[e] = (a.gelu ? act_gelu(up) : act_silu(up)) * gt; // src/infer.c:440-450
+					}
+					pf_store4(a.out, token, ub, pf_steps(a.M), h);
+				} else {
+#pragma unroll
+					for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
+						const int uu = ub + 2 * pr;
+						float v0 = acc[n][c][4 * g + 2 * pr], v1 = acc[n][c][4 * g + 2 * pr + 1];
+						if (a.bqkv) {
+							v0 += a.bqkv[uu];
+							v1 += a.bqkv[uu + 1];
+						}
+						v0 = clipf(v0, a.clip);
+						v1 = clipf(v1, a.clip);
+						if (uu < a.q_dim + a.kv_dim) { // src/infer.c:223-236
+							const int ul = uu < a.q_dim ? uu : uu - a.q_dim;
+							const float2 cs = a.rope[(size_t)token * (a.head_dim >> 1) + ((ul % a.head_dim) >> 1)];
+							const float r0 = v0 * cs.x - v1 * cs.y, r1 = v0 * cs.y + v1 * cs.x;
+							v0 = r0, v1 = r1;
+						}
+						if (uu < a.q_dim) {
+							*(float2*)(a.out + (size_t)token * a.q_dim + uu) = make_float2(v0, v1);
+						} else {
+							int jl = uu - a.q_dim;
+							void* cache = a.kc;
+							if (jl >= a.kv_dim) {
+								jl -= a.kv_dim;
+								cache = a.vc;
+							}
+							const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
+							if constexpr (KVB == 16) {
+								*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // src/infer.c:378-381
+							} else {
+								*(unsigned short*)((unsigned char*)cache + off) = e5m2x2_sat(v0, v1);
+							}
+						}
+					}
+				}
+			}
+		}
+	}
 }
 
 // Weight streams per wave: S strips of 32 units (S = 1..3, whichever wastes the fewest workgroup rounds), except
@@ -685,79 +765,189 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 	}
 	add(0);
 
-	// C layout: column (token) = lane & 31, row (unit) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-#pragma unroll
-	for (int c = 0; c < NC; ++c) {
-		const int token = tok0 + 32 * c + j;
-		if (token >= nb) {
-			continue;
+	pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+}
+
+// ---- the wide form ------------------------------------------------------------------------------------------------------
+// k_pf_gemm splits K over the four waves of a workgroup to fill the chip from few tiles; each wave then fetches its own
+// operands, 0.08 bytes per multiply-add, and at the f16 MFMA rate the kernel runs at whatever the CU's vector memory path
+// keeps in flight (~64 KiB per CU: 8-10 TB/s of L2 traffic, 160-280 TFLOP/s).  When a GEMM has enough tiles to fill the chip
+// WITHOUT splitting K, the four waves take different unit strips of the SAME 64 tokens and the same k: the B operand -- four
+// fifths of the operand bytes -- is fetched once per workgroup, staged through LDS (a ring of three 16 KiB steps, already in
+// the order the lanes consume it: the fragment-major matrix is copied verbatim) and read by all four waves with
+// ds_read_b128; A goes global -> registers as before.  0.03 bytes per multiply-add, no cross-wave reduction.
+// Workgroup tile: 256 units x 64 tokens (FFN-up: 128 units of w1 and of w3).
+// Grid: one dimension, 8 * ceil(nx / 8) * ny workgroups for nx unit blocks and ny token columns.  Workgroups go to the 8 XCDs
+// round robin; XCD c takes the unit blocks c, c + 8, ... and walks the token columns of one unit block before the next, so
+// that the workgroups sharing a slice of weights run at the same time on the same L2 (the slice comes from HBM once) and
+// move through k together; the token columns' B slices are shared the same way by the unit blocks in flight on the XCD.
+template <int EPI>
+struct PfWide {
+	static constexpr int UNITS = EPI == PF_EPI_FFN_UP ? 128 : 256;
+};
+__host__ __device__ inline int pf_wide_grid(int nx, int ny) {
+	return 8 * ((nx + 7) / 8) * ny;
+}
+
+template <int DB, int KVB, int EPI, int AA>
+__global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
+	constexpr int G = Fmt<DB>::G;
+	constexpr int P = 32 / G;  // 16-byte pieces of a row per lane and 64-column step
+	constexpr int OPP = G / 8; // MFMA operands per piece
+	constexpr int NA = 2, NC = 2;
+	constexpr int AB = 2;       // B is fetched two steps ahead (it is staged one step before its use)
+	constexpr int NWB = AA + 1; // A is fetched AA steps ahead
+	constexpr int U = AB * NWB / (NWB % 2 == 0 ? 2 : 1); // lcm(AB, NWB): the loop is unrolled so that every buffer has a static name
+	__shared__ u32x4 bst[3][16][64];
+
+	const int lane = lane_id(), wave = wave_id();
+	const int j = lane & 31, kk = lane >> 5;
+	const int ny = a.ncols;
+	const int bx = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / ny), by = (blockIdx.x >> 3) % ny;
+	if (bx * PfWide<EPI>::UNITS >= a.M) {
+		return;
+	}
+	const int unit0 = bx * PfWide<EPI>::UNITS + wave * (EPI == PF_EPI_FFN_UP ? 32 : 64), tok0 = by * 64;
+	size_t expert_off = 0;
+	if (a.col_expert) {
+		const int e = a.col_expert[by];
+		if (e < 0) {
+			return;
 		}
+		expert_off = (size_t)e * a.expert_stride;
+	}
+	const size_t row_bytes = (size_t)a.K * DB / 8;
+	const int npieces = a.K / G;
+	const int nsteps = pf_steps(a.K);
+
+	const unsigned char* rowp[NA]; // clamped, never branched on (as in k_pf_gemm)
 #pragma unroll
-		for (int n = 0; n < (EPI == PF_EPI_FFN_UP ? 1 : NA); ++n) {
+	for (int s = 0; s < NA; ++s) {
+		if constexpr (EPI == PF_EPI_QKV) {
+			const int u = min(unit0 + 32 * s + j, a.M - 1);
+			const bool is_q = u < a.q_dim, is_k = u < a.q_dim + a.kv_dim;
+			const unsigned char* base = (const unsigned char*)(is_q ? a.w0 : (is_k ? a.w1 : a.w2));
+			const int ul = u - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
+			rowp[s] = base + (size_t)ul * row_bytes;
+		} else if constexpr (EPI == PF_EPI_FFN_UP) {
+			rowp[s] = (const unsigned char*)(s ? a.w1 : a.w0) + expert_off + (size_t)min(unit0 + j, a.M - 1) * row_bytes;
+		} else {
+			rowp[s] = (const unsigned char*)a.w0 + expert_off + (size_t)min(unit0 + 32 * s + j, a.M - 1) * row_bytes;
+		}
+	}
+	const float4* xg = a.xin + (size_t)(tok0 >> 5) * nsteps * 512 + lane;
+
+	u32x4 fb[AB][4];       // this wave's quarter of a step of B on its way to LDS: rows 4 * wave .. + 3 of [token group c][unit u]
+	u32x4 fw[NWB][NA][P];  // a step of this lane's weights
+	auto load_b = [&](u32x4 (&b)[4], int sc) {
+		const int scc = min(sc, nsteps - 1);
 #pragma unroll
-			for (int g = 0; g < 4; ++g) {
-				const int ub = unit0 + 32 * n + 8 * g + 4 * kk; // four consecutive units; M is a multiple of 4
-				if (ub >= a.M) {
-					continue;
+		for (int r = 0; r < 4; ++r) {
+			const int row = wave * 4 + r;
+			b[r] = *(const u32x4*)(xg + ((size_t)(row >> 3) * nsteps + scc) * 512 + (row & 7) * 64);
+		}
+	};
+	auto load_a = [&](u32x4 (&w)[NA][P], int sc) {
+		const int p0 = (2 * min(sc, nsteps - 1) + kk) * P;
+#pragma unroll
+		for (int i = 0; i < P; ++i) {
+			const int piece = min(p0 + i, npieces - 1);
+#pragma unroll
+			for (int n = 0; n < NA; ++n) {
+#ifdef PF_EXP_COALESCED_A // timing experiment only (wrong operands): what the A fetch would cost if a wave-load were 1 KiB contiguous
+				w[n][i] = __builtin_nontemporal_load((gptr16)((const unsigned char*)a.w0 + (size_t)min(unit0 + 32 * n, a.M - 64) * row_bytes) + (size_t)(min(sc, nsteps - 2) * P + i) * 64 + lane);
+#else
+				w[n][i] = __builtin_nontemporal_load((gptr16)rowp[n] + piece);
+#endif
+			}
+		}
+	};
+	auto stage_b = [&](const u32x4 (&b)[4], int slot) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			bst[slot][wave * 4 + r][lane] = b[r];
+		}
+	};
+
+	f32x16 acc[NA][NC];
+#pragma unroll
+	for (int n = 0; n < NA; ++n) {
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				acc[n][c][r] = 0.f;
+			}
+		}
+	}
+	auto compute = [&](const u32x4 (&w)[NA][P], int sc, int slot) {
+		const int p0 = (2 * sc + kk) * P;
+#pragma unroll
+		for (int i = 0; i < P; ++i) {
+			const bool valid = p0 + i < npieces;
+			u32x4 v[NA];
+#pragma unroll
+			for (int n = 0; n < NA; ++n) {
+				v[n] = w[n][i];
+				if (!valid) {
+					v[n] = (u32x4){0u, 0u, 0u, 0u};
 				}
-				if constexpr (EPI == PF_EPI_RESID) {
-					float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
-					float4 t = *p;
-					t.x += acc[n][c][4 * g], t.y += acc[n][c][4 * g + 1], t.z += acc[n][c][4 * g + 2], t.w += acc[n][c][4 * g + 3];
-					*p = t;
-				} else if constexpr (EPI == PF_EPI_STORE) { // M is arbitrary here (a vocabulary): scalar, bounded stores
+			}
 #pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						if (ub + e < a.M) {
-							a.out[(size_t)token * a.M + ub + e] = acc[n][c][4 * g + e];
-						}
-					}
-				} else if constexpr (EPI == PF_EPI_FFN_UP) {
-					float h[4];
+			for (int jj = 0; jj < OPP; ++jj) {
+				f16x8 wa[NA];
 #pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						float up = acc[0][c][4 * g + e], gt = acc[1][c][4 * g + e];
-						h[e] = (a.gelu ? act_gelu(up) : act_silu(up)) * gt; // src/infer.c:440-450
-					}
-					pf_store4(a.out, token, ub, pf_steps(a.M), h);
-				} else {
+				for (int n = 0; n < NA; ++n) {
+					wa[n] = pf_operand<DB>(v[n], jj);
+				}
+				const int m = i * OPP + jj;
 #pragma unroll
-					for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
-						const int uu = ub + 2 * pr;
-						float v0 = acc[n][c][4 * g + 2 * pr], v1 = acc[n][c][4 * g + 2 * pr + 1];
-						if (a.bqkv) {
-							v0 += a.bqkv[uu];
-							v1 += a.bqkv[uu + 1];
-						}
-						v0 = clipf(v0, a.clip);
-						v1 = clipf(v1, a.clip);
-						if (uu < a.q_dim + a.kv_dim) { // src/infer.c:223-236
-							const int ul = uu < a.q_dim ? uu : uu - a.q_dim;
-							const float2 cs = a.rope[(size_t)token * (a.head_dim >> 1) + ((ul % a.head_dim) >> 1)];
-							const float r0 = v0 * cs.x - v1 * cs.y, r1 = v0 * cs.y + v1 * cs.x;
-							v0 = r0, v1 = r1;
-						}
-						if (uu < a.q_dim) {
-							*(float2*)(a.out + (size_t)token * a.q_dim + uu) = make_float2(v0, v1);
-						} else {
-							int jl = uu - a.q_dim;
-							void* cache = a.kc;
-							if (jl >= a.kv_dim) {
-								jl -= a.kv_dim;
-								cache = a.vc;
-							}
-							const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
-							if constexpr (KVB == 16) {
-								*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // src/infer.c:378-381
-							} else {
-								*(unsigned short*)((unsigned char*)cache + off) = e5m2x2_sat(v0, v1);
-							}
+				for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+					for (int c = 0; c < NC; ++c) {
+						const f16x8 bop = __builtin_bit_cast(f16x8, bst[slot][c * 8 + m * 2 + hl][lane]);
+#pragma unroll
+						for (int n = 0; n < NA; ++n) {
+							acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[n], bop, acc[n][c], 0, 0, 0);
 						}
 					}
 				}
 			}
 		}
+	};
+
+#pragma unroll
+	for (int d = 0; d < AB; ++d) {
+		load_b(fb[d], d);
 	}
+#pragma unroll
+	for (int d = 0; d < AA; ++d) {
+		load_a(fw[d], d);
+	}
+	stage_b(fb[0], 0);
+	__syncthreads();
+	// step s: fetch B(s + AB) and A(s + AA), stage B(s + 1) (fetched a step ago), multiply step s, barrier
+	for (int s0 = 0; s0 < nsteps; s0 += U) {
+#pragma unroll
+		for (int I = 0; I < U; ++I) {
+			const int s = s0 + I;
+			if (s < nsteps) {
+#ifndef PF_EXP_NOLOAD
+				load_b(fb[I % AB], s + AB);
+				load_a(fw[(I + AA) % NWB], s + AA);
+				__builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef PF_EXP_NOSTAGE
+				stage_b(fb[(I + 1) % AB], (s + 1) % 3);
+#endif
+				compute(fw[I % NWB], s, s % 3);
+#ifndef PF_EXP_NOBARRIER
+				__syncthreads();
+#endif
+			}
+		}
+	}
+	pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
 }
 
 } // namespace calm

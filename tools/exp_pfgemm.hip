@@ -50,6 +50,7 @@ static float fp8_value(uint8_t b) {
 	return __half2float(h);
 }
 
+// S > 0: k_pf_gemm with S strips per wave;  S = -AA: k_pf_gemm_wide fetching A AA steps ahead
 template <int EPI, int S>
 static void run(const char* name, int M, int K, int nb, int iters) {
 	const int cols = (nb + 63) / 64;
@@ -82,8 +83,16 @@ static void run(const char* name, int M, int K, int nb, int iters) {
 	memset(&a, 0, sizeof(a));
 	a.xin = (const float4*)dXf, a.w0 = dW, a.w1 = dW + wbytes, a.K = K, a.M = M, a.nb = nb, a.out = dOut;
 	a.clip = 3.4e38f;
-	const dim3 grid((M + PfTile<EPI, S>::UNITS - 1) / PfTile<EPI, S>::UNITS, cols);
-	auto launch = [&]() { hipLaunchKernelGGL((k_pf_gemm<8, 16, EPI, S>), grid, dim3(256), 0, 0, a); };
+	constexpr int UNITS = S > 0 ? PfTile<EPI, (S > 0 ? S : 1)>::UNITS : PfWide<EPI>::UNITS;
+	a.ncols = cols;
+	const dim3 grid = S > 0 ? dim3((M + UNITS - 1) / UNITS, cols) : dim3(pf_wide_grid((M + UNITS - 1) / UNITS, cols));
+	auto launch = [&]() {
+		if constexpr (S > 0) {
+			hipLaunchKernelGGL((k_pf_gemm<8, 16, EPI, (S > 0 ? S : 1)>), grid, dim3(256), 0, 0, a);
+		} else {
+			hipLaunchKernelGGL((k_pf_gemm_wide<8, 16, EPI, (S < 0 ? -S : 1)>), grid, dim3(256), 0, 0, a);
+		}
+	};
 	launch();
 	CK(hipDeviceSynchronize());
 	double worst = 0, scale = 0;
@@ -131,15 +140,21 @@ static void run(const char* name, int M, int K, int nb, int iters) {
 int main(int argc, char** argv) {
 	const int nb = argc > 1 ? atoi(argv[1]) : 256;
 	const int iters = argc > 2 ? atoi(argv[2]) : 20;
-	run<PF_EPI_STORE, 1>("qkv-like", 6144, 4096, nb, iters);
-	run<PF_EPI_STORE, 2>("qkv-like", 6144, 4096, nb, iters);
 	run<PF_EPI_STORE, 3>("qkv-like", 6144, 4096, nb, iters);
-	run<PF_EPI_STORE, 1>("wo-like", 4096, 4096, nb, iters);
+	run<PF_EPI_STORE, -1>("qkv-like", 6144, 4096, nb, iters);
+	run<PF_EPI_STORE, -3>("qkv-like", 6144, 4096, nb, iters);
 	run<PF_EPI_STORE, 2>("wo-like", 4096, 4096, nb, iters);
+	run<PF_EPI_STORE, -1>("wo-like", 4096, 4096, nb, iters);
+	run<PF_EPI_STORE, -3>("wo-like", 4096, 4096, nb, iters);
 	run<PF_EPI_FFN_UP, 1>("ffn-up", 14336, 4096, nb, iters);
-	run<PF_EPI_STORE, 1>("ffn-down", 4096, 14336, nb, iters);
+	run<PF_EPI_FFN_UP, -1>("ffn-up", 14336, 4096, nb, iters);
+	run<PF_EPI_FFN_UP, -3>("ffn-up", 14336, 4096, nb, iters);
 	run<PF_EPI_STORE, 2>("ffn-down", 4096, 14336, nb, iters);
+	run<PF_EPI_STORE, -1>("ffn-down", 4096, 14336, nb, iters);
+	run<PF_EPI_STORE, -3>("ffn-down", 4096, 14336, nb, iters);
 	run<PF_EPI_STORE, 2>("ragged", 1000, 4128, nb < 200 ? nb : 200, iters);
+	run<PF_EPI_STORE, -1>("ragged", 1000, 4128, nb < 200 ? nb : 200, iters);
 	run<PF_EPI_STORE, 3>("classifier", 32000, 4096, nb, iters);
+	run<PF_EPI_STORE, -1>("classifier", 32000, 4096, nb, iters);
 	return 0;
 }
