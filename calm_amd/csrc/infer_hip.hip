@@ -79,6 +79,7 @@ int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
+int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
 char g_devname[256] = "none";
 
 // CALM_HIP_PROF_JSON=<path>: algorithmic bytes per kernel, accumulated over every decode step of the process and written at
@@ -769,29 +770,38 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 	                   c->pf_rope, half_hd);
 	const dim3 block(256);
 	const int cols = (nb + 63) / 64;
-	// S unit strips per wave (operands reused S times): the S whose grid costs the fewest workgroup rounds
-	// (one workgroup per CU at a time, a round takes S units of time); ties go to the larger S
-	auto gemm = [&](const PfGemmArgs& a, auto EPI) {
+	// Two forms of the GEMM (prefill.hip.h).  Enough tiles to fill the chip without splitting K (256 units x 64 tokens per
+	// workgroup: from ~3/4 of the CUs busy the wide form wins, profiles/r02_prefill_gemm.txt): k_pf_gemm_wide.  Otherwise the
+	// K-split form with S unit strips per wave (operands reused S times): the S whose grid costs the fewest workgroup rounds
+	// (one workgroup per CU at a time, a round takes S units of time); ties go to the larger S.
+	auto gemm = [&](PfGemmArgs a, auto EPI, int ncols) {
 		constexpr int epi = decltype(EPI)::value;
+		constexpr int kvb = epi == PF_EPI_QKV ? KVB : 16; // only the QKV epilogue touches the cache
+		const int nx = (a.M + PfWide<epi>::UNITS - 1) / PfWide<epi>::UNITS;
+		if (g_pf_wide && (long)nx * ncols * 4 >= (long)g_ncu * 3) {
+			a.ncols = ncols;
+			hipLaunchKernelGGL((k_pf_gemm_wide<DB, kvb, epi, 1>), dim3(pf_wide_grid(nx, ncols)), block, 0, g_stream, a);
+			return;
+		}
 		if constexpr (epi == PF_EPI_FFN_UP) {
-			hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
+			hipLaunchKernelGGL((k_pf_gemm<DB, kvb, epi, 1>), dim3((a.M + 31) / 32, ncols), block, 0, g_stream, a);
 		} else {
 			int best = 1;
 			long best_cost = 0;
 			for (int S = 1; S <= 3; ++S) {
-				long wgs = (long)((a.M + 32 * S - 1) / (32 * S)) * cols;
+				long wgs = (long)((a.M + 32 * S - 1) / (32 * S)) * ncols;
 				long cost = (wgs + g_ncu - 1) / g_ncu * S;
 				if (S == 1 || cost <= best_cost) {
 					best = S, best_cost = cost;
 				}
 			}
-			const dim3 grid((a.M + 32 * best - 1) / (32 * best), cols);
+			const dim3 grid((a.M + 32 * best - 1) / (32 * best), ncols);
 			if (best == 3) {
-				hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 3>), grid, block, 0, g_stream, a);
+				hipLaunchKernelGGL((k_pf_gemm<DB, kvb, epi, 3>), grid, block, 0, g_stream, a);
 			} else if (best == 2) {
-				hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 2>), grid, block, 0, g_stream, a);
+				hipLaunchKernelGGL((k_pf_gemm<DB, kvb, epi, 2>), grid, block, 0, g_stream, a);
 			} else {
-				hipLaunchKernelGGL((k_pf_gemm<DB, KVB, epi, 1>), grid, block, 0, g_stream, a);
+				hipLaunchKernelGGL((k_pf_gemm<DB, kvb, epi, 1>), grid, block, 0, g_stream, a);
 			}
 		}
 	};
@@ -811,28 +821,28 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 		a.w0 = w->wq[l], a.w1 = w->wk[l], a.w2 = w->wv[l], a.bqkv = w->bqkv[l];
 		a.out = c->pf_q;
 		a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes, a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
-		gemm(a, EpiQkv());
+		gemm(a, EpiQkv(), cols);
 		// causal attention of every token of the chunk over the cache (its own row included)
 		launch_pf_attn<KVB>(c, l, nb, pos0);
 		// x += wo . att   (src/infer.c:408-415)
 		a.xin = (const float4*)c->pf_att, a.K = c->q_dim, a.M = c->dim, a.w0 = w->wo[l], a.out = c->pf_x;
-		gemm(a, EpiResid());
+		gemm(a, EpiResid(), cols);
 		// FFN   (src/infer.c:417-457); parallel-residual models reuse the attention norm's output
 		if (!p->norm_par) {
 			hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
 		}
 		if (c->n_experts == 0) {
 			a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
-			gemm(a, EpiUp());
+			gemm(a, EpiUp(), cols);
 			a.xin = (const float4*)c->pf_h, a.K = c->hidden, a.M = c->dim, a.w0 = w->w2[l], a.out = c->pf_x;
-			gemm(a, EpiResid());
+			gemm(a, EpiResid(), cols);
 			continue;
 		}
 		// mixture of experts (src/infer.c:422-457): gate logits of every token, routing into packed per-expert row
 		// groups, ONE grouped GEMM per matrix over all experts' rows, then the experts' outputs are added to the
 		// residual in rank order
 		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->n_experts, a.w0 = w->moegate[l], a.out = c->pf_gate;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_STORE, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
+		hipLaunchKernelGGL((k_pf_gemm<DB, 16, PF_EPI_STORE, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
 		const int ecols = (nb * c->n_active + 63) / 64 + c->n_experts; // worst case for this chunk
 		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, ecols, c->pf_rows, c->pf_colexp, c->pf_slot,
 		                   c->pf_wsel);
@@ -841,16 +851,16 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 		m.nb = ecols * 64;
 		m.col_expert = c->pf_colexp, m.expert_stride = (size_t)c->hidden * c->dim * DB / 8;
 		m.xin = (const float4*)c->pf_xe, m.K = c->dim, m.M = c->hidden, m.w0 = w->w1[l], m.w1 = w->w3[l], m.out = c->pf_h;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_FFN_UP, 1>), dim3((m.M + 31) / 32, ecols), block, 0, g_stream, m);
+		gemm(m, EpiUp(), ecols);
 		m.xin = (const float4*)c->pf_h, m.K = c->hidden, m.M = c->dim, m.w0 = w->w2[l], m.out = c->pf_y;
-		hipLaunchKernelGGL((k_pf_gemm<DB, KVB, PF_EPI_STORE, 2>), dim3((m.M + 63) / 64, ecols), block, 0, g_stream, m);
+		gemm(m, std::integral_constant<int, PF_EPI_STORE>(), ecols);
 		hipLaunchKernelGGL(k_pf_combine, dim3(nb), block, 0, g_stream, c->pf_x, c->pf_y, c->pf_slot, c->pf_wsel, c->n_active, c->dim);
 	}
 	if (score) {
 		// final norm + classifier for every token of the chunk (src/infer.c:465-469), then log softmax of the target
 		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_final_weight, c->dim, p->norm_eps, (int)p->norm_ln);
 		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->vocab, a.w0 = w->wcls, a.out = c->pf_logits;
-		gemm(a, std::integral_constant<int, PF_EPI_STORE>());
+		gemm(a, std::integral_constant<int, PF_EPI_STORE>(), cols);
 		hipLaunchKernelGGL(k_pf_logprob, dim3(nb), block, 0, g_stream, c->pf_logits, c->vocab, c->pf_target, c->pf_lp);
 	}
 	HIP_CHECK(hipGetLastError());
@@ -922,6 +932,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_t;
 	} else if (!strcmp(key, "split_min")) {
 		slot = &g_split_min;
+	} else if (!strcmp(key, "pf_wide")) {
+		slot = &g_pf_wide;
 	} else if (!strcmp(key, "stage")) {
 		CALM_REQUIRE(value < (int)g_devs.size(), "calm_hip_configure(\"stage\"): no such stage");
 		int old_stage = g_alloc_stage;
@@ -1014,6 +1026,7 @@ extern "C" void init_hip(void) {
 	}
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
+	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
 		printf("# HIP: %s (%s), %d CUs, %.1f GiB, device %d\n", prop.name, prop.gcnArchName, g_ncu, (double)prop.totalGlobalMem / (1024.0 * 1024 * 1024), dev);
 	}

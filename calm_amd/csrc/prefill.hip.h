@@ -34,7 +34,7 @@ namespace calm {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int PF_NT = 256; // tokens per chunk: up to four 64-token workgroup columns
+constexpr int PF_NT = 1024; // tokens per chunk: up to sixteen 64-token workgroup columns (the wide GEMM form fills the chip from ~512)
 
 enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3 };
 constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
@@ -854,11 +854,7 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 			const int piece = min(p0 + i, npieces - 1);
 #pragma unroll
 			for (int n = 0; n < NA; ++n) {
-#ifdef PF_EXP_COALESCED_A // timing experiment only (wrong operands): what the A fetch would cost if a wave-load were 1 KiB contiguous
-				w[n][i] = __builtin_nontemporal_load((gptr16)((const unsigned char*)a.w0 + (size_t)min(unit0 + 32 * n, a.M - 64) * row_bytes) + (size_t)(min(sc, nsteps - 2) * P + i) * 64 + lane);
-#else
 				w[n][i] = __builtin_nontemporal_load((gptr16)rowp[n] + piece);
-#endif
 			}
 		}
 	};
@@ -932,18 +928,12 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 		for (int I = 0; I < U; ++I) {
 			const int s = s0 + I;
 			if (s < nsteps) {
-#ifndef PF_EXP_NOLOAD
 				load_b(fb[I % AB], s + AB);
 				load_a(fw[(I + AA) % NWB], s + AA);
 				__builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef PF_EXP_NOSTAGE
 				stage_b(fb[(I + 1) % AB], (s + 1) % 3);
-#endif
 				compute(fw[I % NWB], s, s % 3);
-#ifndef PF_EXP_NOBARRIER
 				__syncthreads();
-#endif
 			}
 		}
 	}

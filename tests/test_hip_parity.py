@@ -420,26 +420,67 @@ def test_prefill_equals_the_serial_prompt_loop(hiplib, case, kvbits):
 
 
 def test_prefill_in_two_calls_and_odd_chunks(hiplib):
-    """a prompt longer than one 256-token chunk, split at awkward places, with the second call starting at pos > 0"""
-    spec = cf.tiny_spec("pf", max_seq_len=512, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=500)
+    """a prompt longer than one 1024-token chunk, split at awkward places, with the second call starting at pos > 0"""
+    spec = cf.tiny_spec("pf", max_seq_len=1536, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=500)
     tensors, md = cf.synth_model(spec, "fp8", seed=21)
     model = HostModel(tensors, md)
     rng = np.random.default_rng(4)
-    toks = [int(t) for t in rng.integers(0, 500, size=400)]
+    toks = [int(t) for t in rng.integers(0, 500, size=1300)]
     o = oracle.OracleBackend(model)
     b = HipBackend(model)
     try:
         for pos, tok in enumerate(toks[:-1]):
             o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         lo = o.forward(toks[-1], len(toks) - 1, 0).copy()
-        b.prefill(toks[:297], 0)       # chunks of 256 + 41
-        b.prefill(toks[297:399], 297)  # one chunk of 102 (64 + 38) that attends to the 297 rows before it
+        b.prefill(toks[:1065], 0)         # chunks of 1024 + 41
+        b.prefill(toks[1065:1299], 1065)  # one chunk of 234 (3 x 64 + 42) that attends to the 1065 rows before it
         lb = b.forward(toks[-1], len(toks) - 1, 0)
         assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
         b.prefill([], 0)  # empty prompt: no-op
     finally:
         b.close()
         o.close()
+
+
+@pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16"), ("mixtral-8x7b", "fp8")])
+def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
+    """BASELINE widths, one layer, a 1100-token prompt (one full 1024-token chunk + 76): every GEMM of the full chunk runs in
+    the wide form (k_pf_gemm_wide: B staged through LDS, no K split), the short chunk in the K-split form.  Against serial
+    ingestion on the same backend, against the K-split form alone (calm_hip_configure("pf_wide", 0)), and the scored
+    log-probabilities of both forms against each other."""
+    spec = cf.SPECS[name]
+    tensors, md = cf.synth_model_big(spec, dtype, seed=10, n_layers=1)
+    model = HostModel(tensors, md, context=1280)
+    rng = np.random.default_rng(12)
+    n = 1100
+    toks = [int(t) for t in rng.integers(0, spec.vocab_size, size=n + 1)]
+    serial = HipBackend(model)
+    wide = HipBackend(model)
+    ksplit = HipBackend(model)
+    try:
+        for pos, tok in enumerate(toks[:n]):
+            serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        ls = serial.forward(toks[n], n, 0).copy()
+        assert hiplib.calm_hip_configure(b"pf_wide", -1) == 1
+        wide.prefill(toks[:n], 0)
+        lw = wide.forward(toks[n], n, 0).copy()
+        lpw = wide.prefill_logprobs(toks[: n + 1], 0)
+        hiplib.calm_hip_configure(b"pf_wide", 0)
+        try:
+            ksplit.prefill(toks[:n], 0)
+            lk = ksplit.forward(toks[n], n, 0).copy()
+            lpk = ksplit.prefill_logprobs(toks[: n + 1], 0)
+        finally:
+            hiplib.calm_hip_configure(b"pf_wide", 1)
+        assert rel_err(lw, ls) < 2e-4, rel_err(lw, ls)
+        assert rel_err(lk, ls) < 2e-4, rel_err(lk, ls)
+        assert np.isfinite(lpw).all() and np.abs(lpw - lpk).max() < 2e-3 * max(1.0, float(np.abs(lpk).max()))
+        for ks, kb in zip(_kv_floats(hiplib, serial, 16), _kv_floats(hiplib, wide, 16)):
+            assert np.abs(ks - kb).max() <= 2e-3 * max(np.abs(ks).max(), 1e-6)
+    finally:
+        serial.close()
+        wide.close()
+        ksplit.close()
 
 
 @pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 2), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1), ("dbrx-132b", "fp8", 1)])
