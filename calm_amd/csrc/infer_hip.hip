@@ -79,6 +79,7 @@ int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
+int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
 char g_devname[256] = "none";
 
@@ -742,8 +743,37 @@ void launch_pf_attn_lpr(Ctx* c, int l, int nb, int pos0) {
 	hipLaunchKernelGGL((k_pf_attn<KVB, LPR>), dim3(c->n_heads, (nb + TQ - 1) / TQ), dim3(PF_ATTN_BLOCK), 0, g_stream, a);
 }
 
+// the matrix-core form (prefill.hip.h: k_pf_attn_mfma) for head sizes 64 / 128
+template <int KVB, int HD>
+void launch_pf_attn_mfma(Ctx* c, int l, int nb, int pos0) {
+	AttnArgs a;
+	a.q = c->pf_q;
+	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
+	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+	a.out = c->pf_att;
+	a.partial = nullptr;
+	a.ts = c->ts;
+	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
+	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
+	const int hg = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
+	const dim3 grid(c->n_kv_heads, (nb + 32 * (4 / hg) - 1) / (32 * (4 / hg)));
+	if (hg == 4) {
+		hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 4>), grid, dim3(256), 0, g_stream, a);
+	} else if (hg == 2) {
+		hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 2>), grid, dim3(256), 0, g_stream, a);
+	} else {
+		hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 1>), grid, dim3(256), 0, g_stream, a);
+	}
+}
+
 template <int KVB>
 void launch_pf_attn(Ctx* c, int l, int nb, int pos0) {
+	if (g_pf_attn_mfma && c->head_dim == 128) {
+		return launch_pf_attn_mfma<KVB, 128>(c, l, nb, pos0);
+	}
+	if (g_pf_attn_mfma && c->head_dim == 64) {
+		return launch_pf_attn_mfma<KVB, 64>(c, l, nb, pos0);
+	}
 	switch (c->lpr) {
 	case 4:
 		return launch_pf_attn_lpr<KVB, 4>(c, l, nb, pos0);
@@ -934,6 +964,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_min;
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
+	} else if (!strcmp(key, "pf_attn_mfma")) {
+		slot = &g_pf_attn_mfma;
 	} else if (!strcmp(key, "stage")) {
 		CALM_REQUIRE(value < (int)g_devs.size(), "calm_hip_configure(\"stage\"): no such stage");
 		int old_stage = g_alloc_stage;
@@ -1027,6 +1059,7 @@ extern "C" void init_hip(void) {
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
+	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
 		printf("# HIP: %s (%s), %d CUs, %.1f GiB, device %d\n", prop.name, prop.gcnArchName, g_ncu, (double)prop.totalGlobalMem / (1024.0 * 1024 * 1024), dev);
 	}

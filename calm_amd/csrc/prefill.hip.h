@@ -423,6 +423,220 @@ __global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
 	}
 }
 
+// ---- the same attention on the matrix cores ------------------------------------------------------------------------------
+// k_pf_attn spends its time in lane arithmetic (one dot-product lane group per cached row: 519 us for a 1024-token chunk of the
+// Mistral-7B shape, as long as all four weight GEMMs of the layer once those run on the f16 MFMA).  Here a wave owns one query
+// head and a tile of 32 consecutive tokens; the workgroup's four waves are the query heads that share a kv head (or, with
+// fewer than four of them, further token tiles), so the K / V rows of a 32-key tile are fetched once per workgroup into LDS:
+//   S^T[key][query] = K[key][:] . q[query][:]      A = K rows (binary16 as cached; e5m2 widened), B = q as hi + lo binary16
+//   online softmax down the columns: a lane holds 16 keys of ONE query (C layout: column = lane & 31), so the running
+//   maximum and sum are in-lane reductions plus one exchange with lane ^ 32
+//   O^T[d][query] += V^T[d][key] . P[key][query]   A = V transposed (by the LDS write), B = P as hi + lo binary16, taken from
+//   S^T's accumulator registers as they are: a lane's 8 registers are the 8 keys the MFMA wants from it, in the order
+//   key = 16 u + 8 (e >> 2) + 4 (lane >> 5) + (e & 3), and the V^T image is written in that key order
+// Every product is exact in fp32 (binary16 x binary16), accumulation is fp32: the result agrees with k_pf_attn to fp32 rounding.
+// LDS images (per 32-key tile, ring of 3): K [key][HD] with the 16-byte chunk index XOR-swizzled by the key, V^T [d][32 keys]
+// (64 B rows) with the 8-key chunk index XOR-swizzled by (d >> 3) & 3 -- both make the ds_read_b128 operand fetches conflict
+// free for the hardware's 16-lane groups.
+// grid = (n_kv_heads, ceil(nb / (32 * TW))), 256 threads;  HG = heads per round (4, 2 or 1, dividing kv_mul), TW = 4 / HG
+template <int KVB, int HD, int HG>
+__global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
+	constexpr int TW = 4 / HG;       // token tiles per workgroup
+	constexpr int NT = HD / 16;      // MFMA k-steps of a q . k dot product
+	constexpr int ND = HD / 32;      // 32-row tiles of O^T
+	constexpr int CK = HD / 8;       // 16-byte chunks of a K row
+	__shared__ u32x4 kst[3][32 * CK];
+	__shared__ u32x4 vst[3][HD * 4];
+
+	const int lane = lane_id(), wave = wave_id();
+	const int j = lane & 31, hh = lane >> 5;
+	const int kvh = blockIdx.x;
+	const int hr = wave % HG, tw = wave / HG;
+	const int b0 = (blockIdx.y * TW + tw) * 32;           // this wave's first token
+	const int bw = blockIdx.y * TW * 32;                  // the workgroup's first token
+	const int nb = a.pf_nb;
+	const int kv_all = a.pf_kv0 + min(bw + TW * 32, nb);  // rows the workgroup's last token attends to
+	const int ntiles = (kv_all + 31) >> 5;
+	const int my_tiles = b0 < nb ? (a.pf_kv0 + min(b0 + 32, nb) + 31) >> 5 : 0;
+	const float inv_sqrt_hd = 1.0f / sqrtf((float)a.head_dim);
+	const int qpos = a.pf_kv0 + b0 + j; // this lane's query may look at rows <= qpos
+
+	constexpr int EB = KVB / 8;
+	const unsigned char* kbase = (const unsigned char*)a.kc + (size_t)kvh * a.seq_len * HD * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + (size_t)kvh * a.seq_len * HD * EB;
+	// staging: a wave-load covers 64 / CK rows of 16-byte chunks (fp8: of 8-byte chunks); the workgroup's 256 lanes cover
+	// 1024 / CK rows per pass, 32 rows in CK / 8 ... passes
+	constexpr int RPP = 256 / CK;  // rows per pass of the whole workgroup
+	constexpr int NP = 32 / RPP;   // passes per tile (HD 128: 2, HD 64: 1)
+	const int srow = threadIdx.x / CK, sck = threadIdx.x % CK;
+	u32x4 kreg[NP], vreg[NP];
+	auto fetch = [&](int kt) {
+#pragma unroll
+		for (int p = 0; p < NP; ++p) {
+			const int row = min(kt * 32 + p * RPP + srow, kv_all - 1);
+			if constexpr (KVB == 16) {
+				kreg[p] = *(const u32x4*)(kbase + ((size_t)row * HD + sck * 8) * 2);
+				vreg[p] = *(const u32x4*)(vbase + ((size_t)row * HD + sck * 8) * 2);
+			} else { // e5m2 -> binary16: the byte becomes the upper byte
+				const u32x2 kw = *(const u32x2*)(kbase + (size_t)row * HD + sck * 8);
+				const u32x2 vw = *(const u32x2*)(vbase + (size_t)row * HD + sck * 8);
+				kreg[p] = (u32x4){__builtin_amdgcn_perm(kw[0], kw[0], 0x050c040cu), __builtin_amdgcn_perm(kw[0], kw[0], 0x070c060cu),
+				                  __builtin_amdgcn_perm(kw[1], kw[1], 0x050c040cu), __builtin_amdgcn_perm(kw[1], kw[1], 0x070c060cu)};
+				vreg[p] = (u32x4){__builtin_amdgcn_perm(vw[0], vw[0], 0x050c040cu), __builtin_amdgcn_perm(vw[0], vw[0], 0x070c060cu),
+				                  __builtin_amdgcn_perm(vw[1], vw[1], 0x050c040cu), __builtin_amdgcn_perm(vw[1], vw[1], 0x070c060cu)};
+			}
+		}
+	};
+	auto kswz = [](int key) { return HD == 128 ? (key & 15) : ((key >> 1) & 7); };
+	auto stage = [&](int slot) {
+#pragma unroll
+		for (int p = 0; p < NP; ++p) {
+			const int key = p * RPP + srow; // within the tile
+			kst[slot][key * CK + (sck ^ kswz(key))] = kreg[p];
+			// V transposed: this lane holds d = 8 sck .. + 7 of `key`; position of the key in the MFMA's order, 8-key chunk swizzled
+			const int pi = (key & 16) + 8 * ((key >> 2) & 1) + (key & 3) + 4 * ((key >> 3) & 1);
+			unsigned short* vt = (unsigned short*)vst[slot];
+#pragma unroll
+			for (int e = 0; e < 8; ++e) {
+				const int d = 8 * sck + e;
+				const unsigned w = vreg[p][e >> 1];
+				vt[d * 32 + ((((pi >> 3) ^ ((d >> 3) & 3)) << 3) | (pi & 7))] = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffff));
+			}
+		}
+	};
+
+	fetch(0);
+	stage(0);
+	if (ntiles > 1) {
+		fetch(1);
+	}
+	__syncthreads();
+
+	for (int r = 0; r < a.kv_mul / HG; ++r) {
+		const int h = kvh * a.kv_mul + r * HG + hr;
+		// q of this lane's token: hi / lo operands, d = 16 t + 8 hh + e
+		u32x4 qh[NT], ql[NT];
+		{
+			const float* qsrc = a.q + (size_t)min(b0 + j, nb - 1) * a.pf_stride + h * HD + 8 * hh;
+#pragma unroll
+			for (int t = 0; t < NT; ++t) {
+				const float4 q0 = *(const float4*)(qsrc + 16 * t), q1 = *(const float4*)(qsrc + 16 * t + 4);
+				unsigned hi, lo;
+				pf_split2(q0.x, q0.y, hi, lo), qh[t][0] = hi, ql[t][0] = lo;
+				pf_split2(q0.z, q0.w, hi, lo), qh[t][1] = hi, ql[t][1] = lo;
+				pf_split2(q1.x, q1.y, hi, lo), qh[t][2] = hi, ql[t][2] = lo;
+				pf_split2(q1.z, q1.w, hi, lo), qh[t][3] = hi, ql[t][3] = lo;
+			}
+		}
+		f32x16 o[ND];
+#pragma unroll
+		for (int dt = 0; dt < ND; ++dt) {
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				o[dt][i] = 0.f;
+			}
+		}
+		float m = -INFINITY, l = 0.f;
+
+		for (int kt = 0; kt < ntiles; ++kt) {
+			const int slot = kt % 3;
+			// stage tile kt + 1 (fetched an iteration ago), fetch tile kt + 2
+			if (kt + 1 < ntiles) {
+				stage((kt + 1) % 3);
+			}
+			if (kt + 2 < ntiles) {
+				fetch(kt + 2);
+			}
+			if (kt < my_tiles) {
+				f32x16 sacc;
+#pragma unroll
+				for (int i = 0; i < 16; ++i) {
+					sacc[i] = 0.f;
+				}
+#pragma unroll
+				for (int t = 0; t < NT; ++t) {
+					const f16x8 kop = __builtin_bit_cast(f16x8, kst[slot][j * CK + ((2 * t + hh) ^ kswz(j))]);
+					sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kop, __builtin_bit_cast(f16x8, qh[t]), sacc, 0, 0, 0);
+					sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kop, __builtin_bit_cast(f16x8, ql[t]), sacc, 0, 0, 0);
+				}
+				// scores of this lane's query against keys kt * 32 + (i & 3) + 8 (i >> 2) + 4 hh   (src/infer.c:244-248)
+				float mt = -INFINITY;
+#pragma unroll
+				for (int i = 0; i < 16; ++i) {
+					const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+					sacc[i] = key <= qpos ? sacc[i] * inv_sqrt_hd : -INFINITY;
+					mt = fmaxf(mt, sacc[i]);
+				}
+				mt = fmaxf(mt, __shfl_xor(mt, 32));
+				const float mn = fmaxf(m, mt); // finite from the first tile on: key 0 is visible to every query
+				const float c = __expf(m - mn);
+				float ls = 0.f;
+#pragma unroll
+				for (int i = 0; i < 16; ++i) {
+					sacc[i] = __expf(sacc[i] - mn); // masked: exp(-inf) = 0
+					ls += sacc[i];
+				}
+				ls += __shfl_xor(ls, 32);
+				l = l * c + ls;
+				m = mn;
+				if (__any(c != 1.0f)) {
+#pragma unroll
+					for (int dt = 0; dt < ND; ++dt) {
+#pragma unroll
+						for (int i = 0; i < 16; ++i) {
+							o[dt][i] *= c;
+						}
+					}
+				}
+				u32x4 ph[2], pl[2];
+#pragma unroll
+				for (int u = 0; u < 2; ++u) {
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						const float p0 = sacc[8 * u + 2 * e], p1 = sacc[8 * u + 2 * e + 1];
+						const __half2 hv = __floats2half2_rn(p0, p1); // 0 <= p <= 1
+						const float2 hf = __half22float2(hv);
+						ph[u][e] = __builtin_bit_cast(unsigned, hv);
+						pl[u][e] = __builtin_bit_cast(unsigned, __floats2half2_rn(p0 - hf.x, p1 - hf.y));
+					}
+				}
+#pragma unroll
+				for (int dt = 0; dt < ND; ++dt) {
+					const int d = 32 * dt + j;
+#pragma unroll
+					for (int u = 0; u < 2; ++u) {
+						const f16x8 vop = __builtin_bit_cast(f16x8, vst[slot][d * 4 + ((2 * u + hh) ^ ((d >> 3) & 3))]);
+						o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vop, __builtin_bit_cast(f16x8, ph[u]), o[dt], 0, 0, 0);
+						o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vop, __builtin_bit_cast(f16x8, pl[u]), o[dt], 0, 0, 0);
+					}
+				}
+			}
+			__syncthreads();
+		}
+		// O^T tile dt: column = this lane's query, rows d = 32 dt + (i & 3) + 8 (i >> 2) + 4 hh   (src/infer.c:258-266)
+		if (b0 + j < nb) {
+			const int ns = pf_steps(a.pf_stride);
+#pragma unroll
+			for (int dt = 0; dt < ND; ++dt) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					const float v4[4] = {o[dt][4 * g] / l, o[dt][4 * g + 1] / l, o[dt][4 * g + 2] / l, o[dt][4 * g + 3] / l};
+					pf_store4(a.out, b0 + j, h * HD + 32 * dt + 8 * g + 4 * hh, ns, v4);
+				}
+			}
+		}
+		// a further round of heads walks the same tiles again: restart the ring
+		if (r + 1 < a.kv_mul / HG) {
+			fetch(0);
+			stage(0);
+			if (ntiles > 1) {
+				fetch(1);
+			}
+			__syncthreads();
+		}
+	}
+}
+
 // log of the softmax probability of `target[b]` under row b of the logits (src/sampler.c:19-32 followed by the
 // log of src/run.c:298): one workgroup per token.  target < 0: nothing to score, the slot gets 0.
 __global__ __launch_bounds__(256) void k_pf_logprob(const float* logits, int vocab, const int* target, float* out) {

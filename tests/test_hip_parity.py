@@ -442,6 +442,47 @@ def test_prefill_in_two_calls_and_odd_chunks(hiplib):
         o.close()
 
 
+@pytest.mark.parametrize("kvbits", [16, 8])
+@pytest.mark.parametrize("head_dim,n_heads,n_kv_heads", [(64, 4, 4), (64, 4, 2), (64, 8, 2), (64, 12, 2), (64, 16, 2), (128, 4, 1), (128, 6, 2), (128, 2, 2)])
+def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_heads, kvbits):
+    """k_pf_attn_mfma (head sizes 64 / 128): every grouping of query heads per kv head it is compiled for -- 1, 2, 4 heads per
+    round, one or several rounds, several token tiles per workgroup -- with both cache formats: a 333-token prompt in two
+    calls (the second starts at position 201: partial tiles on both sides), then one decode step against the oracle;
+    and the same prompt through the lane-arithmetic kernel (calm_hip_configure("pf_attn_mfma", 0)): cache rows equal"""
+    dim = 256
+    spec = cf.tiny_spec("pfa", max_seq_len=400, dim=dim, hidden_dim=512, n_heads=n_heads, n_kv_heads=n_kv_heads, head_dim=head_dim, vocab_size=300, n_layers=2)
+    tensors, md = cf.synth_model(spec, "fp8", seed=31)
+    model = HostModel(tensors, md)
+    rng = np.random.default_rng(6)
+    toks = [int(t) for t in rng.integers(0, 300, size=334)]
+    o = oracle.OracleBackend(model, kvbits=kvbits)
+    b = HipBackend(model, kvbits=kvbits)
+    v = HipBackend(model, kvbits=kvbits)
+    try:
+        for pos, tok in enumerate(toks[:-1]):
+            o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        lo = o.forward(toks[-1], 333, 0).copy()
+        assert hiplib.calm_hip_configure(b"pf_attn_mfma", -1) == 1
+        b.prefill(toks[:201], 0)
+        b.prefill(toks[201:333], 201)
+        lb = b.forward(toks[-1], 333, 0).copy()
+        assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
+        hiplib.calm_hip_configure(b"pf_attn_mfma", 0)
+        try:
+            v.prefill(toks[:201], 0)
+            v.prefill(toks[201:333], 201)
+        finally:
+            hiplib.calm_hip_configure(b"pf_attn_mfma", 1)
+        lv = v.forward(toks[-1], 333, 0).copy()
+        assert rel_err(lb, lv) < (2e-5 if kvbits == 16 else 3e-2), rel_err(lb, lv)
+        for km, kv in zip(_kv_floats(hiplib, b, kvbits), _kv_floats(hiplib, v, kvbits)):
+            assert np.abs(km - kv).max() <= (2e-3 if kvbits == 16 else 0.26) * max(np.abs(kv).max(), 1e-6)
+    finally:
+        b.close()
+        v.close()
+        o.close()
+
+
 @pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16"), ("mixtral-8x7b", "fp8")])
 def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
     """BASELINE widths, one layer, a 1100-token prompt (one full 1024-token chunk + 76): every GEMM of the full chunk runs in

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Prompt-ingestion rate on the GPU box: prefill_hip (64-token chunks on the f32 matrix cores) against the
+"""Prompt-ingestion rate on the GPU box: prefill_hip (1024-token chunks on the f16 matrix cores, hi + lo activations) against the
 serial FF_UPDATE_KV_ONLY loop the reference runs (src/run.c:208,216-218), on a layer-reduced model of a
 BASELINE shape; rates are per layer-reduced model and scaled to the full depth by layer count.
 
@@ -33,7 +33,7 @@ for n in ((N,) if PROFILE else (64, N)):
     dt = time.perf_counter() - t0
     act = spec.n_experts_active if spec.n_experts else 1
     flop = 2.0 * n * L * (spec.dim * (spec.n_heads * spec.head_dim * 2 + 2 * spec.n_kv_heads * spec.head_dim) + 3 * act * spec.dim * spec.hidden_dim)
-    print(f"prefill {n:5d} tokens, L={L}: {dt*1e3:8.2f} ms = {n/dt:9.0f} tok/s ({dt/n/L*1e6:7.2f} us/token/layer, {flop/dt/1e12:6.1f} TFLOP/s f32); "
+    print(f"prefill {n:5d} tokens, L={L}: {dt*1e3:8.2f} ms = {n/dt:9.0f} tok/s ({dt/n/L*1e6:7.2f} us/token/layer, {flop/dt/1e12:6.1f} TFLOP/s algorithmic); "
           f"full depth ({spec.n_layers} layers): {n/dt*L/spec.n_layers:8.0f} tok/s")
 if PROFILE:
     be.close()
