@@ -810,7 +810,13 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 		const int nx = (a.M + PfWide<epi>::UNITS - 1) / PfWide<epi>::UNITS;
 		if (g_pf_wide && (long)nx * ncols * 4 >= (long)g_ncu * 3) {
 			a.ncols = ncols;
-			hipLaunchKernelGGL((k_pf_gemm_wide<DB, kvb, epi, 1>), dim3(pf_wide_grid(nx, ncols)), block, 0, g_stream, a);
+			auto kern = k_pf_gemm_wide<DB, kvb, epi, 1>;
+			static bool lds_allowed = false; // (one flag per instantiation of this lambda: per kernel)
+			if (!lds_allowed) {
+				allow_lds(kern, PfWideA<DB>::LDS_BYTES);
+				lds_allowed = true;
+			}
+			hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nx, ncols)), block, PfWideA<DB>::LDS_BYTES, g_stream, a);
 			return;
 		}
 		if constexpr (epi == PF_EPI_FFN_UP) {

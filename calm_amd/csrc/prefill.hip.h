@@ -1003,19 +1003,36 @@ __host__ __device__ inline int pf_wide_grid(int nx, int ny) {
 	return 8 * ((nx + 7) / 8) * ny;
 }
 
+// A step of A (64 columns of this wave's 64 weight rows) is fetched row-contiguous -- a wave-load covers whole 32 / 64 / 128-byte
+// row segments, 8-32 cache lines instead of one line per lane -- and turned into the MFMA's lane order through a wave-private
+// LDS image (row stride padded by 16 bytes: the ds_read_b128 operand fetches are conflict free for the 16-lane groups).
+// No barrier is involved: a wave's LDS operations execute in order.
+template <int DB>
+struct PfWideA {
+	static constexpr int BR = 64 * DB / 8;       // bytes of a row per step: 32 (gf4), 64 (fp8), 128 (fp16)
+	static constexpr int PR = BR / 16;           // 16-byte pieces per row = wave-loads per step
+	static constexpr int RS = BR + 16;           // row stride of the image
+	static constexpr int WAVE_BYTES = 64 * RS;
+	static constexpr int LDS_BYTES = 3 * 16 * 1024 + 4 * WAVE_BYTES; // B ring + the four waves' A images
+};
+
 template <int DB, int KVB, int EPI, int AA>
 __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 	constexpr int G = Fmt<DB>::G;
-	constexpr int P = 32 / G;  // 16-byte pieces of a row per lane and 64-column step
+	constexpr int P = 32 / G;  // 16-byte pieces of a row per lane (k-half) and 64-column step
 	constexpr int OPP = G / 8; // MFMA operands per piece
 	constexpr int NA = 2, NC = 2;
-	constexpr int AB = 2;       // B is fetched two steps ahead (it is staged one step before its use)
-	constexpr int NWB = AA + 1; // A is fetched AA steps ahead
+	constexpr int PR = PfWideA<DB>::PR, RS = PfWideA<DB>::RS;
+	constexpr int RPL = 64 / PR;  // rows per wave-load
+	constexpr int AB = 2;         // B is fetched two steps ahead (it is staged one step before its use)
+	constexpr int NWB = AA + 1;   // A is fetched AA steps ahead
 	constexpr int U = AB * NWB / (NWB % 2 == 0 ? 2 : 1); // lcm(AB, NWB): the loop is unrolled so that every buffer has a static name
-	__shared__ u32x4 bst[3][16][64];
+	extern __shared__ u32x4 pfw_lds[];
+	u32x4(*bst)[16][64] = (u32x4(*)[16][64])pfw_lds; // [3][16][64]
 
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
+	unsigned char* const aimg = (unsigned char*)(pfw_lds + 3 * 16 * 64) + wave * PfWideA<DB>::WAVE_BYTES;
 	const int ny = a.ncols;
 	const int bx = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / ny), by = (blockIdx.x >> 3) % ny;
 	if (bx * PfWide<EPI>::UNITS >= a.M) {
@@ -1031,28 +1048,32 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 		expert_off = (size_t)e * a.expert_stride;
 	}
 	const size_t row_bytes = (size_t)a.K * DB / 8;
-	const int npieces = a.K / G;
+	const int row_pieces = (int)(row_bytes / 16);
 	const int nsteps = pf_steps(a.K);
 
-	const unsigned char* rowp[NA]; // clamped, never branched on (as in k_pf_gemm)
+	// wave-load q of a step: this lane fetches piece (lane % PR) of row q * RPL + lane / PR of the wave's 64 rows
+	// (rows 0-31: first strip, 32-63: second strip -- FFN-up: w1 and w3 of one strip).  Clamped, never branched on.
+	const int apiece = lane % PR;
+	const unsigned char* rowq[PR];
 #pragma unroll
-	for (int s = 0; s < NA; ++s) {
+	for (int q = 0; q < PR; ++q) {
+		const int r = q * RPL + lane / PR;
 		if constexpr (EPI == PF_EPI_QKV) {
-			const int u = min(unit0 + 32 * s + j, a.M - 1);
+			const int u = min(unit0 + r, a.M - 1);
 			const bool is_q = u < a.q_dim, is_k = u < a.q_dim + a.kv_dim;
 			const unsigned char* base = (const unsigned char*)(is_q ? a.w0 : (is_k ? a.w1 : a.w2));
 			const int ul = u - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
-			rowp[s] = base + (size_t)ul * row_bytes;
+			rowq[q] = base + (size_t)ul * row_bytes;
 		} else if constexpr (EPI == PF_EPI_FFN_UP) {
-			rowp[s] = (const unsigned char*)(s ? a.w1 : a.w0) + expert_off + (size_t)min(unit0 + j, a.M - 1) * row_bytes;
+			rowq[q] = (const unsigned char*)(r >= 32 ? a.w1 : a.w0) + expert_off + (size_t)min(unit0 + (r & 31), a.M - 1) * row_bytes;
 		} else {
-			rowp[s] = (const unsigned char*)a.w0 + expert_off + (size_t)min(unit0 + 32 * s + j, a.M - 1) * row_bytes;
+			rowq[q] = (const unsigned char*)a.w0 + expert_off + (size_t)min(unit0 + r, a.M - 1) * row_bytes;
 		}
 	}
 	const float4* xg = a.xin + (size_t)(tok0 >> 5) * nsteps * 512 + lane;
 
-	u32x4 fb[AB][4];       // this wave's quarter of a step of B on its way to LDS: rows 4 * wave .. + 3 of [token group c][unit u]
-	u32x4 fw[NWB][NA][P];  // a step of this lane's weights
+	u32x4 fb[AB][4];   // this wave's quarter of a step of B on its way to LDS: rows 4 * wave .. + 3 of [token group c][unit u]
+	u32x4 fa[NWB][PR]; // a step of the wave's A rows on its way to the wave's LDS image
 	auto load_b = [&](u32x4 (&b)[4], int sc) {
 		const int scc = min(sc, nsteps - 1);
 #pragma unroll
@@ -1061,21 +1082,24 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 			b[r] = *(const u32x4*)(xg + ((size_t)(row >> 3) * nsteps + scc) * 512 + (row & 7) * 64);
 		}
 	};
-	auto load_a = [&](u32x4 (&w)[NA][P], int sc) {
-		const int p0 = (2 * min(sc, nsteps - 1) + kk) * P;
+	auto load_a = [&](u32x4 (&w)[PR], int sc) {
+		const int piece = min(min(sc, nsteps - 1) * PR + apiece, row_pieces - 1);
 #pragma unroll
-		for (int i = 0; i < P; ++i) {
-			const int piece = min(p0 + i, npieces - 1);
-#pragma unroll
-			for (int n = 0; n < NA; ++n) {
-				w[n][i] = __builtin_nontemporal_load((gptr16)rowp[n] + piece);
-			}
+		for (int q = 0; q < PR; ++q) {
+			w[q] = __builtin_nontemporal_load((gptr16)rowq[q] + piece);
 		}
 	};
 	auto stage_b = [&](const u32x4 (&b)[4], int slot) {
 #pragma unroll
 		for (int r = 0; r < 4; ++r) {
 			bst[slot][wave * 4 + r][lane] = b[r];
+		}
+	};
+	auto stage_a = [&](const u32x4 (&w)[PR], int sc) {
+		const bool valid = sc * PR + apiece < row_pieces; // ragged rows: pieces past the row's end multiply as zeros
+#pragma unroll
+		for (int q = 0; q < PR; ++q) {
+			*(u32x4*)(aimg + (q * RPL + lane / PR) * RS + apiece * 16) = valid ? w[q] : (u32x4){0u, 0u, 0u, 0u};
 		}
 	};
 
@@ -1090,40 +1114,58 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 			}
 		}
 	}
-	auto compute = [&](const u32x4 (&w)[NA][P], int sc, int slot) {
-		const int p0 = (2 * sc + kk) * P;
+	// The B operands of MFMA group m + 1 (four ds_read_b128: two token tiles x hi, lo) are asked for before the eight MFMAs of
+	// group m are issued -- 256 matrix-core cycles cover the LDS round trip; left to itself the compiler issues each read two
+	// MFMAs ahead of its use and every group starts with a stall.
+	auto compute = [&](int slot) {
+		u32x4 w[NA][P];
 #pragma unroll
-		for (int i = 0; i < P; ++i) {
-			const bool valid = p0 + i < npieces;
-			u32x4 v[NA];
+		for (int n = 0; n < NA; ++n) {
 #pragma unroll
-			for (int n = 0; n < NA; ++n) {
-				v[n] = w[n][i];
-				if (!valid) {
-					v[n] = (u32x4){0u, 0u, 0u, 0u};
-				}
+			for (int i = 0; i < P; ++i) {
+				w[n][i] = *(const u32x4*)(aimg + (32 * n + j) * RS + (kk * P + i) * 16);
 			}
+		}
+		u32x4 bq[2][4];
+		auto read_b = [&](u32x4 (&q)[4], int m) {
 #pragma unroll
-			for (int jj = 0; jj < OPP; ++jj) {
-				f16x8 wa[NA];
-#pragma unroll
-				for (int n = 0; n < NA; ++n) {
-					wa[n] = pf_operand<DB>(v[n], jj);
-				}
-				const int m = i * OPP + jj;
+			for (int c = 0; c < NC; ++c) {
 #pragma unroll
 				for (int hl = 0; hl < 2; ++hl) {
+					q[c * 2 + hl] = bst[slot][c * 8 + m * 2 + hl][lane];
+				}
+			}
+		};
+		read_b(bq[0], 0);
 #pragma unroll
-					for (int c = 0; c < NC; ++c) {
-						const f16x8 bop = __builtin_bit_cast(f16x8, bst[slot][c * 8 + m * 2 + hl][lane]);
+		for (int m = 0; m < 4; ++m) {
+			if (m + 1 < 4) {
+				read_b(bq[(m + 1) & 1], m + 1);
+			}
+			f16x8 wa[NA];
 #pragma unroll
-						for (int n = 0; n < NA; ++n) {
-							acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[n], bop, acc[n][c], 0, 0, 0);
-						}
+			for (int n = 0; n < NA; ++n) {
+				wa[n] = pf_operand<DB>(w[n][m / OPP], m % OPP);
+			}
+#pragma unroll
+			for (int hl = 0; hl < 2; ++hl) {
+#pragma unroll
+				for (int c = 0; c < NC; ++c) {
+#pragma unroll
+					for (int n = 0; n < NA; ++n) {
+						acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[n], __builtin_bit_cast(f16x8, bq[m & 1][c * 2 + hl]), acc[n][c], 0, 0, 0);
 					}
 				}
 			}
 		}
+		// the order asked of the scheduler: A pieces + 4 reads | 4 reads, 8 MFMA | 4 reads, 8 MFMA | 4 reads, 8 MFMA | 8 MFMA
+		__builtin_amdgcn_sched_group_barrier(0x100, NA * P + 4, 0);
+#pragma unroll
+		for (int m = 0; m < 3; ++m) {
+			__builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+			__builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+		}
+		__builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
 	};
 
 #pragma unroll
@@ -1132,21 +1174,22 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 	}
 #pragma unroll
 	for (int d = 0; d < AA; ++d) {
-		load_a(fw[d], d);
+		load_a(fa[d], d);
 	}
 	stage_b(fb[0], 0);
 	__syncthreads();
-	// step s: fetch B(s + AB) and A(s + AA), stage B(s + 1) (fetched a step ago), multiply step s, barrier
+	// step s: fetch B(s + AB) and A(s + AA), stage B(s + 1) (fetched a step ago) and A(s), multiply step s, barrier
 	for (int s0 = 0; s0 < nsteps; s0 += U) {
 #pragma unroll
 		for (int I = 0; I < U; ++I) {
 			const int s = s0 + I;
 			if (s < nsteps) {
 				load_b(fb[I % AB], s + AB);
-				load_a(fw[(I + AA) % NWB], s + AA);
+				load_a(fa[(I + AA) % NWB], s + AA);
 				__builtin_amdgcn_sched_barrier(0);
 				stage_b(fb[(I + 1) % AB], (s + 1) % 3);
-				compute(fw[I % NWB], s, s % 3);
+				stage_a(fa[I % NWB], s);
+				compute(s % 3);
 				__syncthreads();
 			}
 		}

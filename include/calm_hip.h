@@ -99,9 +99,10 @@ float* decode_sample_hip(struct Transformer* transformer, int token, int pos, in
 /* Batched prompt ingestion: the KV-cache effect of
  *     for (i = 0; i < n; ++i) forward_hip(transformer, tokens[i], pos + i, FF_UPDATE_KV_ONLY);
  * i.e. of the reference's serial prompt loop (src/run.c:208,216-218; README.md:80 "prompt processing is
- * serial"), computed 64 tokens at a time: weights are streamed once per chunk and the multiply-adds run on
- * the matrix cores in exact fp32 (v_mfma_f32_32x32x2_f32), so the cache rows agree with the serial path to
- * fp32 rounding.  Returns after the work is complete (`tokens` is host memory and may be reused).
+ * serial"), computed up to 1024 tokens at a time: weights are streamed once per chunk and the multiply-adds run on
+ * the f16 matrix cores with the fp32 activations carried as hi + lo binary16 (every product exact, fp32 accumulation:
+ * 3-7e-7 per GEMM), so the cache rows agree with the serial path to fp32 rounding.  Activations beyond +-65504 saturate.
+ * Returns after the work is complete (`tokens` is host memory and may be reused).
  * Mixture-of-experts models are routed per token on the device and each expert runs one GEMM over the rows
  * routed to it.  Positions at or beyond seq_len (rolling buffer, sink rotation between tokens) are processed
  * through the decode path one token at a time inside the call -- same result, no speed-up. */

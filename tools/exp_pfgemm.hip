@@ -90,7 +90,13 @@ static void run(const char* name, int M, int K, int nb, int iters) {
 		if constexpr (S > 0) {
 			hipLaunchKernelGGL((k_pf_gemm<8, 16, EPI, (S > 0 ? S : 1)>), grid, dim3(256), 0, 0, a);
 		} else {
-			hipLaunchKernelGGL((k_pf_gemm_wide<8, 16, EPI, (S < 0 ? -S : 1)>), grid, dim3(256), 0, 0, a);
+			auto kern = k_pf_gemm_wide<8, 16, EPI, (S < 0 ? -S : 1)>;
+			static bool once = false;
+			if (!once) {
+				CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PfWideA<8>::LDS_BYTES));
+				once = true;
+			}
+			hipLaunchKernelGGL(kern, grid, dim3(256), PfWideA<8>::LDS_BYTES, 0, a);
 		}
 	};
 	launch();
