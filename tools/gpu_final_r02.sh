@@ -1,22 +1,33 @@
 #!/bin/bash
 # Round-2 evidence session on the GPU box (outputs under gpurun_out/final_r02, summaries copied to profiles/ by hand afterwards):
-#  1. the default bench line (CPU reference timed on the same model, full-depth parity inside)
 #  2. tools/hipprof.sh over the bench command: rocprofv3 kernel trace + the library's algorithmic-byte account + FETCH_SIZE pass
+#     (first: the bench line of section 1 then quotes roofline.traffic from the PMC file this pass stamps)
+#  1. the default bench line (CPU reference timed on the same model, full-depth parity inside)
 #  3. bench lines of the other BASELINE shapes at full size (device-side weight synthesis), DBRX also as a 4-stage pipeline
 #  4. the reference CLI on this backend, first 32 / last 32 positions of a 4096 context (CALM_POSO), full 32-layer Mistral shape
 #  5. SQ counter tables of the gf4 kernels
+#  SECTIONS="1 2 3" selects (default: all five)
 TAG=${1:-r02}
+SECTIONS=${SECTIONS:-"1 2 3 4 5"}
+want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-echo "== 1. bench" | tee $OUT/summary.txt
-( time timeout 600 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
-tail -c 3600 $OUT/bench.json >> $OUT/summary.txt; tail -4 $OUT/bench.err >> $OUT/summary.txt
+: > $OUT/summary.txt
+if want 2; then
 echo "== 2. hipprof" | tee -a $OUT/summary.txt
 tools/hipprof.sh -t $TAG -w "mistral-7b fp8" -- python bench.py --no-cpu --no-device-greedy --steps 64 --warmup 8 >> $OUT/summary.txt 2>&1
 cp profiles/${TAG}_kernel_stats.md profiles/${TAG}_pmc.json $OUT/ 2>/dev/null
+fi
+if want 1; then
+echo "== 1. bench" | tee -a $OUT/summary.txt
+( time timeout 600 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
+tail -c 3600 $OUT/bench.json >> $OUT/summary.txt; tail -4 $OUT/bench.err >> $OUT/summary.txt
+fi
+if want 3; then
 echo "== 3. other shapes at full size" | tee -a $OUT/summary.txt
+rm -f $OUT/other_configs.jsonl
 for cfg in "llama-3-8b gf4" "tinyllama-1.1b fp16" "mixtral-8x7b fp8" "dbrx-132b fp8"; do
   set -- $cfg
   timeout 600 python bench.py --model $1 --dtype $2 --no-cpu >> $OUT/other_configs.jsonl 2>> $OUT/other.err; echo "$cfg exit $?" >> $OUT/summary.txt
@@ -28,6 +39,8 @@ for l in open("gpurun_out/final_r02/other_configs.jsonl"):
     d = json.loads(l)
     print(d["config"]["workload"][:40], "|", d["config"]["parallelism"][:40], "|", d["value"], "tok/s", d["achieved_GBps"], "GB/s", d["hbm_frac_of_spec"], "| ffn_up", d["stages"].get("ffn_up"))
 PY
+fi
+if want 4; then
 echo "== 4. reference CLI on the HIP backend: first / last 32 positions of a 4096 context" | tee -a $OUT/summary.txt
 if [ -x oracle/_ref/run_hip ]; then
   python -m calm_amd.calmfile mistral-7b fp8 /tmp/mistral7b_fp8.calm >> $OUT/summary.txt 2>&1
@@ -38,7 +51,10 @@ if [ -x oracle/_ref/run_hip ]; then
   done
   rm -f /tmp/mistral7b_fp8.calm
 fi
+fi
+if want 5; then
 echo "== 5. gf4 counters" | tee -a $OUT/summary.txt
 tools/pmc_kernel.sh final_${TAG}_pmc_gf4 llama-3-8b gf4 4 > /dev/null 2>&1
 cat gpurun_out/final_${TAG}_pmc_gf4/summary.txt >> $OUT/summary.txt 2>/dev/null
+fi
 cat $OUT/summary.txt
