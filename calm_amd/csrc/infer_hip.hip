@@ -157,7 +157,8 @@ struct Ctx {
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
 	// batched prompt ingestion (allocated on first use): token-major [PF_NT][...] activations of one chunk
-	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr;
+	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr, *pf_partial = nullptr;
+	unsigned* pf_tile_count = nullptr;
 	float2* pf_rope = nullptr;
 	int* pf_tok = nullptr;
 	// ... of a mixture-of-experts model: gate logits, per-expert row lists, one expert's gathered rows
@@ -695,6 +696,9 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 // ---------------------------------------------------------------- batched prompt ingestion -----
 
+constexpr size_t PF_SPLIT_SLOTS = 768; // partial tiles of a split launch (tiles x ranges: about one per CU, x 2-3 for grid padding)
+constexpr int PF_SPLIT_TILES = 4096;
+
 void pf_alloc(Ctx* c) {
 	if (c->pf_x) {
 		return;
@@ -717,6 +721,10 @@ void pf_alloc(Ctx* c) {
 	c->pf_h = frag(c->hidden, erows);
 	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
 	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
+	// k_pf_gemm_wide with K cut into ranges: partial tiles (64 KiB each) and the tiles' arrival counters (left at zero by every launch)
+	c->pf_partial = (float*)dev_alloc(PF_SPLIT_SLOTS * 16384 * sizeof(float));
+	c->pf_tile_count = (unsigned*)dev_alloc(PF_SPLIT_TILES * sizeof(unsigned));
+	HIP_CHECK(hipMemset(c->pf_tile_count, 0, PF_SPLIT_TILES * sizeof(unsigned)));
 	if (c->n_experts > 0) {
 		c->pf_gate = (float*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(float));
 		c->pf_rows = (int*)dev_alloc((size_t)erows * sizeof(int));
@@ -808,15 +816,32 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 		constexpr int epi = decltype(EPI)::value;
 		constexpr int kvb = epi == PF_EPI_QKV ? KVB : 16; // only the QKV epilogue touches the cache
 		const int nx = (a.M + PfWide<epi>::UNITS - 1) / PfWide<epi>::UNITS;
-		if (g_pf_wide && (long)nx * ncols * 4 >= (long)g_ncu * 3) {
+		const int tiles = 8 * ((nx + 7) / 8) * ncols, nsteps = pf_steps(a.K);
+		// too few tiles: the wide form with K cut into ranges (one workgroup each, the last to arrive folds the partial tiles)
+		// pays for long rows (the FFN-down: 85 against 119 us at 256 tokens, 50 against 114 at 64) and for the FFN-up of very
+		// short prompts; at K = 4096 it ties with the K-split form (profiles/r02_prefill_gemm.txt)
+		int ks = 1; // 0: the K-split form
+		if ((long)nx * ncols * 4 < (long)g_ncu * 3) {
+			ks = 0;
+			if (nsteps >= 128 || epi == PF_EPI_FFN_UP) {
+				int k = g_ncu / (nx * ncols);
+				k = k > 8 ? 8 : k;
+				k = k > nsteps / 16 ? nsteps / 16 : k;
+				if (k >= 2 && (size_t)tiles * k <= PF_SPLIT_SLOTS && tiles <= PF_SPLIT_TILES) {
+					ks = k;
+				}
+			}
+		}
+		if (g_pf_wide && ks >= 1) {
 			a.ncols = ncols;
+			a.ksplit = ks, a.partial = c->pf_partial, a.tile_count = c->pf_tile_count;
 			auto kern = k_pf_gemm_wide<DB, kvb, epi, 1>;
 			static bool lds_allowed = false; // (one flag per instantiation of this lambda: per kernel)
 			if (!lds_allowed) {
 				allow_lds(kern, PfWideA<DB>::LDS_BYTES);
 				lds_allowed = true;
 			}
-			hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nx, ncols)), block, PfWideA<DB>::LDS_BYTES, g_stream, a);
+			hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nx, ncols, ks)), block, PfWideA<DB>::LDS_BYTES, g_stream, a);
 			return;
 		}
 		if constexpr (epi == PF_EPI_FFN_UP) {
@@ -1403,7 +1428,7 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}
-	void* pf_bufs[] = {c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_wsel, c->pf_xe, c->pf_y, c->pf_rows, c->pf_colexp, c->pf_slot, c->pf_logits, c->pf_lp, c->pf_target};
+	void* pf_bufs[] = {c->pf_partial, c->pf_tile_count, c->pf_x, c->pf_xn, c->pf_q, c->pf_att, c->pf_h, c->pf_rope, c->pf_tok, c->pf_gate, c->pf_wsel, c->pf_xe, c->pf_y, c->pf_rows, c->pf_colexp, c->pf_slot, c->pf_logits, c->pf_lp, c->pf_target};
 	for (void* b : pf_bufs) {
 		if (b) {
 			HIP_CHECK(hipFree(b));

@@ -681,6 +681,12 @@ struct PfGemmArgs {
 	const int* col_expert;
 	size_t expert_stride;
 	int ncols; // k_pf_gemm_wide: token columns of the launch (its grid is one-dimensional)
+	// k_pf_gemm_wide with too few tiles to fill the chip: K is cut into ksplit ranges, one workgroup each; partial tiles go to
+	// `partial` ([tile][range][wave][register][lane] floats), the last of a tile's workgroups to bump tile_count[tile] adds them
+	// in range order (deterministic) and runs the epilogue
+	int ksplit;
+	float* partial;
+	unsigned* tile_count;
 };
 
 // operand j of a 16-byte piece of a weight row: 8 consecutive weights as binary16 (exact in all three formats).
@@ -995,12 +1001,14 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 // round robin; XCD c takes the unit blocks c, c + 8, ... and walks the token columns of one unit block before the next, so
 // that the workgroups sharing a slice of weights run at the same time on the same L2 (the slice comes from HBM once) and
 // move through k together; the token columns' B slices are shared the same way by the unit blocks in flight on the XCD.
+// Short prompts (too few tiles): x ksplit workgroups per tile, each a range of K; nobody waits for anybody -- the last of a
+// tile's workgroups to arrive folds the partial tiles in range order and runs the epilogue.
 template <int EPI>
 struct PfWide {
 	static constexpr int UNITS = EPI == PF_EPI_FFN_UP ? 128 : 256;
 };
-__host__ __device__ inline int pf_wide_grid(int nx, int ny) {
-	return 8 * ((nx + 7) / 8) * ny;
+__host__ __device__ inline int pf_wide_grid(int nx, int ny, int ksplit = 1) {
+	return 8 * ((nx + 7) / 8) * ny * ksplit;
 }
 
 // A step of A (64 columns of this wave's 64 weight rows) is fetched row-contiguous -- a wave-load covers whole 32 / 64 / 128-byte
@@ -1033,8 +1041,10 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
 	unsigned char* const aimg = (unsigned char*)(pfw_lds + 3 * 16 * 64) + wave * PfWideA<DB>::WAVE_BYTES;
-	const int ny = a.ncols;
-	const int bx = (blockIdx.x & 7) + 8 * ((blockIdx.x >> 3) / ny), by = (blockIdx.x >> 3) % ny;
+	const int ny = a.ncols, KS = a.ksplit;
+	// order within an XCD: unit block, then K range, then token column
+	const int idx = blockIdx.x >> 3;
+	const int bx = (blockIdx.x & 7) + 8 * (idx / (ny * KS)), by = idx % ny, ks = (idx / ny) % KS;
 	if (bx * PfWide<EPI>::UNITS >= a.M) {
 		return;
 	}
@@ -1050,6 +1060,7 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 	const size_t row_bytes = (size_t)a.K * DB / 8;
 	const int row_pieces = (int)(row_bytes / 16);
 	const int nsteps = pf_steps(a.K);
+	const int s_begin = (int)((long)ks * nsteps / KS), s_end = (int)((long)(ks + 1) * nsteps / KS); // this workgroup's steps
 
 	// wave-load q of a step: this lane fetches piece (lane % PR) of row q * RPL + lane / PR of the wave's 64 rows
 	// (rows 0-31: first strip, 32-63: second strip -- FFN-up: w1 and w3 of one strip).  Clamped, never branched on.
@@ -1170,27 +1181,82 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 
 #pragma unroll
 	for (int d = 0; d < AB; ++d) {
-		load_b(fb[d], d);
+		load_b(fb[d], s_begin + d);
 	}
 #pragma unroll
 	for (int d = 0; d < AA; ++d) {
-		load_a(fa[d], d);
+		load_a(fa[d], s_begin + d);
 	}
 	stage_b(fb[0], 0);
 	__syncthreads();
-	// step s: fetch B(s + AB) and A(s + AA), stage B(s + 1) (fetched a step ago) and A(s), multiply step s, barrier
-	for (int s0 = 0; s0 < nsteps; s0 += U) {
+	// step t of this workgroup's range (absolute step s): fetch B(s + AB) and A(s + AA), stage B(s + 1) (fetched a step ago) and
+	// A(s), multiply step s, barrier.  Fetches past the range read real data that is not used.
+	const int nloc = s_end - s_begin;
+	for (int t0 = 0; t0 < nloc; t0 += U) {
 #pragma unroll
 		for (int I = 0; I < U; ++I) {
-			const int s = s0 + I;
-			if (s < nsteps) {
+			const int t = t0 + I, s = s_begin + t;
+			if (t < nloc) {
 				load_b(fb[I % AB], s + AB);
 				load_a(fa[(I + AA) % NWB], s + AA);
 				__builtin_amdgcn_sched_barrier(0);
-				stage_b(fb[(I + 1) % AB], (s + 1) % 3);
+				stage_b(fb[(I + 1) % AB], (t + 1) % 3);
 				stage_a(fa[I % NWB], s);
-				compute(s % 3);
+				compute(t % 3);
 				__syncthreads();
+			}
+		}
+	}
+	if (KS > 1) {
+		// partial tile out (register order: coalesced both ways), count in; the last one in folds all of them, its own included,
+		// in range order -- the sum does not depend on who came last
+		__shared__ unsigned arrived;
+		const int tile = bx * ny + by;
+		float* mine = a.partial + (((size_t)tile * KS + ks) * 4 + wave) * (NA * NC * 16 * 64) + lane;
+#pragma unroll
+		for (int n = 0; n < NA; ++n) {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					// written through (agent scope): a fence here would write back the XCD's whole L2
+					__hip_atomic_store(mine + ((n * NC + c) * 16 + r) * 64, acc[n][c][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			arrived = __hip_atomic_fetch_add(a.tile_count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__syncthreads();
+		if (arrived != (unsigned)KS - 1) {
+			return;
+		}
+		if (threadIdx.x == 0) {
+			__hip_atomic_store(a.tile_count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+		}
+#pragma unroll
+		for (int n = 0; n < NA; ++n) {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					acc[n][c][r] = 0.f;
+				}
+			}
+		}
+		for (int p = 0; p < KS; ++p) {
+			const float* src = a.partial + (((size_t)tile * KS + p) * 4 + wave) * (NA * NC * 16 * 64) + lane;
+#pragma unroll
+			for (int n = 0; n < NA; ++n) {
+#pragma unroll
+				for (int c = 0; c < NC; ++c) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						acc[n][c][r] += __hip_atomic_load(src + ((n * NC + c) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
 			}
 		}
 	}

@@ -50,7 +50,7 @@ static float fp8_value(uint8_t b) {
 	return __half2float(h);
 }
 
-// S > 0: k_pf_gemm with S strips per wave;  S = -AA: k_pf_gemm_wide fetching A AA steps ahead
+// S > 0: k_pf_gemm with S strips per wave;  S = -1: k_pf_gemm_wide;  S = -(10 * KS + 1): k_pf_gemm_wide with K split KS ways
 template <int EPI, int S>
 static void run(const char* name, int M, int K, int nb, int iters) {
 	const int cols = (nb + 63) / 64;
@@ -85,12 +85,18 @@ static void run(const char* name, int M, int K, int nb, int iters) {
 	a.clip = 3.4e38f;
 	constexpr int UNITS = S > 0 ? PfTile<EPI, (S > 0 ? S : 1)>::UNITS : PfWide<EPI>::UNITS;
 	a.ncols = cols;
-	const dim3 grid = S > 0 ? dim3((M + UNITS - 1) / UNITS, cols) : dim3(pf_wide_grid((M + UNITS - 1) / UNITS, cols));
+	const int KS = S <= -10 ? (-S) / 10 : 1;
+	a.ksplit = KS;
+	const int ntile = 8 * (((M + UNITS - 1) / UNITS + 7) / 8) * cols;
+	CK(hipMalloc(&a.partial, (size_t)ntile * KS * 16384 * sizeof(float)));
+	CK(hipMalloc(&a.tile_count, (size_t)ntile * sizeof(unsigned)));
+	CK(hipMemset(a.tile_count, 0, (size_t)ntile * sizeof(unsigned)));
+	const dim3 grid = S > 0 ? dim3((M + UNITS - 1) / UNITS, cols) : dim3(pf_wide_grid((M + UNITS - 1) / UNITS, cols, KS));
 	auto launch = [&]() {
 		if constexpr (S > 0) {
 			hipLaunchKernelGGL((k_pf_gemm<8, 16, EPI, (S > 0 ? S : 1)>), grid, dim3(256), 0, 0, a);
 		} else {
-			auto kern = k_pf_gemm_wide<8, 16, EPI, (S < 0 ? -S : 1)>;
+			auto kern = k_pf_gemm_wide<8, 16, EPI, 1>;
 			static bool once = false;
 			if (!once) {
 				CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, PfWideA<8>::LDS_BYTES));
@@ -141,6 +147,8 @@ static void run(const char* name, int M, int K, int nb, int iters) {
 	CK(hipFree(dX));
 	CK(hipFree(dXf));
 	CK(hipFree(dOut));
+	CK(hipFree(a.partial));
+	CK(hipFree(a.tile_count));
 }
 
 int main(int argc, char** argv) {
@@ -148,18 +156,23 @@ int main(int argc, char** argv) {
 	const int iters = argc > 2 ? atoi(argv[2]) : 20;
 	run<PF_EPI_STORE, 3>("qkv-like", 6144, 4096, nb, iters);
 	run<PF_EPI_STORE, -1>("qkv-like", 6144, 4096, nb, iters);
-	run<PF_EPI_STORE, -3>("qkv-like", 6144, 4096, nb, iters);
+	run<PF_EPI_STORE, -21>("qkv-like", 6144, 4096, nb, iters);
+	run<PF_EPI_STORE, -41>("qkv-like", 6144, 4096, nb, iters);
 	run<PF_EPI_STORE, 2>("wo-like", 4096, 4096, nb, iters);
 	run<PF_EPI_STORE, -1>("wo-like", 4096, 4096, nb, iters);
-	run<PF_EPI_STORE, -3>("wo-like", 4096, 4096, nb, iters);
+	run<PF_EPI_STORE, -21>("wo-like", 4096, 4096, nb, iters);
+	run<PF_EPI_STORE, -41>("wo-like", 4096, 4096, nb, iters);
+	run<PF_EPI_STORE, -81>("wo-like", 4096, 4096, nb, iters);
 	run<PF_EPI_FFN_UP, 1>("ffn-up", 14336, 4096, nb, iters);
 	run<PF_EPI_FFN_UP, -1>("ffn-up", 14336, 4096, nb, iters);
-	run<PF_EPI_FFN_UP, -3>("ffn-up", 14336, 4096, nb, iters);
+	run<PF_EPI_FFN_UP, -21>("ffn-up", 14336, 4096, nb, iters);
 	run<PF_EPI_STORE, 2>("ffn-down", 4096, 14336, nb, iters);
 	run<PF_EPI_STORE, -1>("ffn-down", 4096, 14336, nb, iters);
-	run<PF_EPI_STORE, -3>("ffn-down", 4096, 14336, nb, iters);
+	run<PF_EPI_STORE, -41>("ffn-down", 4096, 14336, nb, iters);
+	run<PF_EPI_STORE, -81>("ffn-down", 4096, 14336, nb, iters);
 	run<PF_EPI_STORE, 2>("ragged", 1000, 4128, nb < 200 ? nb : 200, iters);
 	run<PF_EPI_STORE, -1>("ragged", 1000, 4128, nb < 200 ? nb : 200, iters);
+	run<PF_EPI_STORE, -41>("ragged", 1000, 4128, nb < 200 ? nb : 200, iters);
 	run<PF_EPI_STORE, 3>("classifier", 32000, 4096, nb, iters);
 	run<PF_EPI_STORE, -1>("classifier", 32000, 4096, nb, iters);
 	return 0;
