@@ -212,7 +212,7 @@ def main():
     # MFMA-bound on the f16 matrix cores: every weight x activation product is two v_mfma_f32_32x32x16_f16 products (the fp32
     # activation as hi + lo binary16), so the peak in algorithmic FLOPs is half the 2.5 PF dense f16 peak (MI355X_MICROARCH.md)
     prefill = None
-    if spec.n_experts == 0 and not args.no_device_greedy:
+    if not args.no_device_greedy and args.pipeline <= 1:
         n_pf = min(2048, model.config.seq_len - 1)
         prompt = [int(t) for t in np.random.default_rng(args.seed).integers(0, spec.vocab_size, size=n_pf)]
         be.prefill(prompt[:64], 0)
@@ -221,7 +221,8 @@ def main():
         be.prefill(prompt, 0)
         pf_elapsed = time.perf_counter() - t0
         q_dim, kv_dim = spec.n_heads * spec.head_dim, spec.n_kv_heads * spec.head_dim
-        flop = 2.0 * n_pf * n_layers * (spec.dim * (2 * q_dim + 2 * kv_dim) + 3 * spec.dim * spec.hidden_dim)
+        n_act = spec.n_experts_active if spec.n_experts else 1
+        flop = 2.0 * n_pf * n_layers * (spec.dim * (2 * q_dim + 2 * kv_dim) + 3 * n_act * spec.dim * spec.hidden_dim)
         prefill = {"tokens": n_pf, "tok_s": round(n_pf / pf_elapsed, 1), "vs_serial_decode": round(n_pf / pf_elapsed / tok_s, 2),
                    "roofline": {"bound": "mfma", "achieved": round(flop / pf_elapsed / 1e12, 1), "peak": 1250.0, "unit": "TFLOP/s",
                                 "frac": round(flop / pf_elapsed / 1e12 / 1250.0, 4),
