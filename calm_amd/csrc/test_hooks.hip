@@ -127,6 +127,74 @@ extern "C" int calm_hip_test_argmax(const float* logits, int n) {
 	return r;
 }
 
+namespace {
+__global__ void k_test_pf_pack(void* out, const float* X, int K) { // row-major fp32 -> the fragment-major hi + lo matrix (prefill.hip.h: pf_unit)
+	const int t = blockIdx.x;
+	for (int i = threadIdx.x; i < K / 8; i += blockDim.x) {
+		float v[8];
+		for (int e = 0; e < 8; ++e) {
+			v[e] = X[(size_t)t * K + 8 * i + e];
+		}
+		pf_store8(out, t, 8 * i, pf_steps(K), v);
+	}
+}
+} // namespace
+
+extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, float* out, int M, int K, int nb, int form) {
+	init_hip();
+	CALM_REQUIRE(K % 32 == 0 && M % 4 == 0 && nb > 0, "K must be a multiple of 32 and M of 4");
+	const int cols = (nb + 63) / 64;
+	const size_t wbytes = (size_t)M * K * dbits / 8;
+	void* dw = upload_hip((void*)w, wbytes);
+	float* dx = (float*)upload_hip((void*)x, (size_t)nb * K * sizeof(float));
+	const size_t fbytes = (size_t)cols * 64 * pf_steps(K) * 64 * sizeof(float);
+	void* dxf = dev_alloc(fbytes);
+	HIP_CHECK(hipMemsetAsync(dxf, 0, fbytes, g_stream));
+	float* dout = (float*)dev_alloc((size_t)nb * M * sizeof(float));
+	HIP_CHECK(hipMemsetAsync(dout, 0, (size_t)nb * M * sizeof(float), g_stream));
+	hipLaunchKernelGGL(k_test_pf_pack, dim3(nb), dim3(256), 0, g_stream, dxf, dx, K);
+	PfGemmArgs a;
+	memset(&a, 0, sizeof(a));
+	a.xin = (const float4*)dxf, a.w0 = dw, a.K = K, a.M = M, a.nb = nb, a.out = dout, a.clip = 3.4e38f;
+	a.ncols = cols, a.ksplit = 1;
+	constexpr int UNITS = PfWide<PF_EPI_STORE>::UNITS;
+	const int nx = (M + UNITS - 1) / UNITS, tiles = 8 * ((nx + 7) / 8) * cols;
+	if (form >= 2) {
+		CALM_REQUIRE(form <= 8 && pf_steps(K) >= form, "K ranges: 2..8, at least one step each");
+		a.ksplit = form;
+		a.partial = (float*)dev_alloc((size_t)tiles * form * 16384 * sizeof(float));
+		a.tile_count = (unsigned*)dev_alloc((size_t)tiles * sizeof(unsigned));
+		HIP_CHECK(hipMemsetAsync(a.tile_count, 0, (size_t)tiles * sizeof(unsigned), g_stream));
+	}
+	by_dbits(dbits, [&](auto DBT) {
+		constexpr int DB = decltype(DBT)::value;
+		if (form >= 1) {
+			auto kern = k_pf_gemm_wide<DB, 16, PF_EPI_STORE, 1>;
+			allow_lds(kern, PfWideA<DB>::LDS_BYTES);
+			hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nx, cols, a.ksplit)), dim3(256), PfWideA<DB>::LDS_BYTES, g_stream, a);
+		} else if (form == 0) {
+			hipLaunchKernelGGL((k_pf_gemm<DB, 16, PF_EPI_STORE, 2>), dim3((M + 63) / 64, cols), dim3(256), 0, g_stream, a);
+		} else if (form == -1) {
+			hipLaunchKernelGGL((k_pf_gemm<DB, 16, PF_EPI_STORE, 1>), dim3((M + 31) / 32, cols), dim3(256), 0, g_stream, a);
+		} else {
+			hipLaunchKernelGGL((k_pf_gemm<DB, 16, PF_EPI_STORE, 3>), dim3((M + 95) / 96, cols), dim3(256), 0, g_stream, a);
+		}
+	});
+	HIP_CHECK(hipGetLastError());
+	download_hip(out, dout, (size_t)nb * M * sizeof(float));
+	if (form >= 2) {
+		unsigned left = 0; // every tile's counter is back at zero
+		std::vector<unsigned> cnt(tiles);
+		download_hip(cnt.data(), a.tile_count, (size_t)tiles * sizeof(unsigned));
+		for (unsigned v : cnt) {
+			left |= v;
+		}
+		CALM_REQUIRE(left == 0, "a tile counter was not reset");
+		free_hip(a.partial), free_hip(a.tile_count);
+	}
+	free_hip(dw), free_hip(dx), free_hip(dxf), free_hip(dout);
+}
+
 extern "C" int calm_hip_test_sample(const float* logits, int n, float temperature, float minp, unsigned long long* rng_state) {
 	init_hip();
 	float* dl = (float*)upload_hip((void*)logits, n * sizeof(float));

@@ -32,7 +32,7 @@ EXPORTS = [
     "free_hip", "download_hip", "decode_greedy_hip", "decode_sample_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip",
 ]
 # include/calm_hip_test.h: libcalm_hip_test.so, tests and tools only
-TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_test_sample", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_membench"]
+TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_test_sample", "calm_hip_test_pf_gemm", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_membench"]
 
 
 class _Libs:
@@ -62,6 +62,7 @@ class _Libs:
                 "calm_hip_test_attn": (None, [fp, C.c_void_p, C.c_void_p, fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
                 "calm_hip_test_argmax": (C.c_int, [fp, C.c_int]),
                 "calm_hip_test_sample": (C.c_int, [fp, C.c_int, C.c_float, C.c_float, C.POINTER(C.c_ulonglong)]),
+                "calm_hip_test_pf_gemm": (None, [C.c_int, C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]),
                 "calm_hip_read_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
                 "calm_hip_write_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
                 "calm_hip_membench": (C.c_double, [C.c_size_t, C.c_int, C.c_int]),

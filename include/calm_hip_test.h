@@ -35,6 +35,10 @@ void calm_hip_test_attn(const float* q, const uint16_t* kcache, const uint16_t* 
 
 /* first index of the strict maximum (reference src/sampler.c:34-42), computed on the device */
 int calm_hip_test_argmax(const float* logits, int n);
+/* one prompt GEMM alone (prefill.hip.h): out[nb][M] = x[nb][K] . w[M][K]^T, w in a model weight format (dbits 4 / 8 / 16), x as
+ * hi + lo binary16.  form 0 / -1 / -3: k_pf_gemm with 2 / 1 / 3 unit strips per wave; 1: k_pf_gemm_wide; 2..8: k_pf_gemm_wide with
+ * K cut into that many ranges (one workgroup each, last arriver folds) */
+void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, float* out, int M, int K, int nb, int form);
 /* k_sample_minp alone on n host logits: one draw, *rng_state advanced (sampler as in src/sampler.h) */
 int calm_hip_test_sample(const float* logits, int n, float temperature, float minp, unsigned long long* rng_state);
 
