@@ -907,7 +907,8 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 		const int ecols = (nb * c->n_active + 63) / 64 + c->n_experts; // worst case for this chunk
 		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, ecols, c->pf_rows, c->pf_colexp, c->pf_slot,
 		                   c->pf_wsel);
-		hipLaunchKernelGGL(k_pf_gather, dim3(ecols * 64), block, 0, g_stream, (float4*)c->pf_xe, (const float4*)c->pf_xn, c->pf_rows, c->pf_colexp, c->dim);
+		hipLaunchKernelGGL(k_pf_gather, dim3(ecols * 2, (pf_steps(c->dim) + 7) / 8), block, 0, g_stream, (float4*)c->pf_xe, (const float4*)c->pf_xn, c->pf_rows, c->pf_colexp,
+		                   c->dim);
 		PfGemmArgs m = a;
 		m.nb = ecols * 64;
 		m.col_expert = c->pf_colexp, m.expert_stride = (size_t)c->hidden * c->dim * DB / 8;

@@ -146,13 +146,21 @@ __global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, cons
 // grouped GEMM launch serves all experts:
 //   rows[r]      token of packed row r, or -1 for padding          col_expert[c]  expert of column c, -1 past the end
 //   slot[t*k+j]  packed row of token t's rank-j expert             wsel[t*k+j]    its routing weight
-// One workgroup of PF_NT threads; everything is in token order (deterministic).
+// One workgroup of PF_NT threads, thread t = token t; everything is in token order (deterministic): a token's place in its
+// expert's group is the number of earlier tokens routed to that expert -- a ballot per expert within the wave plus the waves'
+// counts (a token routes to an expert at most once).
 __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int max_cols, int* rows, int* col_expert, int* slot,
                                                     float* wsel) {
-	__shared__ int se[PF_NT * PF_MAX_ACTIVE];
+	constexpr int NW = PF_NT / 64;
+	__shared__ int wave_cnt[CALM_MAX_EXPERTS][NW]; // tokens of wave w routed to expert e, then the exclusive prefix over w
 	__shared__ int first_col[CALM_MAX_EXPERTS + 1];
 	__shared__ int cnt[CALM_MAX_EXPERTS];
-	const int t = threadIdx.x;
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	int mine[PF_MAX_ACTIVE], inwave[PF_MAX_ACTIVE];
+#pragma unroll
+	for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+		mine[k] = -1, inwave[k] = 0;
+	}
 	if (t < nb) {
 		const float* g = gate + (size_t)t * n_experts;
 		float max_val = -3.402823466e+38f;
@@ -161,26 +169,52 @@ __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, i
 		}
 		unsigned long long mask = 0;
 		float wsum = 0.f;
-		for (int k = 0; k < n_active; ++k) {
-			int best = -1;
-			for (int j = 0; j < n_experts; ++j) {
-				if ((mask & (1ull << j)) == 0 && (best == -1 || g[j] > g[best])) {
-					best = j;
+#pragma unroll
+		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+			if (k < n_active) {
+				int best = -1;
+				for (int j = 0; j < n_experts; ++j) {
+					if ((mask & (1ull << j)) == 0 && (best == -1 || g[j] > g[best])) {
+						best = j;
+					}
 				}
+				mine[k] = best;
+				wsum += expf(g[best] - max_val);
+				mask |= 1ull << best;
 			}
-			se[t * n_active + k] = best;
-			wsum += expf(g[best] - max_val);
-			mask |= 1ull << best;
 		}
-		for (int k = 0; k < n_active; ++k) {
-			wsel[t * n_active + k] = expf(g[se[t * n_active + k]] - max_val) / wsum;
+#pragma unroll
+		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+			if (k < n_active) {
+				wsel[t * n_active + k] = expf(g[mine[k]] - max_val) / wsum;
+			}
+		}
+	}
+	const unsigned long long below = (1ull << lane) - 1;
+	for (int e = 0; e < n_experts; ++e) {
+		bool to_e = false;
+#pragma unroll
+		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+			to_e |= mine[k] == e;
+		}
+		const unsigned long long m = __ballot(to_e);
+		if (lane == 0) {
+			wave_cnt[e][wave] = __popcll(m);
+		}
+#pragma unroll
+		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+			if (mine[k] == e) {
+				inwave[k] = __popcll(m & below);
+			}
 		}
 	}
 	__syncthreads();
 	if (t < n_experts) {
 		int c = 0;
-		for (int i = 0; i < nb * n_active; ++i) {
-			c += se[i] == t;
+		for (int w = 0; w < NW; ++w) {
+			const int n = wave_cnt[t][w];
+			wave_cnt[t][w] = c;
+			c += n;
 		}
 		cnt[t] = c;
 	}
@@ -199,36 +233,40 @@ __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, i
 		}
 	}
 	__syncthreads();
-	if (t < n_experts) {
-		int r = first_col[t] * 64;
-		for (int tok = 0; tok < nb; ++tok) {
-			for (int k = 0; k < n_active; ++k) {
-				if (se[tok * n_active + k] == t) {
-					rows[r] = tok;
-					slot[tok * n_active + k] = r;
-					++r;
-				}
-			}
+#pragma unroll
+	for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+		if (mine[k] >= 0) {
+			const int r = first_col[mine[k]] * 64 + wave_cnt[mine[k]][wave] + inwave[k];
+			rows[r] = t;
+			slot[t * n_active + k] = r;
 		}
-		for (; r < first_col[t + 1] * 64; ++r) {
+	}
+	// the padding of every expert's last column
+	for (int e = 0; e < n_experts; ++e) {
+		for (int r = first_col[e] * 64 + cnt[e] + t; r < first_col[e + 1] * 64; r += PF_NT) {
 			rows[r] = -1;
 		}
 	}
 }
 
-// packed row r (fragment-major) = row rows[r] of src; padding rows keep whatever they held (finite)
+// packed row r (fragment-major) = row rows[r] of src; padding rows keep whatever they held (finite).
+// A wave writes whole 1 KiB blocks of the destination ([32-row group][step][MFMA][hi, lo][lane]: 64 consecutive units) and
+// fetches, per lane, the unit of its row's source token from the L2-resident source matrix.
+// grid = (row groups of 32, ceil(nsteps / 8)), 256 threads
 __global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* src, const int* rows, const int* col_expert, int n) {
-	const int r = blockIdx.x;
-	if (col_expert[r >> 6] < 0) {
+	const int g = blockIdx.x, lane = lane_id(), wave = wave_id();
+	if (col_expert[g >> 1] < 0) {
 		return;
 	}
-	const int t = rows[r], nsteps = pf_steps(n);
+	const int t = rows[32 * g + (lane & 31)], nsteps = pf_steps(n);
+	const int s0 = blockIdx.y * 8, s1 = min(s0 + 8, nsteps);
 	if (t < 0) {
 		return;
 	}
-	for (int k4 = threadIdx.x; k4 < (n >> 2); k4 += 256) { // the hi units of a row, then its lo units: all of them
-		const int k = (k4 >> 1) * 8, hl = (k4 & 1) * 64;
-		dst[pf_unit(r, k, nsteps) + hl] = src[pf_unit(t, k, nsteps) + hl];
+	const float4* sp = src + (size_t)(t >> 5) * nsteps * 512 + (lane & 32) + (t & 31);
+	float4* dp = dst + (size_t)g * nsteps * 512 + lane;
+	for (int b = s0 * 8 + wave; b < s1 * 8; b += 4) { // block b: step b / 8, (MFMA, hi / lo) b % 8
+		dp[(size_t)b * 64] = sp[(size_t)b * 64];
 	}
 }
 
