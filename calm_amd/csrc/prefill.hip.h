@@ -756,7 +756,69 @@ __device__ __forceinline__ f16x8 pf_operand(u32x4 v, int j) {
 	return __builtin_bit_cast(f16x8, r);
 }
 
-// Epilogue of a wave's NA x NC accumulator tiles (32 units x 32 tokens each; FFN-up: NA = 2 are w1 and w3 of one strip).
+// What happens to four consecutive output units ub .. ub + 3 (ub a multiple of 4, ub < M) of one token -- everything but the
+// FFN-up's gated activation, which needs two accumulators.
+template <int KVB, int EPI>
+__device__ __forceinline__ void pf_epi4(const PfGemmArgs& a, const int token, const int ub, const float (&v)[4]) {
+	if constexpr (EPI == PF_EPI_RESID) {
+		float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
+		float4 t = *p;
+		t.x += v[0], t.y += v[1], t.z += v[2], t.w += v[3];
+		*p = t;
+	} else if constexpr (EPI == PF_EPI_STORE) { // M is arbitrary here (a vocabulary): bounded; one 16-byte store where the rows allow it
+		if ((a.M & 3) == 0) {
+			*(float4*)(a.out + (size_t)token * a.M + ub) = make_float4(v[0], v[1], v[2], v[3]);
+		} else {
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				if (ub + e < a.M) {
+					a.out[(size_t)token * a.M + ub + e] = v[e];
+				}
+			}
+		}
+	} else {
+		static_assert(EPI == PF_EPI_QKV, "the FFN-up epilogue is not per accumulator");
+		float r[4];
+#pragma unroll
+		for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
+			const int uu = ub + 2 * pr;
+			float v0 = v[2 * pr], v1 = v[2 * pr + 1];
+			if (a.bqkv) {
+				v0 += a.bqkv[uu];
+				v1 += a.bqkv[uu + 1];
+			}
+			v0 = clipf(v0, a.clip);
+			v1 = clipf(v1, a.clip);
+			if (uu < a.q_dim + a.kv_dim) { // src/infer.c:223-236
+				const int ul = uu < a.q_dim ? uu : uu - a.q_dim;
+				const float2 cs = a.rope[(size_t)token * (a.head_dim >> 1) + ((ul % a.head_dim) >> 1)];
+				const float r0 = v0 * cs.x - v1 * cs.y, r1 = v0 * cs.y + v1 * cs.x;
+				v0 = r0, v1 = r1;
+			}
+			r[2 * pr] = v0, r[2 * pr + 1] = v1;
+		}
+		if (ub < a.q_dim) {
+			*(float4*)(a.out + (size_t)token * a.q_dim + ub) = make_float4(r[0], r[1], r[2], r[3]);
+		} else {
+			int jl = ub - a.q_dim;
+			void* cache = a.kc;
+			if (jl >= a.kv_dim) {
+				jl -= a.kv_dim;
+				cache = a.vc;
+			}
+			const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
+			if constexpr (KVB == 16) { // src/infer.c:378-381
+				const __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]);
+				*(u32x2*)((__half*)cache + off) = (u32x2){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+			} else {
+				*(unsigned*)((unsigned char*)cache + off) = (unsigned)e5m2x2_sat(r[0], r[1]) | ((unsigned)e5m2x2_sat(r[2], r[3]) << 16);
+			}
+		}
+	}
+}
+
+// Epilogue of a wave's NA x NC accumulator tiles (32 units x 32 tokens each; FFN-up: NA = 2 are w1 and w3 of one strip),
+// straight from the accumulator registers: a lane stores for ITS token (one cache line per lane and store).
 // C layout: column (token) = lane & 31, row (unit) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
 template <int KVB, int EPI, int NA, int NC>
 __device__ __forceinline__ void pf_epilogue(const PfGemmArgs& a, const f32x16 (&acc)[NA][NC], const int unit0, const int tok0, const int j, const int kk) {
@@ -771,23 +833,11 @@ __device__ __forceinline__ void pf_epilogue(const PfGemmArgs& a, const f32x16 (&
 		for (int n = 0; n < (EPI == PF_EPI_FFN_UP ? 1 : NA); ++n) {
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
-				const int ub = unit0 + 32 * n + 8 * g + 4 * kk; // four consecutive units; M is a multiple of 4
+				const int ub = unit0 + 32 * n + 8 * g + 4 * kk; // four consecutive units; M is a multiple of 4 (a vocabulary may not be)
 				if (ub >= a.M) {
 					continue;
 				}
-				if constexpr (EPI == PF_EPI_RESID) {
-					float4* p = (float4*)(a.out + (size_t)token * a.M + ub);
-					float4 t = *p;
-					t.x += acc[n][c][4 * g], t.y += acc[n][c][4 * g + 1], t.z += acc[n][c][4 * g + 2], t.w += acc[n][c][4 * g + 3];
-					*p = t;
-				} else if constexpr (EPI == PF_EPI_STORE) { // M is arbitrary here (a vocabulary): scalar, bounded stores
-#pragma unroll
-					for (int e = 0; e < 4; ++e) {
-						if (ub + e < a.M) {
-							a.out[(size_t)token * a.M + ub + e] = acc[n][c][4 * g + e];
-						}
-					}
-				} else if constexpr (EPI == PF_EPI_FFN_UP) {
+				if constexpr (EPI == PF_EPI_FFN_UP) {
 					float h[4];
 #pragma unroll
 					for (int e = 0; e < 4; ++e) {
@@ -796,40 +846,37 @@ __device__ __forceinline__ void pf_epilogue(const PfGemmArgs& a, const f32x16 (&
 					}
 					pf_store4(a.out, token, ub, pf_steps(a.M), h);
 				} else {
-#pragma unroll
-					for (int pr = 0; pr < 2; ++pr) { // RoPE pairs (2i, 2i+1); q / k / v boundaries are multiples of 8
-						const int uu = ub + 2 * pr;
-						float v0 = acc[n][c][4 * g + 2 * pr], v1 = acc[n][c][4 * g + 2 * pr + 1];
-						if (a.bqkv) {
-							v0 += a.bqkv[uu];
-							v1 += a.bqkv[uu + 1];
-						}
-						v0 = clipf(v0, a.clip);
-						v1 = clipf(v1, a.clip);
-						if (uu < a.q_dim + a.kv_dim) { // src/infer.c:223-236
-							const int ul = uu < a.q_dim ? uu : uu - a.q_dim;
-							const float2 cs = a.rope[(size_t)token * (a.head_dim >> 1) + ((ul % a.head_dim) >> 1)];
-							const float r0 = v0 * cs.x - v1 * cs.y, r1 = v0 * cs.y + v1 * cs.x;
-							v0 = r0, v1 = r1;
-						}
-						if (uu < a.q_dim) {
-							*(float2*)(a.out + (size_t)token * a.q_dim + uu) = make_float2(v0, v1);
-						} else {
-							int jl = uu - a.q_dim;
-							void* cache = a.kc;
-							if (jl >= a.kv_dim) {
-								jl -= a.kv_dim;
-								cache = a.vc;
-							}
-							const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
-							if constexpr (KVB == 16) {
-								*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // src/infer.c:378-381
-							} else {
-								*(unsigned short*)((unsigned char*)cache + off) = e5m2x2_sat(v0, v1);
-							}
-						}
-					}
+					const float v[4] = {acc[n][c][4 * g], acc[n][c][4 * g + 1], acc[n][c][4 * g + 2], acc[n][c][4 * g + 3]};
+					pf_epi4<KVB, EPI>(a, token, ub, v);
 				}
+			}
+		}
+	}
+}
+
+// The same for the wide form's 2 x 2 tiles (64 units x 64 tokens per wave), through a wave-private LDS image [32 tokens][64
+// units (+ 4)]: a store instruction then covers four tokens x 64 consecutive units -- eight cache lines instead of sixty-four
+// (the token-per-lane stores were 8-20 % of a GEMM, profiles/r02_prefill_gemm.txt).  `img`: 32 x 68 floats of LDS nobody else uses.
+template <int KVB, int EPI>
+__device__ __forceinline__ void pf_epilogue_rows(const PfGemmArgs& a, const f32x16 (&acc)[2][2], const int unit0, const int tok0, float* img) {
+	const int lane = lane_id(), j = lane & 31, kk = lane >> 5;
+#pragma unroll
+	for (int c = 0; c < 2; ++c) {
+#pragma unroll
+		for (int n = 0; n < 2; ++n) {
+#pragma unroll
+			for (int g = 0; g < 4; ++g) {
+				*(float4*)(img + j * 68 + 32 * n + 8 * g + 4 * kk) = make_float4(acc[n][c][4 * g], acc[n][c][4 * g + 1], acc[n][c][4 * g + 2], acc[n][c][4 * g + 3]);
+			}
+		}
+		const int ub = unit0 + 4 * (lane & 15);
+#pragma unroll
+		for (int it = 0; it < 8; ++it) {
+			const int row = 4 * it + (lane >> 4), token = tok0 + 32 * c + row;
+			const float4 t = *(const float4*)(img + row * 68 + 4 * (lane & 15));
+			if (token < a.nb && ub < a.M) {
+				const float v[4] = {t.x, t.y, t.z, t.w};
+				pf_epi4<KVB, EPI>(a, token, ub, v);
 			}
 		}
 	}
@@ -1298,7 +1345,15 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 			}
 		}
 	}
-	pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+	if constexpr (EPI == PF_EPI_FFN_UP) {
+		pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk); // its fragment-major stores are 512 bytes contiguous as they are
+	} else {
+		if (a.M & 3) { // a vocabulary that is not a multiple of 4: rows are not 16-byte aligned
+			pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+		} else { // the B ring is free: every wave has passed the loop's last barrier
+			pf_epilogue_rows<KVB, EPI>(a, acc, unit0, tok0, (float*)pfw_lds + wave * (32 * 68));
+		}
+	}
 }
 
 } // namespace calm
