@@ -13,6 +13,11 @@
 // 1e-3 logits parity with the CPU path; the split measures 4..8e-7 (tools/hilo_study.py), the same as the f32
 // MFMA form this file used before (bit-for-bit an fmaf chain, 157 TF peak).  Activations beyond +-65504 saturate.
 //
+// Two GEMM forms.  k_pf_gemm (next paragraph) fills the chip from few tiles by splitting K over the waves of a workgroup: short
+// prompts.  k_pf_gemm_wide (further down: B staged once per workgroup through LDS, A through a wave-private LDS image, XCD-aware
+// workgroup order, optionally K cut into ranges across workgroups) moves 2.5 x fewer operand bytes per multiply-add through the
+// vector memory path and takes over as soon as its 256 x 64 tiles cover the chip.  Attention has its own matrix-core kernel.
+//
 // GEMM structure (k_pf_gemm).  A wave owns NA x 2 accumulator tiles of 32 units x 32 tokens: NA = 1..3 unit
 // strips (QKV, residual, classifier GEMMs; the count that wastes the fewest workgroup rounds) or the w1 / w3 pair
 // of one strip (FFN-up), times two token tiles -- so every decoded weight feeds two MFMAs and every activation
@@ -25,7 +30,7 @@
 //      matrix (pf_unit below): a wave's 16-byte loads are 1 KiB contiguous, and the matrix is L2 resident.
 // The k order inside the dot product is permuted (both operands agree), which fp32 addition does not mind
 // beyond rounding.  Operands of the next sub-step are loaded (double buffer, scheduling barrier) before the
-// current one's 64..192 MFMAs are issued.  Mixture-of-experts layers run the same kernel as a grouped GEMM
+// current one's 8..48 MFMAs are issued.  Mixture-of-experts layers run the same kernel as a grouped GEMM
 // (k_pf_route packs the rows, a workgroup column looks up its expert).
 #pragma once
 
