@@ -799,13 +799,13 @@ void launch_pf_attn(Ctx* c, int l, int nb, int pos0) {
 // one chunk of nb <= PF_NT tokens at positions pos0 .. pos0 + nb - 1 (no wrap of the rolling buffer):
 // the layer loop of src/infer.c:349-458 with a token dimension
 template <int DB, int KVB>
-void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
+void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	struct Config* p = &c->t->config;
 	struct Weights* w = &c->t->weights;
 	const int half_hd = c->head_dim / 2;
 	const int n0 = c->dim > half_hd ? c->dim : half_hd;
-	hipLaunchKernelGGL((k_pf_begin<DB>), dim3((n0 + 255) / 256, nb), dim3(256), 0, g_stream, c->pf_tok, pos0, c->pf_x, w->token_embedding_table, c->dim, c->rope_freq,
-	                   c->pf_rope, half_hd);
+	hipLaunchKernelGGL((k_pf_begin<DB>), dim3((n0 + 255) / 256, nb), dim3(256), 0, g_stream, c->pf_tok, pos0, c->pf_x,
+	                   embed ? w->token_embedding_table : nullptr, c->dim, c->rope_freq, c->pf_rope, half_hd);
 	const dim3 block(256);
 	const int cols = (nb + 63) / 64;
 	// Two forms of the GEMM (prefill.hip.h).  Enough tiles to fill the chip without splitting K (256 units x 64 tokens per
@@ -836,11 +836,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 			a.ncols = ncols;
 			a.ksplit = ks, a.partial = c->pf_partial, a.tile_count = c->pf_tile_count;
 			auto kern = k_pf_gemm_wide<DB, kvb, epi, 1>;
-			static bool lds_allowed = false; // (one flag per instantiation of this lambda: per kernel)
-			if (!lds_allowed) {
-				allow_lds(kern, PfWideA<DB>::LDS_BYTES);
-				lds_allowed = true;
-			}
+			allow_lds(kern, PfWideA<DB>::LDS_BYTES); // (an attribute of the function on the current device)
 			hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nx, ncols, ks)), block, PfWideA<DB>::LDS_BYTES, g_stream, a);
 			return;
 		}
@@ -928,10 +924,10 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
 	HIP_CHECK(hipGetLastError());
 }
 
-void dispatch_prefill_chunk(Ctx* c, int nb, int pos0, bool score) {
+void dispatch_prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed = true) {
 #define CASE(db, kvb)                       \
 	if (c->dbits == db && c->kvbits == kvb) \
-	return prefill_chunk<db, kvb>(c, nb, pos0, score)
+	return prefill_chunk<db, kvb>(c, nb, pos0, score, embed)
 	CASE(16, 16);
 	CASE(8, 16);
 	CASE(4, 16);
@@ -1272,6 +1268,11 @@ struct MultiCtx {
 	std::vector<struct Transformer*> stage; // one trimmed struct Transformer per stage, each prepared on its own device
 	std::vector<std::vector<void*>> owned;  // the device copies of each stage's tensors
 	std::vector<hipEvent_t> handoff;        // stage s's residual stream has arrived on stage s + 1
+	// Stage s + 1 has finished the step (or prompt chunk) whose input it was handed: only then may stage s overwrite that input
+	// with the next one.  Steps that return logits end with a host synchronisation and cannot overlap, but FF_UPDATE_KV_ONLY
+	// steps -- run.c's prompt loop -- are only enqueued: without this a faster stage s runs ahead into stage s + 1's residual.
+	std::vector<hipEvent_t> done;
+	std::vector<char> done_valid;
 };
 std::map<struct Transformer*, MultiCtx*> g_multi;
 
@@ -1335,6 +1336,12 @@ void prepare_multi(struct Transformer* t) {
 			HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
 			m->handoff.push_back(e);
 		}
+		{
+			hipEvent_t e;
+			HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+			m->done.push_back(e);
+			m->done_valid.push_back(0);
+		}
 		l0 += n;
 	}
 	g_pending_uploads.clear();
@@ -1360,8 +1367,15 @@ float* forward_multi(MultiCtx* m, int token, int pos, unsigned flags) {
 		sp.kv_only = kv_only || s + 1 < P; // only the last stage has a final norm and a classifier
 		sp.copy_logits = !sp.kv_only;
 		run_step(c, token, nullptr, pos, sp, s == 0);
+		if (s > 0) {
+			HIP_CHECK(hipEventRecord(m->done[s], g_stream)); // this stage is through with the x it was handed
+			m->done_valid[s] = 1;
+		}
 		if (s + 1 < P) {
 			Ctx* nx = ctx_of(m->stage[s + 1]);
+			if (m->done_valid[s + 1]) {
+				HIP_CHECK(hipStreamWaitEvent(g_stream, m->done[s + 1], 0)); // ... of the step before: its x may go now
+			}
 			HIP_CHECK(hipMemcpyPeerAsync(nx->x, g_devs[s + 1].dev, c->x, g_devs[s].dev, (size_t)c->dim * sizeof(float), g_stream));
 			HIP_CHECK(hipEventRecord(m->handoff[s], g_stream));
 		}
@@ -1400,6 +1414,9 @@ extern "C" void release_hip(struct Transformer* t) {
 			free(m->stage[s]);
 		}
 		for (hipEvent_t e : m->handoff) {
+			HIP_CHECK(hipEventDestroy(e));
+		}
+		for (hipEvent_t e : m->done) {
 			HIP_CHECK(hipEventDestroy(e));
 		}
 		use_dev(0);
@@ -1487,61 +1504,112 @@ extern "C" void copy_hip(void* dst, const void* src, size_t size) {
 
 namespace {
 
-// prefill_hip / prefill_logprobs_hip: logprob == nullptr -> KV cache only
+// prefill_hip / prefill_logprobs_hip: logprob == nullptr -> KV cache only.  A model sharded inside the library
+// (CALM_HIP_DEVICES) runs a chunk stage after stage: the residual rows X[nb][dim] cross with hipMemcpyPeerAsync + the
+// hand-off event, as one token's x does in forward_multi; scoring happens on the last stage.
 void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, float* logprob) {
-	Ctx* c = ctx_of(t);
+	std::vector<Ctx*> st;
+	MultiCtx* m = nullptr;
+	auto mt = g_multi.find(t);
+	if (mt != g_multi.end()) {
+		m = mt->second;
+		for (struct Transformer* stage : m->stage) {
+			st.push_back(ctx_of(stage));
+		}
+	} else {
+		st.push_back(ctx_of(t));
+	}
+	const int P = (int)st.size();
+	Ctx* const first = st.front();
+	Ctx* const last = st.back();
+	auto on_stage = [&](int s) {
+		if (m) {
+			use_dev(s);
+		}
+	};
 	CALM_REQUIRE(n >= 0 && pos >= 0, "negative token count / position");
 	for (int i = 0; i < n; ++i) {
-		CALM_REQUIRE(tokens[i] >= 0 && tokens[i] < c->vocab, "token out of range");
+		CALM_REQUIRE(tokens[i] >= 0 && tokens[i] < first->vocab, "token out of range");
 	}
-	CALM_REQUIRE(!logprob || (t->weights.wcls && t->weights.rms_final_weight), "scoring needs the final norm and the classifier");
+	CALM_REQUIRE(!logprob || (last->t->weights.wcls && last->t->weights.rms_final_weight), "scoring needs the final norm and the classifier");
 	// The batched path covers the positions before the rolling buffer wraps; positions at or past seq_len
 	// (sink rotation between tokens) go through the decode path one token at a time, still on the device.
 	int done = 0;
-	if ((c->n_experts == 0 || c->n_active <= PF_MAX_ACTIVE) && c->t->weights.token_embedding_table) {
-		pf_alloc(c);
-		if (logprob && !c->pf_logits) {
-			c->pf_logits = (float*)dev_alloc((size_t)PF_NT * c->vocab * sizeof(float));
-			c->pf_lp = (float*)dev_alloc(PF_NT * sizeof(float));
-			c->pf_target = (int*)dev_alloc(PF_NT * sizeof(int));
+	if ((first->n_experts == 0 || first->n_active <= PF_MAX_ACTIVE) && first->t->weights.token_embedding_table) {
+		for (int s = 0; s < P; ++s) {
+			on_stage(s);
+			pf_alloc(st[s]);
 		}
-		while (done < n && pos + done < c->seq_len) {
+		if (logprob && !last->pf_logits) { // (the last stage's device is current)
+			last->pf_logits = (float*)dev_alloc((size_t)PF_NT * last->vocab * sizeof(float));
+			last->pf_lp = (float*)dev_alloc(PF_NT * sizeof(float));
+			last->pf_target = (int*)dev_alloc(PF_NT * sizeof(int));
+		}
+		while (done < n && pos + done < first->seq_len) {
 			int nb = n - done < PF_NT ? n - done : PF_NT;
-			if (pos + done + nb > c->seq_len) {
-				nb = c->seq_len - (pos + done);
+			if (pos + done + nb > first->seq_len) {
+				nb = first->seq_len - (pos + done);
 			}
-			HIP_CHECK(hipMemcpyAsync(c->pf_tok, tokens + done, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
-			if (logprob) {
-				int target[PF_NT];
-				for (int b = 0; b < nb; ++b) {
-					target[b] = done + b + 1 < n ? tokens[done + b + 1] : -1;
+			int target[PF_NT];
+			for (int s = 0; s < P; ++s) {
+				on_stage(s);
+				Ctx* c = st[s];
+				if (s == 0) {
+					HIP_CHECK(hipMemcpyAsync(c->pf_tok, tokens + done, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
+				} else {
+					HIP_CHECK(hipStreamWaitEvent(g_stream, m->handoff[s - 1], 0));
 				}
-				HIP_CHECK(hipMemcpyAsync(c->pf_target, target, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
+				const bool score = logprob != nullptr && s == P - 1;
+				if (score) {
+					for (int b = 0; b < nb; ++b) {
+						target[b] = done + b + 1 < n ? tokens[done + b + 1] : -1;
+					}
+					HIP_CHECK(hipMemcpyAsync(c->pf_target, target, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
+				}
+				dispatch_prefill_chunk(c, nb, pos + done, score, s == 0);
+				if (s > 0) {
+					HIP_CHECK(hipEventRecord(m->done[s], g_stream));
+					m->done_valid[s] = 1;
+				}
+				if (s + 1 < P) {
+					if (m->done_valid[s + 1]) { // stage s + 1 is through with the chunk (or step) before
+						HIP_CHECK(hipStreamWaitEvent(g_stream, m->done[s + 1], 0));
+					}
+					HIP_CHECK(hipMemcpyPeerAsync(st[s + 1]->pf_x, g_devs[s + 1].dev, c->pf_x, g_devs[s].dev, (size_t)nb * c->dim * sizeof(float), g_stream));
+					HIP_CHECK(hipEventRecord(m->handoff[s], g_stream));
+				}
 			}
-			dispatch_prefill_chunk(c, nb, pos + done, logprob != nullptr);
-			if (logprob) {
-				HIP_CHECK(hipMemcpyAsync(logprob + done, c->pf_lp, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, g_stream));
-				HIP_CHECK(hipStreamSynchronize(g_stream)); // `target` lives on this stack frame
+			if (logprob) { // (the last stage's stream; `target` lives on this stack frame)
+				HIP_CHECK(hipMemcpyAsync(logprob + done, last->pf_lp, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, g_stream));
+				HIP_CHECK(hipStreamSynchronize(g_stream));
 			}
 			done += nb;
 		}
 	}
 	for (; done < n; ++done) {
-		StepPlan sp = {};
-		sp.kv_only = logprob == nullptr;
-		sp.copy_logits = !sp.kv_only;
-		run_step(c, tokens[done], nullptr, pos + done, sp);
+		const float* l = nullptr;
+		if (m) {
+			l = forward_multi(m, tokens[done], pos + done, logprob ? 0u : (unsigned)FF_UPDATE_KV_ONLY);
+			on_stage(P - 1);
+		} else {
+			StepPlan sp = {};
+			sp.kv_only = logprob == nullptr;
+			sp.copy_logits = !sp.kv_only;
+			run_step(first, tokens[done], nullptr, pos + done, sp);
+			if (logprob) {
+				HIP_CHECK(hipStreamSynchronize(g_stream));
+				l = first->logits_h;
+			}
+		}
 		if (logprob) {
-			HIP_CHECK(hipStreamSynchronize(g_stream));
 			float lp = 0.f;
 			if (done + 1 < n) { // src/sampler.c:19-32, then the log of src/run.c:298
-				const float* l = c->logits_h;
 				float mx = l[0];
-				for (int i = 1; i < c->vocab; ++i) {
+				for (int i = 1; i < last->vocab; ++i) {
 					mx = l[i] > mx ? l[i] : mx;
 				}
 				float sum = 0.f;
-				for (int i = 0; i < c->vocab; ++i) {
+				for (int i = 0; i < last->vocab; ++i) {
 					sum += expf(l[i] - mx);
 				}
 				lp = (l[tokens[done + 1]] - mx) - logf(sum);
@@ -1549,7 +1617,10 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 			logprob[done] = lp;
 		}
 	}
-	HIP_CHECK(hipStreamSynchronize(g_stream)); // `tokens` may be reused by the caller; KV rows are complete
+	// `tokens` may be reused by the caller; KV rows are complete: the last stage's stream is behind every hand-off
+	on_stage(P - 1);
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	on_stage(0);
 }
 
 } // namespace

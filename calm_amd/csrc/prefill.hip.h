@@ -97,7 +97,7 @@ template <int DB>
 __global__ void k_pf_begin(const int* tokens, int pos0, float* X, const void* embed, int dim, const float* rope_freq, float2* rope, int half_hd) {
 	const int b = blockIdx.y;
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
-	if (i < dim) {
+	if (embed && i < dim) { // (a later pipeline stage receives X from the stage before it)
 		X[(size_t)b * dim + i] = decode_elem<DB>(embed, (size_t)tokens[b] * dim + i);
 	}
 	if (i < half_hd) {

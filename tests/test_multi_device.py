@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, ROOT, load_golden
+from calm_amd import abi
 from calm_amd.host import HipBackend, load_lib
 from oracle import oracle
 
@@ -66,6 +67,106 @@ def test_stages_in_one_process_reproduce_the_single_device_logits(hiplib, tmp_pa
             assert np.array_equal(got[pos], want), (case, stages, pos, float(np.abs(got[pos] - want).max()))
     finally:
         b.close()
+
+
+KVONLY_WORKER = textwrap.dedent(
+    """
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["CALM_ROOT"])
+    from calm_amd import abi
+    from calm_amd.host import HipBackend, HostModel
+    model = HostModel.from_file(os.environ["CALM_MODEL"])
+    toks = json.loads(os.environ["CALM_TOKENS"])
+    out = []
+    for n in json.loads(os.environ["CALM_CUTS"]):
+        b = HipBackend(model)
+        for pos in range(n):  # run.c's prompt loop: enqueued, not synchronised (src/run.c:208,216-218)
+            b.forward(toks[pos], pos, abi.FF_UPDATE_KV_ONLY)
+        out.append(b.forward(toks[n], n, 0).copy())
+        b.close()
+    np.save(os.environ["CALM_OUT"], np.stack(out))
+    """
+)
+
+
+@pytest.mark.parametrize("case", ["sink_fp16", "tiny_fp8", "moe_fp8"])
+def test_runs_of_kv_only_steps_on_a_sharded_model(hiplib, tmp_path, case):
+    """FF_UPDATE_KV_ONLY steps are only enqueued: nothing but the stages' own events keeps stage 0 from running ahead into stage
+    1's residual stream.  Prompts of several lengths (past seq_len for the sink model) fed as runs of KV-only steps, then one
+    step with logits: the golden logits of the reference, and the unsharded backend bit for bit."""
+    model, z = load_golden(case)
+    if model.config.n_layers < 2:
+        pytest.skip("fewer layers than stages")
+    toks = [int(t) for t in z["tokens"]]
+    cuts = [n for n in (3, 8, 16, 17, 20, len(toks) - 1) if n < len(toks)]
+    out = str(tmp_path / f"kv_{case}.npy")
+    env = dict(os.environ, CALM_ROOT=ROOT, CALM_MODEL=os.path.join(GOLDEN, case + ".calm"), CALM_TOKENS=json.dumps(toks), CALM_OUT=out, CALM_CUTS=json.dumps(cuts),
+               CALM_HIP_DEVICES="2")
+    r = subprocess.run([sys.executable, "-c", KVONLY_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = np.load(out)
+    for i, n in enumerate(cuts):
+        assert np.abs(got[i] - z["logits"][n]).max() < 1e-3 * np.abs(z["logits"][n]).max(), (case, n)
+        b = HipBackend(model)
+        try:
+            for pos in range(n):
+                b.forward(toks[pos], pos, abi.FF_UPDATE_KV_ONLY)
+            assert np.array_equal(got[i], b.forward(toks[n], n, 0)), (case, n)
+        finally:
+            b.close()
+
+
+PREFILL_WORKER = textwrap.dedent(
+    """
+    import json, os, sys
+    import numpy as np
+    sys.path.insert(0, os.environ["CALM_ROOT"])
+    from calm_amd.host import HipBackend, HostModel
+    model = HostModel.from_file(os.environ["CALM_MODEL"])
+    toks = json.loads(os.environ["CALM_TOKENS"])
+    n = int(os.environ["CALM_NPROMPT"])
+    b = HipBackend(model)
+    b.prefill(toks[:n // 2], 0)              # two calls, the second at pos > 0
+    b.prefill(toks[n // 2:n], n // 2)
+    after = b.forward(toks[n], n, 0).copy()  # one decode step on top of the batched prompt
+    b2 = HipBackend(model)
+    lp = b2.prefill_logprobs(toks[:n + 1], 0)
+    np.savez(os.environ["CALM_OUT"], after=after, lp=lp)
+    sys.stdout.write(json.dumps({"stages": b.stages}) + "\\n")
+    b.close()
+    b2.close()
+    """
+)
+
+
+@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "dbrx_like_fp8"])
+def test_prompt_ingestion_on_a_sharded_model(hiplib, tmp_path, case):
+    """prefill_hip / prefill_logprobs_hip on CALM_HIP_DEVICES=2: a chunk runs stage after stage, the residual rows crossing like
+    one token's x does; the logits of the next decode step and every scored log-probability equal the unsharded backend's bit
+    for bit (sink_fp16: the prompt runs past seq_len, the tail goes through the sharded decode path inside the call)"""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    n = len(toks) - 1
+    if model.config.n_layers < 2:
+        pytest.skip("fewer layers than stages")
+    out = str(tmp_path / f"pf_{case}.npz")
+    env = dict(os.environ, CALM_ROOT=ROOT, CALM_MODEL=os.path.join(GOLDEN, case + ".calm"), CALM_TOKENS=json.dumps(toks), CALM_OUT=out, CALM_NPROMPT=str(n),
+               CALM_HIP_DEVICES="2")
+    r = subprocess.run([sys.executable, "-c", PREFILL_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["stages"] == 2
+    got = np.load(out)
+    b = HipBackend(model)
+    b2 = HipBackend(model)
+    try:
+        b.prefill(toks[: n // 2], 0)
+        b.prefill(toks[n // 2 : n], n // 2)
+        assert np.array_equal(got["after"], b.forward(toks[n], n, 0))
+        assert np.array_equal(got["lp"], b2.prefill_logprobs(toks[: n + 1], 0))
+    finally:
+        b.close()
+        b2.close()
 
 
 @pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip (reference CLI linked to libcalm_hip.so) not built")
