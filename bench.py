@@ -162,7 +162,6 @@ def main():
     if args.pipeline > 1:
         # a model split over stages is driven through forward_hip only: no per-stage timing; the roofline below is then the
         # whole step's algorithmic bytes over its time (every stage idles while the others work: one token in flight)
-        args.no_device_greedy = True
         dom = {"GBps": round(achieved, 1), "bytes": int(step_bytes), "us": round(elapsed / args.steps * 1e6, 2)}
     else:
         for i, name in enumerate(STAGES):
@@ -201,7 +200,7 @@ def main():
 
     # device-side greedy decode of the same K tokens (no host round trip per token): extra, not `value`
     device_greedy = None
-    if not args.no_device_greedy:
+    if not args.no_device_greedy and args.pipeline <= 1:  # (decode_greedy_hip is a single-device entry point)
         be.decode_greedy(first_token, 0, min(args.steps, 8))  # captures its graphs
         t0 = time.perf_counter()
         dev_toks, _ = be.decode_greedy(first_token, 0, args.steps)
@@ -212,7 +211,7 @@ def main():
     # MFMA-bound on the f16 matrix cores: every weight x activation product is two v_mfma_f32_32x32x16_f16 products (the fp32
     # activation as hi + lo binary16), so the peak in algorithmic FLOPs is half the 2.5 PF dense f16 peak (MI355X_MICROARCH.md)
     prefill = None
-    if not args.no_device_greedy and args.pipeline <= 1:
+    if not args.no_device_greedy:
         n_pf = min(2048, model.config.seq_len - 1)
         prompt = [int(t) for t in np.random.default_rng(args.seed).integers(0, spec.vocab_size, size=n_pf)]
         be.prefill(prompt[:64], 0)
