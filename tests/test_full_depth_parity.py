@@ -73,7 +73,19 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
                 margin = float(top2[1] - top2[0])
                 diverged.append((pos, h, ref_tokens[pos], margin, float(np.abs(lr).max())))
             tok = ref_tokens[pos]
-        return {"worst": worst, "diverged": diverged, "ref_tokens": ref_tokens, "hip_tokens": hip_tokens}
+        # the same stream as a PROMPT: prefill_hip over positions 0 .. m - 1 (f16 matrix cores, hi + lo activations, every layer),
+        # then the decode step at position m against the reference's logits there; and the scored log-probabilities of the stream
+        m = n_tokens - 1
+        prompt = [first_token] + ref_tokens[: m - 1]
+        hip.prefill(prompt, 0)
+        pf_err = rel_err(hip.forward(ref_tokens[m - 1], m, 0), ref_logits[m])
+        lp = hip.prefill_logprobs(prompt + [ref_tokens[m - 1]], 0)
+        want = []
+        for pos in range(m):
+            lr = ref_logits[pos].astype(np.float64)
+            want.append((lr[ref_tokens[pos]] - lr.max()) - np.log(np.exp(lr - lr.max()).sum()))
+        lp_err = float(np.abs(lp[:m] - np.array(want)).max())
+        return {"worst": worst, "diverged": diverged, "ref_tokens": ref_tokens, "hip_tokens": hip_tokens, "prefill": pf_err, "logprob": lp_err}
     finally:
         hip.close()
         ref.close()
@@ -82,7 +94,10 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
 @pytest.mark.parametrize("name,dtype,n_tokens", [("mistral-7b", "fp8", 256), ("llama-3-8b", "gf4", 64), ("tinyllama-1.1b", "fp16", 64)])
 def test_full_depth_logits_and_greedy_stream_match_the_reference(hiplib, name, dtype, n_tokens):
     r = full_depth_check(name, dtype, n_tokens)
-    print(f"{name} {dtype} full depth, {n_tokens} positions: worst max|d|/max|logit| = {r['worst']:.3e}; argmax differences: {r['diverged']}")
+    print(f"{name} {dtype} full depth, {n_tokens} positions: worst max|d|/max|logit| = {r['worst']:.3e}; argmax differences: {r['diverged']}; "
+          f"after prefill_hip of the stream {r['prefill']:.3e}; scored log-probabilities off by at most {r['logprob']:.3e}")
+    assert r["prefill"] <= TOL, r["prefill"]
+    assert r["logprob"] <= 5e-3, r["logprob"]  # log-probabilities of greedy picks: |d logit| <= 1e-3 max|logit| ~ a few 1e-3
     for pos, h, t, margin, lmax in r["diverged"]:
         # a different pick is only acceptable at a near-tie of the REFERENCE's own logits
         assert margin < 4 * TOL * lmax, f"{name} {dtype}: greedy streams part at position {pos} (hip {h}, reference {t}) with a reference top-2 margin of {margin:.3e}"
