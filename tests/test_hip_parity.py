@@ -446,8 +446,8 @@ def test_prefill_in_two_calls_and_odd_chunks(hiplib):
 @pytest.mark.parametrize("head_dim,n_heads,n_kv_heads", [(64, 4, 4), (64, 4, 2), (64, 8, 2), (64, 12, 2), (64, 16, 2), (128, 4, 1), (128, 6, 2), (128, 2, 2)])
 def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_heads, kvbits):
     """k_pf_attn_mfma (head sizes 64 / 128): every grouping of query heads per kv head it is compiled for -- 1, 2, 4 heads per
-    round, one or several rounds, several token tiles per workgroup -- with both cache formats: a 333-token prompt in two
-    calls (the second starts at position 201: partial tiles on both sides), then one decode step against the oracle;
+    round, one or several rounds, several token tiles per workgroup -- with both cache formats: a 333-token prompt in four
+    calls (201, 1, 33 and 98 tokens: partial tiles on both sides, a single query), then one decode step against the oracle;
     and the same prompt through the lane-arithmetic kernel (calm_hip_configure("pf_attn_mfma", 0)): cache rows equal"""
     dim = 256
     spec = cf.tiny_spec("pfa", max_seq_len=400, dim=dim, hidden_dim=512, n_heads=n_heads, n_kv_heads=n_kv_heads, head_dim=head_dim, vocab_size=300, n_layers=2)
@@ -464,7 +464,9 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
         lo = o.forward(toks[-1], 333, 0).copy()
         assert hiplib.calm_hip_configure(b"pf_attn_mfma", -1) == 1
         b.prefill(toks[:201], 0)
-        b.prefill(toks[201:333], 201)
+        b.prefill(toks[201:202], 201)  # a chunk of one token ...
+        b.prefill(toks[202:235], 202)  # ... of one tile and one token ...
+        b.prefill(toks[235:333], 235)
         lb = b.forward(toks[-1], 333, 0).copy()
         assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
         hiplib.calm_hip_configure(b"pf_attn_mfma", 0)
