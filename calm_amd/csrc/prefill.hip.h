@@ -859,29 +859,35 @@ __device__ __forceinline__ void pf_epilogue(const PfGemmArgs& a, const f32x16 (&
 	}
 }
 
-// The same for the wide form's 2 x 2 tiles (64 units x 64 tokens per wave), through a wave-private LDS image [32 tokens][64
-// units (+ 4)]: a store instruction then covers four tokens x 64 consecutive units -- eight cache lines instead of sixty-four
-// (the token-per-lane stores were 8-20 % of a GEMM, profiles/r02_prefill_gemm.txt).  `img`: 32 x 68 floats of LDS nobody else uses.
-template <int KVB, int EPI>
-__device__ __forceinline__ void pf_epilogue_rows(const PfGemmArgs& a, const f32x16 (&acc)[2][2], const int unit0, const int tok0, float* img) {
+// The same through a wave-private LDS image [32 tokens][32 NA units (+ 4)]: a store instruction then covers whole runs of
+// consecutive units of a few tokens -- eight cache lines instead of sixty-four (the token-per-lane stores were 8-20 % of a GEMM,
+// profiles/r02_prefill_gemm.txt); the RoPE table reads and the KV-cache stores of the QKV epilogue coalesce the same way.
+// `img`: 32 x (32 NA + 4) floats of LDS nobody else uses.  Not for the FFN-up (its fragment-major stores are contiguous as they are).
+template <int KVB, int EPI, int NA>
+__device__ __forceinline__ void pf_epilogue_rows(const PfGemmArgs& a, const f32x16 (&acc)[NA][2], const int unit0, const int tok0, float* img) {
+	constexpr int RS = 32 * NA + 4;     // row stride of the image (floats)
+	constexpr int CH = 8 * NA;          // float4 chunks per token row
+	constexpr int RPI = 64 / CH;        // token rows per pass of the wave (NA = 3: two rows, 48 lanes)
 	const int lane = lane_id(), j = lane & 31, kk = lane >> 5;
 #pragma unroll
 	for (int c = 0; c < 2; ++c) {
 #pragma unroll
-		for (int n = 0; n < 2; ++n) {
+		for (int n = 0; n < NA; ++n) {
 #pragma unroll
 			for (int g = 0; g < 4; ++g) {
-				*(float4*)(img + j * 68 + 32 * n + 8 * g + 4 * kk) = make_float4(acc[n][c][4 * g], acc[n][c][4 * g + 1], acc[n][c][4 * g + 2], acc[n][c][4 * g + 3]);
+				*(float4*)(img + j * RS + 32 * n + 8 * g + 4 * kk) = make_float4(acc[n][c][4 * g], acc[n][c][4 * g + 1], acc[n][c][4 * g + 2], acc[n][c][4 * g + 3]);
 			}
 		}
-		const int ub = unit0 + 4 * (lane & 15);
+		const int ub = unit0 + 4 * (lane % CH);
 #pragma unroll
-		for (int it = 0; it < 8; ++it) {
-			const int row = 4 * it + (lane >> 4), token = tok0 + 32 * c + row;
-			const float4 t = *(const float4*)(img + row * 68 + 4 * (lane & 15));
-			if (token < a.nb && ub < a.M) {
-				const float v[4] = {t.x, t.y, t.z, t.w};
-				pf_epi4<KVB, EPI>(a, token, ub, v);
+		for (int it = 0; it < 32 / RPI; ++it) {
+			const int row = RPI * it + lane / CH, token = tok0 + 32 * c + row;
+			if (lane < RPI * CH) {
+				const float4 t = *(const float4*)(img + row * RS + 4 * (lane % CH));
+				if (token < a.nb && ub < a.M) {
+					const float v[4] = {t.x, t.y, t.z, t.w};
+					pf_epi4<KVB, EPI>(a, token, ub, v);
+				}
 			}
 		}
 	}
@@ -1075,7 +1081,15 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 	}
 	add(0);
 
-	pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+	if constexpr (EPI == PF_EPI_FFN_UP) {
+		pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+	} else {
+		if (a.M & 3) { // a vocabulary that is not a multiple of 4: rows are not 16-byte aligned
+			pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+		} else { // part[1] is free: its last reader was wave 1, two barriers ago
+			pf_epilogue_rows<KVB, EPI, NA>(a, acc, unit0, tok0, &part[1][0][0]);
+		}
+	}
 }
 
 // ---- the wide form ------------------------------------------------------------------------------------------------------
@@ -1356,7 +1370,7 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 		if (a.M & 3) { // a vocabulary that is not a multiple of 4: rows are not 16-byte aligned
 			pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
 		} else { // the B ring is free: every wave has passed the loop's last barrier
-			pf_epilogue_rows<KVB, EPI>(a, acc, unit0, tok0, (float*)pfw_lds + wave * (32 * 68));
+			pf_epilogue_rows<KVB, EPI, NA>(a, acc, unit0, tok0, (float*)pfw_lds + wave * (32 * 68));
 		}
 	}
 }
