@@ -808,22 +808,22 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	                   embed ? w->token_embedding_table : nullptr, c->dim, c->rope_freq, c->pf_rope, half_hd);
 	const dim3 block(256);
 	const int cols = (nb + 63) / 64;
-	// Two forms of the GEMM (prefill.hip.h).  Enough tiles to fill the chip without splitting K (256 units x 64 tokens per
-	// workgroup: from ~3/4 of the CUs busy the wide form wins, profiles/r02_prefill_gemm.txt): k_pf_gemm_wide.  Otherwise the
-	// K-split form with S unit strips per wave (operands reused S times): the S whose grid costs the fewest workgroup rounds
-	// (one workgroup per CU at a time, a round takes S units of time); ties go to the larger S.
+	// Two forms of the GEMM (prefill.hip.h): k_pf_gemm_wide (256 units x 64 tokens per workgroup, no K split inside the workgroup)
+	// where its tiles cover enough of the chip, else the K-split form with S unit strips per wave (operands reused S times): the
+	// S whose grid costs the fewest workgroup rounds (a round takes S units of time); ties go to the larger S.
 	auto gemm = [&](PfGemmArgs a, auto EPI, int ncols) {
 		constexpr int epi = decltype(EPI)::value;
 		constexpr int kvb = epi == PF_EPI_QKV ? KVB : 16; // only the QKV epilogue touches the cache
 		const int nx = (a.M + PfWide<epi>::UNITS - 1) / PfWide<epi>::UNITS;
 		const int tiles = 8 * ((nx + 7) / 8) * ncols, nsteps = pf_steps(a.K);
-		// too few tiles: the wide form with K cut into ranges (one workgroup each, the last to arrive folds the partial tiles)
-		// pays for long rows (the FFN-down: 85 against 119 us at 256 tokens, 50 against 114 at 64) and for the FFN-up of very
-		// short prompts; at K = 4096 it ties with the K-split form (profiles/r02_prefill_gemm.txt)
+		// Which form (profiles/r02_prefill_gemm.txt: Mistral-7B and TinyLlama shapes at 64-1024 tokens): the wide form from 5/8 of
+		// the CUs busy; below that, the wide form with K cut into ranges (one workgroup each, the last to arrive folds the partial
+		// tiles) where rows are long (the FFN-down: 85 against 119 us at 256 tokens), for the FFN-up, and x 2 from half the CUs;
+		// otherwise the K-split form.
 		int ks = 1; // 0: the K-split form
-		if ((long)nx * ncols * 4 < (long)g_ncu * 3) {
+		if ((long)nx * ncols * 8 < (long)g_ncu * 5) {
 			ks = 0;
-			if (nsteps >= 128 || epi == PF_EPI_FFN_UP) {
+			if (nsteps >= 80 || epi == PF_EPI_FFN_UP || nx * ncols * 2 >= g_ncu) {
 				int k = g_ncu / (nx * ncols);
 				k = k > 8 ? 8 : k;
 				k = k > nsteps / 16 ? nsteps / 16 : k;
@@ -845,9 +845,9 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		} else {
 			int best = 1;
 			long best_cost = 0;
-			for (int S = 1; S <= 3; ++S) {
+			for (int S = 1; S <= 3; ++S) { // (three strips leave one workgroup per CU and nothing to hide its stalls behind: x 1.3)
 				long wgs = (long)((a.M + 32 * S - 1) / (32 * S)) * ncols;
-				long cost = (wgs + g_ncu - 1) / g_ncu * S;
+				long cost = (wgs + g_ncu - 1) / g_ncu * S * (S == 3 ? 13 : 10);
 				if (S == 1 || cost <= best_cost) {
 					best = S, best_cost = cost;
 				}

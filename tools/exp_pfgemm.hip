@@ -154,6 +154,22 @@ static void run(const char* name, int M, int K, int nb, int iters) {
 int main(int argc, char** argv) {
 	const int nb = argc > 1 ? atoi(argv[1]) : 256;
 	const int iters = argc > 2 ? atoi(argv[2]) : 20;
+	if (argc > 3) { // TinyLlama-1.1B's shapes (dim 2048, hidden 5632)
+		run<PF_EPI_STORE, 2>("t-qkv", 2560, 2048, nb, iters);
+		run<PF_EPI_STORE, 3>("t-qkv", 2560, 2048, nb, iters);
+		run<PF_EPI_STORE, -1>("t-qkv", 2560, 2048, nb, iters);
+		run<PF_EPI_STORE, -21>("t-qkv", 2560, 2048, nb, iters);
+		run<PF_EPI_STORE, 2>("t-wo", 2048, 2048, nb, iters);
+		run<PF_EPI_STORE, -1>("t-wo", 2048, 2048, nb, iters);
+		run<PF_EPI_STORE, -21>("t-wo", 2048, 2048, nb, iters);
+		run<PF_EPI_FFN_UP, 1>("t-ffn-up", 5632, 2048, nb, iters);
+		run<PF_EPI_FFN_UP, -1>("t-ffn-up", 5632, 2048, nb, iters);
+		run<PF_EPI_STORE, 2>("t-ffn-down", 2048, 5632, nb, iters);
+		run<PF_EPI_STORE, -1>("t-ffn-down", 2048, 5632, nb, iters);
+		run<PF_EPI_STORE, -21>("t-ffn-down", 2048, 5632, nb, iters);
+		run<PF_EPI_STORE, -41>("t-ffn-down", 2048, 5632, nb, iters);
+		return 0;
+	}
 	run<PF_EPI_STORE, 3>("qkv-like", 6144, 4096, nb, iters);
 	run<PF_EPI_STORE, -1>("qkv-like", 6144, 4096, nb, iters);
 	run<PF_EPI_STORE, -21>("qkv-like", 6144, 4096, nb, iters);
