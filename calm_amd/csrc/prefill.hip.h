@@ -916,7 +916,6 @@ __global__ __launch_bounds__(256, S < 3 ? 2 : 1) void k_pf_gemm(PfGemmArgs a) {
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
 	const int unit0 = blockIdx.x * PfTile<EPI, S>::UNITS, tok0 = blockIdx.y * 64;
-	const int nb = a.nb;
 	size_t expert_off = 0;
 	if (a.col_expert) {
 		const int e = a.col_expert[blockIdx.y];

@@ -105,7 +105,8 @@ float* decode_sample_hip(struct Transformer* transformer, int token, int pos, in
  * Returns after the work is complete (`tokens` is host memory and may be reused).
  * Mixture-of-experts models are routed per token on the device and each expert runs one GEMM over the rows
  * routed to it.  Positions at or beyond seq_len (rolling buffer, sink rotation between tokens) are processed
- * through the decode path one token at a time inside the call -- same result, no speed-up. */
+ * through the decode path one token at a time inside the call -- same result, no speed-up.  On a model sharded inside the
+ * library (CALM_HIP_DEVICES) a chunk runs stage after stage, its residual rows crossing as one token's x does. */
 void prefill_hip(struct Transformer* transformer, const int* tokens, int n, int pos);
 
 /* The same, plus the model's verdict on the text: logprob[i] = log softmax(logits after tokens[i])[tokens[i + 1]]
