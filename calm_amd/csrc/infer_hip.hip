@@ -1550,6 +1550,9 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 			if (pos + done + nb > first->seq_len) {
 				nb = first->seq_len - (pos + done);
 			}
+			if (nb <= 2) {
+				break; // a chunk costs about three decode steps whatever its size (it streams every weight once, less efficiently)
+			}
 			int target[PF_NT];
 			for (int s = 0; s < P; ++s) {
 				on_stage(s);

@@ -447,7 +447,7 @@ def test_prefill_in_two_calls_and_odd_chunks(hiplib):
 def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_heads, kvbits):
     """k_pf_attn_mfma (head sizes 64 / 128): every grouping of query heads per kv head it is compiled for -- 1, 2, 4 heads per
     round, one or several rounds, several token tiles per workgroup -- with both cache formats: a 333-token prompt in four
-    calls (201, 1, 33 and 98 tokens: partial tiles on both sides, a single query), then one decode step against the oracle;
+    calls (201, 3, 33 and 96 tokens: partial tiles on both sides, a nearly empty query tile), then one decode step against the oracle;
     and the same prompt through the lane-arithmetic kernel (calm_hip_configure("pf_attn_mfma", 0)): cache rows equal"""
     dim = 256
     spec = cf.tiny_spec("pfa", max_seq_len=400, dim=dim, hidden_dim=512, n_heads=n_heads, n_kv_heads=n_kv_heads, head_dim=head_dim, vocab_size=300, n_layers=2)
@@ -464,9 +464,9 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
         lo = o.forward(toks[-1], 333, 0).copy()
         assert hiplib.calm_hip_configure(b"pf_attn_mfma", -1) == 1
         b.prefill(toks[:201], 0)
-        b.prefill(toks[201:202], 201)  # a chunk of one token ...
-        b.prefill(toks[202:235], 202)  # ... of one tile and one token ...
-        b.prefill(toks[235:333], 235)
+        b.prefill(toks[201:204], 201)  # a chunk of three tokens (the smallest that is batched: one or two go through the decode path) ...
+        b.prefill(toks[204:237], 204)  # ... of one tile and one token ...
+        b.prefill(toks[237:333], 237)
         lb = b.forward(toks[-1], 333, 0).copy()
         assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
         hiplib.calm_hip_configure(b"pf_attn_mfma", 0)
@@ -576,9 +576,10 @@ def test_generate_with_a_batched_prompt_continues_the_reference_stream(hiplib, c
         b.close()
 
 
-@pytest.mark.parametrize("n", [1, 2, 5, 33])
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 33])
 def test_prefill_of_very_short_and_odd_prompts(hiplib, n):
-    """1, 2, 5 tokens (partial query groups of the attention kernel) and 33 (one token past an MFMA column tile),
+    """1, 2 tokens (taken through the decode path: a batched chunk costs about three decode steps), 3, 5 (partial query groups
+    of the attention kernel) and 33 (one token past an MFMA column tile),
     each followed by one decode step checked against the reference's logits; the 33-token case wraps the
     16-slot rolling buffer of sink_fp16 inside the call"""
     case = "sink_fp16" if n == 33 else "ragged_fp8"
