@@ -810,7 +810,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	const int cols = (nb + 63) / 64;
 	// Two forms of the GEMM (prefill.hip.h): k_pf_gemm_wide (256 units x 64 tokens per workgroup, no K split inside the workgroup)
 	// where its tiles cover enough of the chip, else the K-split form with S unit strips per wave (operands reused S times): the
-	// S whose grid costs the fewest workgroup rounds (a round takes S units of time); ties go to the larger S.
+	// S whose grid costs the least (rounds of workgroups over the CUs x a workgroup's time); ties go to the larger S.
 	auto gemm = [&](PfGemmArgs a, auto EPI, int ncols) {
 		constexpr int epi = decltype(EPI)::value;
 		constexpr int kvb = epi == PF_EPI_QKV ? KVB : 16; // only the QKV epilogue touches the cache
@@ -845,9 +845,9 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		} else {
 			int best = 1;
 			long best_cost = 0;
-			for (int S = 1; S <= 3; ++S) { // (three strips leave one workgroup per CU and nothing to hide its stalls behind: x 1.3)
+			for (int S = 1; S <= 3; ++S) { // a workgroup's time grows like 2 + S: the B operand is fetched whatever S is (measured 27 : 40 : 46)
 				long wgs = (long)((a.M + 32 * S - 1) / (32 * S)) * ncols;
-				long cost = (wgs + g_ncu - 1) / g_ncu * S * (S == 3 ? 13 : 10);
+				long cost = (wgs + g_ncu - 1) / g_ncu * (2 + S);
 				if (S == 1 || cost <= best_cost) {
 					best = S, best_cost = cost;
 				}
