@@ -4,12 +4,17 @@ model on MI355X through the drop-in C ABI (forward_hip per token + host argmax, 
 reference src/run.c:167-256), with the roofline fraction of the dominant kernel and the reference CPU
 path timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--model mistral-7b] [--dtype fp8]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model mistral-7b] [--dtype fp8] [--pipeline [P]]
 
 A "step" is one decode step (one token through every layer + classifier + sampling).  Data are
 synthetic (seeded random weights of the real shapes; no checkpoints or network on the box).
 N > 1: the path has one token in flight and does not shard for a model that fits one GPU, so ranks run
 independent replicas (DESIGN.md section "multi-GPU"); value = tokens of all ranks / max-over-ranks time.
+Started without a launcher (`python bench.py --gpus N`, no WORLD_SIZE in the environment) it launches itself under
+torch.distributed.run, one rank per GPU, so the printed n_gpus is N either way.
+--gpus N --pipeline: BASELINE config 5 instead -- ONE process, the layers of DBRX-132B fp8 (or --model) split over P = N pipeline
+stages inside the library (CALM_HIP_DEVICES), stage s on GPU s, one token in flight ("scaling": "capacity": the GPUs add
+memory, not throughput).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -71,20 +76,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
-    ap.add_argument("--model", default="mistral-7b")
+    ap.add_argument("--model", default=None, help="a BASELINE shape (default mistral-7b; dbrx-132b with --pipeline)")
     ap.add_argument("--dtype", default="fp8")
     ap.add_argument("--layers", type=int, default=0, help="override depth (debug only; invalidates the metric)")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="cap on the CPU baseline's timed region")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-device-greedy", action="store_true", help="skip the extra device-side greedy decode leg (rocprofv3 7.2 crashes in it)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--pipeline", type=int, default=0, help="split the layers over P pipeline stages inside this one process (CALM_HIP_DEVICES=P: stage s on GPU s %% visible GPUs; "
-                    "BASELINE config 5's partitioning) instead of running on one GPU")
+    ap.add_argument("--pipeline", type=int, nargs="?", const=-1, default=0,
+                    help="split the layers over P pipeline stages inside this one process (CALM_HIP_DEVICES=P: stage s on GPU s %% visible GPUs; "
+                    "BASELINE config 5's partitioning) instead of running on one GPU; without a value P = --gpus")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU work: the launch / rendezvous / timing protocol only (gloo), for the CPU tests")
     ap.add_argument("--host-synth", action="store_true", help="without a CPU leg: synthesise the weights on the host and upload them (default: on the device)")
     args = ap.parse_args()
+    if args.pipeline == -1:
+        args.pipeline = args.gpus
+    if args.model is None:
+        args.model = "dbrx-132b" if args.pipeline > 1 else "mistral-7b"
+
+    if args.gpus > 1 and args.pipeline <= 1 and "WORLD_SIZE" not in os.environ:
+        # started bare: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU), so that a
+        # plain `python bench.py --gpus 8` measures 8 GPUs and says so
+        import socket
+
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+        sock.close()
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+                                  "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]])
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and args.pipeline <= 1 and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
     if args.pipeline > 1:
         assert world == 1, "--pipeline is a single-process mode: launch without torchrun"
         os.environ["CALM_HIP_DEVICES"] = str(args.pipeline)  # read by init_hip
@@ -99,9 +124,33 @@ def main():
         import torch
         import torch.distributed as dist_
 
-        torch.cuda.set_device(local_rank)
-        dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dry_run:
+            dist_.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_
+
+    if args.dry_run:
+        # the protocol without the device: barrier, a stand-in for the timed region, max-over-ranks, one JSON line on rank 0
+        from calm_amd.replicas import aggregate_throughput
+
+        if dist is not None:
+            dist.barrier()
+        elapsed = 1e-3 * args.steps * (1 + 0.1 * rank)
+        if dist is not None:
+            dist.barrier()
+        agg = aggregate_throughput(dist, args.steps, elapsed, device="cpu")
+        if rank == 0:
+            n_gpus = args.pipeline if args.pipeline > 1 else world
+            print(json.dumps({"metric": f"decode tok/s (batch=1, {args.steps} tok)", "value": round(agg["value"], 2), "unit": "tok/s", "n_gpus": n_gpus,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(agg["elapsed"] / args.steps * 1e3, 4),
+                              "higher_is_better": True, "scaling": "capacity" if args.pipeline > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": "none (dry run: no device work)", "dry_run": True,
+                              "config": {"workload": f"{args.model} {args.dtype}", "parallelism": f"{args.pipeline}-stage layer pipeline" if args.pipeline > 1 else f"{world} replica(s)"}}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     from calm_amd import calmfile as cf
     from calm_amd.host import STAGES, HipBackend, HostModel, generate
@@ -109,6 +158,17 @@ def main():
     spec = cf.SPECS[args.model]
     n_layers = args.layers or spec.n_layers
     want_cpu = not args.no_cpu and world == 1  # the CPU baseline is an N = 1 measurement (rank 0 would otherwise hold the others up)
+    cpu_skipped = None
+    if want_cpu:
+        # the CPU leg needs the whole model in host RAM (46.7 GB for Mixtral-8x7B fp8, 131.6 GB for DBRX-132B fp8)
+        import psutil
+
+        need = sum(a.nbytes for a in cf.stub_tensors(spec, args.dtype, n_layers).values()) + (6 << 30)
+        have = int(psutil.virtual_memory().available)
+        if have < need:
+            cpu_skipped = f"host RAM: the CPU reference needs {need / 2**30:.0f} GiB for this model, {have / 2**30:.0f} GiB available"
+            print(f"bench.py: no CPU leg ({cpu_skipped})", file=sys.stderr)
+            want_cpu = False
     t0 = time.perf_counter()
     if want_cpu:
         # the CPU leg reads the same weights: hold the model on the host (every tensor its own array) and upload from there
@@ -184,6 +244,19 @@ def main():
                 traffic = int(v["hbm_read_bytes_per_launch_corrected"])
                 traffic_source = f"profiles/{os.path.basename(pmc_file)} (separate rocprofv3 --pmc FETCH_SIZE pass over the same kernel sources, x1024 x2)"
         break
+    # the same kernel's average duration in the committed rocprofv3 --kernel-trace summary of this very source tree and shape
+    # (profiles/r*_kernel_stats.json, tools/prof_summary.py), beside the live event-timed figure: the two must agree
+    rocprof = None
+    for ks_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernel_stats.json")), reverse=True):
+        ks = json.load(open(ks_file))
+        if ks.get("_csrc_sha") != csrc_sha() or ks.get("_workload") != f"{args.model} {args.dtype}":
+            continue
+        for k, v in ks.items():
+            if k.startswith("k_ffn_up<") and args.pipeline <= 1:
+                gbps = dom["bytes"] / v["avg_us"] / 1e3
+                rocprof = {"us_per_launch": round(v["avg_us"], 2), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "calls": v["calls"],
+                           "source": f"profiles/{os.path.basename(ks_file)} (rocprofv3 --kernel-trace of the bench command, same kernel sources)"}
+        break
     roofline = {
         "bound": "hbm",
         "kernel": "k_ffn_up" if args.pipeline <= 1 else "whole decode step (all stages)",
@@ -196,6 +269,7 @@ def main():
         "frac_of_measured_ceiling": round(dom["GBps"] / HBM_NT_CEILING_GBPS, 4),
         "bytes_per_launch": dom["bytes"],
         "us_per_launch": dom["us"],
+        "rocprof": rocprof,
     }
 
     # device-side greedy decode of the same K tokens (no host round trip per token): extra, not `value`
@@ -248,12 +322,13 @@ def main():
         "metric": f"decode tok/s (batch=1, {args.steps} tok)",
         "value": round(tok_s, 2),
         "unit": "tok/s",
-        "n_gpus": world,
+        "n_gpus": min(args.pipeline, be.lib.calm_hip_device_count()) if args.pipeline > 1 else world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 4),
         "higher_is_better": True,
-        "scaling": "weak",
+        # replicas: per-GPU work fixed as N grows; the layer pipeline: one model split over the GPUs -- they add capacity, not rate
+        "scaling": "capacity" if args.pipeline > 1 else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
@@ -274,6 +349,7 @@ def main():
         "device_greedy": device_greedy,
         "prefill": prefill,
         "cpu_baseline": cpu,
+        "cpu_baseline_skipped": cpu_skipped,
         "parity": parity,
         "load_seconds": round(load_s, 1),
     }

@@ -54,10 +54,19 @@ def csrc_sha() -> str:
 def build_hip(force: bool = False) -> str:
     """compile every HIP translation unit for gfx950 into libcalm_hip.so"""
     srcs = hip_sources()
+    jobs = []
     if force or not _newer(LIB_HIP, srcs):
-        _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP, os.path.join(CSRC, "infer_hip.hip")])
+        jobs.append([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP, os.path.join(CSRC, "infer_hip.hip")])
     if force or not _newer(LIB_HIP_TEST, srcs):
-        _run([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP_TEST, os.path.join(CSRC, "test_hooks.hip")])
+        jobs.append([HIPCC, *HIP_FLAGS, "-shared", "-o", LIB_HIP_TEST, os.path.join(CSRC, "test_hooks.hip")])
+    # the two libraries are independent translation units (the second includes the first's source): compile side by side
+    procs = []
+    for cmd in jobs:
+        print("+", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
     return LIB_HIP
 
 

@@ -489,6 +489,25 @@ def _synth_lib():
     return _SYNTH_LIB or None
 
 
+def big_zeros(shape, dtype) -> np.ndarray:
+    """np.zeros for the multi-GB host copies of synthetic models: anonymous memory with MADV_HUGEPAGE.  First touch of fresh guest
+    memory runs at ~0.2 GB/s with 4 KiB pages inside these VMs and at ~9 GB/s with transparent huge pages (measured), which is
+    what makes a 46.7 GB (Mixtral-8x7B) or 131.6 GB (DBRX-132B) model on the host a matter of seconds.  Small arrays and platforms
+    without mmap.madvise take the plain path."""
+    import mmap
+
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes < (8 << 20) or not hasattr(mmap, "MADV_HUGEPAGE"):
+        return np.zeros(shape, dtype=dtype)
+    size = (nbytes + (2 << 20) - 1) & ~((2 << 20) - 1)
+    m = mmap.mmap(-1, size, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
+    try:
+        m.madvise(mmap.MADV_HUGEPAGE)
+    except OSError:
+        pass
+    return np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)  # (the array keeps the mapping alive)
+
+
 def _fill_codes(out: np.ndarray, dtype: str, sigma: float, seed: int) -> None:
     """fill the storage array `out` (uint16 / uint8 / uint32) with random weight codes"""
     flat = out.reshape(-1)
@@ -574,7 +593,7 @@ def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optio
         key = (sshape, store)
         a = pool.get(key) if reuse else None
         if a is None:
-            a = np.zeros(sshape, dtype=store)
+            a = big_zeros(sshape, store)
             pool[key] = a
         _fill_codes(a, dtype, sigma, fill_seed)
         return a.view(np.float16) if dtype == "fp16" else (as_fp8(a) if dtype == "fp8" else a.view(np.int32))

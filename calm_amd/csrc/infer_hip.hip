@@ -80,6 +80,7 @@ int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
+long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
 char g_devname[256] = "none";
 
@@ -100,6 +101,45 @@ int env_int(const char* name, int dflt) {
 // Kernels issue unconditional, unclamped 16-byte loads that may run past the end of a row / vector
 // (kernels.hip.h: stage_load, tile_load); every device buffer carries this much slack behind it.
 constexpr size_t DEV_PAD = 64 * 1024;
+
+// Host -> device through two pinned staging buffers: the host's copy into one overlaps the DMA out of the other, on the decode
+// stream.  (A pageable hipMemcpy per tensor -- what upload_cuda does, src/infer.cu:69-71 -- moved a 7 GB model in ~25 s here.)
+// Small tensors take the plain synchronous copy.  Ordered on g_stream; prepare_hip drains it before the host may unmap.
+struct Stager {
+	void* pin[2] = {nullptr, nullptr};
+	hipEvent_t done[2];
+	bool busy[2] = {false, false};
+};
+constexpr size_t STAGE_CHUNK = 32u << 20;
+std::map<int, Stager> g_stagers; // per device
+
+void staged_upload(void* dst, const void* src, size_t size) {
+	if (size < (1u << 20)) {
+		HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyHostToDevice));
+		return;
+	}
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	Stager& st = g_stagers[dev];
+	if (!st.pin[0]) {
+		for (int b = 0; b < 2; ++b) {
+			HIP_CHECK(hipHostMalloc(&st.pin[b], STAGE_CHUNK, hipHostMallocDefault));
+			HIP_CHECK(hipEventCreateWithFlags(&st.done[b], hipEventDisableTiming));
+		}
+	}
+	int b = 0;
+	for (size_t off = 0; off < size; off += STAGE_CHUNK, b ^= 1) {
+		const size_t n = size - off < STAGE_CHUNK ? size - off : STAGE_CHUNK;
+		if (st.busy[b]) {
+			HIP_CHECK(hipEventSynchronize(st.done[b]));
+		}
+		memcpy(st.pin[b], (const char*)src + off, n);
+		HIP_CHECK(hipMemcpyAsync((char*)dst + off, st.pin[b], n, hipMemcpyHostToDevice, g_stream));
+		HIP_CHECK(hipEventRecord(st.done[b], g_stream));
+		st.busy[b] = true;
+	}
+	// the caller may reuse `src` at once (tests stream tensors through one host buffer): everything has left it already
+}
 
 void* dev_alloc(size_t size) {
 	void* p = nullptr;
@@ -187,6 +227,7 @@ struct Ctx {
 	// profiling
 	StageProf prof[CALM_STAGE_COUNT];
 	std::vector<hipEvent_t> events;
+	double marker_us = 0; // what an event between two kernels costs the queue, from the last calibrated profiling step
 };
 
 std::map<struct Transformer*, Ctx*> g_ctx;
@@ -346,7 +387,9 @@ void launch_ffn_up(Ctx* c, int l) {
 	a.x = p->norm_par ? c->xb : c->x;
 	a.norm_w = p->norm_par ? nullptr : w->rms_ffn_weight[l];
 	a.w1 = w->w1[l], a.w3 = w->w3[l], a.moegate = w->moegate[l];
-	a.he = c->he, a.moe_w = c->moe_w, a.moe_e = c->moe_e;
+	// routing weights / expert ids of THIS layer: one slice per layer, so the routing of the last step stays inspectable
+	// (calm_hip_read_moe in the test library; the reference keeps only the last layer's in state.exp, src/infer.c:423-424)
+	a.he = c->he, a.moe_w = c->moe_w + (size_t)l * CALM_MAX_EXPERTS, a.moe_e = c->moe_e + (size_t)l * CALM_MAX_EXPERTS;
 	a.dim = c->dim, a.hidden = c->hidden, a.n_experts = c->n_experts, a.n_active = c->n_active;
 	a.eps = p->norm_eps, a.ln = p->norm_ln, a.gelu = p->act_gelu;
 	int nact = c->n_active > 0 ? c->n_active : 1;
@@ -401,7 +444,7 @@ void launch_ffn_down(Ctx* c, int l) {
 			by_bool(u7, [&](auto U7) {
 				by_bool(rows_full<DB>(kn), [&](auto FULL) {
 					hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->he,
-					                   w2, c->moe_w, c->moe_e, c->dim, c->hidden, c->n_active, k0, kn);
+					                   w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim, c->hidden, c->n_active, k0, kn);
 				});
 			});
 		});
@@ -649,25 +692,36 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 		// kernel before it), so the same step is first replayed from its graph between two events only: what the marked pass
 		// takes beyond that, spread evenly over its spans, is taken off each of them.  (The step is idempotent: same token, same
 		// position, same cache row written twice.)
-		while (c->events.size() < 2) {
-			hipEvent_t e;
-			HIP_CHECK(hipEventCreate(&e));
-			c->events.push_back(e);
-		}
-		replay(); // (first use of this plan: captures the graph)
-		HIP_CHECK(hipEventRecord(c->events[0], g_stream));
-		replay();
-		HIP_CHECK(hipEventRecord(c->events[1], g_stream));
-		HIP_CHECK(hipStreamSynchronize(g_stream));
+		// Only a step WITHOUT side effects beyond its own cache row may run more than once: not past the rolling buffer (the sink
+		// keys are re-rotated in place by every pass, src/infer.c:383-394), not a chained / sampled / arg-max step (next token,
+		// trace and coin are consumed), not a later pipeline stage (x is consumed in place).  Any other step takes the one marked
+		// pass and the marker cost of the last calibrated step -- profiling never changes results (src/infer.cu:761-801).
+		const bool calibrate = !sp.sink && !sp.chained && !sp.sample && !sp.argmax && embed;
 		float plain_ms = 0;
-		HIP_CHECK(hipEventElapsedTime(&plain_ms, c->events[0], c->events[1]));
+		if (calibrate) {
+			while (c->events.size() < 2) {
+				hipEvent_t e;
+				HIP_CHECK(hipEventCreate(&e));
+				c->events.push_back(e);
+			}
+			replay(); // (first use of this plan: captures the graph)
+			HIP_CHECK(hipEventRecord(c->events[0], g_stream));
+			replay();
+			HIP_CHECK(hipEventRecord(c->events[1], g_stream));
+			HIP_CHECK(hipStreamSynchronize(g_stream));
+			HIP_CHECK(hipEventElapsedTime(&plain_ms, c->events[0], c->events[1]));
+		}
 		dispatch_step(c, sp, true);
 		HIP_CHECK(hipStreamSynchronize(g_stream));
 		const size_t nspans = (size_t)c->n_layers * 5 + (sp.kv_only ? 0 : 1);
-		float marked_ms = 0;
-		HIP_CHECK(hipEventElapsedTime(&marked_ms, c->events[0], c->events[nspans]));
-		double marker_us = ((double)marked_ms - (double)plain_ms) * 1e3 / (double)nspans;
-		marker_us = marker_us > 0 ? marker_us : 0;
+		double marker_us = c->marker_us;
+		if (calibrate) {
+			float marked_ms = 0;
+			HIP_CHECK(hipEventElapsedTime(&marked_ms, c->events[0], c->events[nspans]));
+			marker_us = ((double)marked_ms - (double)plain_ms) * 1e3 / (double)nspans;
+			marker_us = marker_us > 0 ? marker_us : 0;
+			c->marker_us = marker_us;
+		}
 		size_t ev = 0;
 		auto span = [&](int stage) {
 			float ms = 0;
@@ -1001,6 +1055,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		return old_stage;
 	} else if (!strcmp(key, "stages")) {
 		return (int)g_devs.size();
+	} else if (!strcmp(key, "pf_redone")) {
+		return (int)g_pf_redone; // prompt tokens prefill_hip sent back through the serial path (activations beyond binary16)
 	} else {
 		return -1;
 	}
@@ -1063,6 +1119,9 @@ extern "C" void init_hip(void) {
 			if (d.dev != dev) {
 				int can = 0;
 				HIP_CHECK(hipDeviceCanAccessPeer(&can, d.dev, g_devs[s_ - 1].dev));
+				// no silent fallback: without peer access every hand-off would be staged through host memory by the runtime
+				CALM_REQUIRE(can || g_devs[s_ - 1].dev == d.dev || env_int("CALM_HIP_ALLOW_NO_PEER", 0),
+				             "CALM_HIP_DEVICES: adjacent pipeline stages sit on devices without peer access (xGMI / PCIe P2P); set CALM_HIP_ALLOW_NO_PEER=1 to run anyway");
 				if (can && g_devs[s_ - 1].dev != d.dev) {
 					hipError_t e = hipDeviceEnablePeerAccess(g_devs[s_ - 1].dev, 0); // the residual stream arrives from the stage before
 					if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
@@ -1103,7 +1162,7 @@ extern "C" void* upload_hip(void* host, size_t size) {
 		use_dev(g_alloc_stage);
 	}
 	void* device = dev_alloc(size);
-	HIP_CHECK(hipMemcpy(device, host, size, hipMemcpyHostToDevice));
+	staged_upload(device, host, size);
 	return device;
 }
 
@@ -1186,8 +1245,10 @@ void prepare_ctx(struct Transformer* t) {
 	c->he = (float*)dev_alloc((size_t)nact * c->hidden * sizeof(float));
 	c->partial = (float*)dev_alloc((size_t)c->n_heads * MAX_SPLIT * (c->head_dim + 2) * sizeof(float));
 	c->logits_d = (float*)dev_alloc((size_t)c->vocab * sizeof(float));
-	c->moe_w = (float*)dev_alloc(CALM_MAX_EXPERTS * sizeof(float));
-	c->moe_e = (int*)dev_alloc(CALM_MAX_EXPERTS * sizeof(int));
+	// routing of the last step: [layer][rank] weights, then [layer][rank] expert ids, one allocation (shown to the host as state.exp)
+	c->moe_w = (float*)dev_alloc((size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int)));
+	c->moe_e = (int*)(c->moe_w + (size_t)c->n_layers * CALM_MAX_EXPERTS);
+	HIP_CHECK(hipMemset(c->moe_w, 0, (size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int))));
 	c->next_tok = (int*)dev_alloc(sizeof(int));
 	c->sample_st = (SampleState*)dev_alloc(sizeof(SampleState));
 	c->trace_count = (int*)dev_alloc(sizeof(int));
@@ -1255,6 +1316,7 @@ void prepare_ctx(struct Transformer* t) {
 	s->he = c->he;
 	s->q = c->q;
 	s->att = c->att;
+	s->exp = c->moe_w; // (extension: the reference's GPU backend leaves it unset) include/calm_hip.h, prepare_hip
 	s->key_cache = c->kc;
 	s->value_cache = c->vc;
 	s->logits = c->logits_h;
@@ -1286,10 +1348,25 @@ void* upload_pending(const void* host, std::vector<void*>& owned) {
 		hipPointerAttribute_t attr;
 		CALM_REQUIRE(hipPointerGetAttributes(&attr, host) == hipSuccess && attr.type == hipMemoryTypeDevice,
 		             "multi-device: a weight pointer that came neither from a deferred upload_hip nor from a staged upload_hip / alloc_hip");
+		int cur = 0;
+		HIP_CHECK(hipGetDevice(&cur));
+		if (attr.device != cur) {
+			// placed on another stage's device (a tied classifier is the embedding table, which lives on stage 0): this stage
+			// gets its own copy -- peer access only reaches one stage back, and a classifier read over xGMI every token would
+			// be the slowest kernel of the step
+			size_t size = 0;
+			void* base = nullptr;
+			HIP_CHECK(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)host));
+			CALM_REQUIRE(base == host && size > DEV_PAD, "multi-device: a weight pointer into the middle of an allocation on another device");
+			void* d = dev_alloc(size - DEV_PAD);
+			HIP_CHECK(hipMemcpyPeer(d, cur, host, attr.device, size - DEV_PAD));
+			owned.push_back(d);
+			return d;
+		}
 		return const_cast<void*>(host);
 	}
 	void* d = dev_alloc(it->second);
-	HIP_CHECK(hipMemcpy(d, host, it->second, hipMemcpyHostToDevice));
+	staged_upload(d, host, it->second);
 	owned.push_back(d);
 	return d;
 }
@@ -1441,7 +1518,7 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (hipEvent_t e : c->events) {
 		HIP_CHECK(hipEventDestroy(e));
 	}
-	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->sample_st, c->logits_d, c->moe_w,  c->moe_e,
+	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->sample_st, c->logits_d, c->moe_w,
 	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc};
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
@@ -1534,11 +1611,45 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 	CALM_REQUIRE(!logprob || (last->t->weights.wcls && last->t->weights.rms_final_weight), "scoring needs the final norm and the classifier");
 	// The batched path covers the positions before the rolling buffer wraps; positions at or past seq_len
 	// (sink rotation between tokens) go through the decode path one token at a time, still on the device.
+	// one token through the decode path (positions past the rolling buffer; a chunk whose activations left the binary16 range)
+	auto serial_token = [&](int i) {
+		const float* l = nullptr;
+		if (m) {
+			l = forward_multi(m, tokens[i], pos + i, logprob ? 0u : (unsigned)FF_UPDATE_KV_ONLY);
+			on_stage(P - 1);
+		} else {
+			StepPlan sp = {};
+			sp.kv_only = logprob == nullptr;
+			sp.copy_logits = !sp.kv_only;
+			run_step(first, tokens[i], nullptr, pos + i, sp);
+			if (logprob) {
+				HIP_CHECK(hipStreamSynchronize(g_stream));
+				l = first->logits_h;
+			}
+		}
+		if (logprob) {
+			float lp = 0.f;
+			if (i + 1 < n) { // src/sampler.c:19-32, then the log of src/run.c:298
+				float mx = l[0];
+				for (int v = 1; v < last->vocab; ++v) {
+					mx = l[v] > mx ? l[v] : mx;
+				}
+				float sum = 0.f;
+				for (int v = 0; v < last->vocab; ++v) {
+					sum += expf(l[v] - mx);
+				}
+				lp = (l[tokens[i + 1]] - mx) - logf(sum);
+			}
+			logprob[i] = lp;
+		}
+	};
 	int done = 0;
 	if ((first->n_experts == 0 || first->n_active <= PF_MAX_ACTIVE) && first->t->weights.token_embedding_table) {
 		for (int s = 0; s < P; ++s) {
 			on_stage(s);
 			pf_alloc(st[s]);
+			// the K-range GEMMs leave their tile counters at zero; a launch that did not run to its end must not poison the next call
+			HIP_CHECK(hipMemsetAsync(st[s]->pf_tile_count, 0, PF_SPLIT_TILES * sizeof(unsigned), g_stream));
 		}
 		if (logprob && !last->pf_logits) { // (the last stage's device is current)
 			last->pf_logits = (float*)dev_alloc((size_t)PF_NT * last->vocab * sizeof(float));
@@ -1586,39 +1697,31 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 				HIP_CHECK(hipMemcpyAsync(logprob + done, last->pf_lp, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, g_stream));
 				HIP_CHECK(hipStreamSynchronize(g_stream));
 			}
+			// did every activation of the chunk fit the hi + lo binary16 form (prefill.hip.h: pf_split2)?  If not -- values beyond
+			// +-65504, NaN -- the chunk's cache rows (and scores) are redone by the serial fp32 decode path, token by token.
+			bool redo = false;
+			for (int s = 0; s < P; ++s) {
+				on_stage(s);
+				HIP_CHECK(hipStreamSynchronize(g_stream));
+				unsigned hit = 0;
+				HIP_CHECK(hipMemcpyFromSymbol(&hit, HIP_SYMBOL(calm_pf_range_hit), sizeof(hit)));
+				if (hit) {
+					redo = true;
+					hit = 0;
+					HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(calm_pf_range_hit), &hit, sizeof(hit)));
+				}
+			}
+			if (redo) {
+				g_pf_redone += nb;
+				for (int i = done; i < done + nb; ++i) {
+					serial_token(i);
+				}
+			}
 			done += nb;
 		}
 	}
 	for (; done < n; ++done) {
-		const float* l = nullptr;
-		if (m) {
-			l = forward_multi(m, tokens[done], pos + done, logprob ? 0u : (unsigned)FF_UPDATE_KV_ONLY);
-			on_stage(P - 1);
-		} else {
-			StepPlan sp = {};
-			sp.kv_only = logprob == nullptr;
-			sp.copy_logits = !sp.kv_only;
-			run_step(first, tokens[done], nullptr, pos + done, sp);
-			if (logprob) {
-				HIP_CHECK(hipStreamSynchronize(g_stream));
-				l = first->logits_h;
-			}
-		}
-		if (logprob) {
-			float lp = 0.f;
-			if (done + 1 < n) { // src/sampler.c:19-32, then the log of src/run.c:298
-				float mx = l[0];
-				for (int i = 1; i < last->vocab; ++i) {
-					mx = l[i] > mx ? l[i] : mx;
-				}
-				float sum = 0.f;
-				for (int i = 0; i < last->vocab; ++i) {
-					sum += expf(l[i] - mx);
-				}
-				lp = (l[tokens[done + 1]] - mx) - logf(sum);
-			}
-			logprob[done] = lp;
-		}
+		serial_token(done);
 	}
 	// `tokens` may be reused by the caller; KV rows are complete: the last stage's stream is behind every hand-off
 	on_stage(P - 1);

@@ -11,7 +11,8 @@
 // v_mfma_f32_32x32x16_f16 products, both exact in fp32 -- 16x the rate of the f32 MFMA form for twice the
 // instructions.  Narrowing the activations to ONE fp16 / bf16 number costs 3e-4..2e-3 per matvec and breaks the
 // 1e-3 logits parity with the CPU path; the split measures 4..8e-7 (tools/hilo_study.py), the same as the f32
-// MFMA form this file used before (bit-for-bit an fmaf chain, 157 TF peak).  Activations beyond +-65504 saturate.
+// MFMA form this file used before (bit-for-bit an fmaf chain, 157 TF peak).  An activation beyond +-65504 (or a NaN) raises
+// calm_pf_range_hit and the chunk is redone by the serial fp32 path (infer_hip.hip: prefill_impl).
 //
 // Two GEMM forms.  k_pf_gemm (next paragraph) fills the chip from few tiles by splitting K over the waves of a workgroup: short
 // prompts.  k_pf_gemm_wide (further down: B staged once per workgroup through LDS, A through a wave-private LDS image, XCD-aware
@@ -54,10 +55,19 @@ constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing ha
 __device__ __forceinline__ size_t pf_unit(int t, int k, int nsteps) {
 	return ((((size_t)(t >> 5) * nsteps + (k >> 6)) * 4 + ((k & 31) >> 3)) << 7) + (((k >> 5) & 1) << 5) + (t & 31);
 }
-// x = hi + lo, two binary16 numbers each (saturating at the binary16 range)
+// Set (never cleared by a kernel) when an activation did not fit the hi + lo form: beyond the binary16 range, or not a number.
+// prefill_impl reads it after every chunk and runs that chunk again through the serial fp32 decode path, so the batched path
+// either agrees with the serial one to fp32 rounding or is not used (one flag per module and device).
+__device__ unsigned calm_pf_range_hit;
+
+// x = hi + lo, two binary16 numbers each.  Out-of-range values saturate HERE (NaN stays NaN: the compares are ordered) and
+// raise calm_pf_range_hit, which sends the whole chunk back through the serial path.
 __device__ __forceinline__ void pf_split2(float a, float b, unsigned& hi, unsigned& lo) {
-	a = fminf(fmaxf(a, -65504.f), 65504.f);
-	b = fminf(fmaxf(b, -65504.f), 65504.f);
+	if (!(fabsf(a) <= 65504.f) || !(fabsf(b) <= 65504.f)) { // also true for NaN
+		calm_pf_range_hit = 1u;
+	}
+	a = a > 65504.f ? 65504.f : (a < -65504.f ? -65504.f : a);
+	b = b > 65504.f ? 65504.f : (b < -65504.f ? -65504.f : b);
 	const __half2 h = __floats2half2_rn(a, b);
 	const float2 hf = __half22float2(h);
 	const __half2 l = __floats2half2_rn(a - hf.x, b - hf.y);
@@ -1322,7 +1332,12 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 			for (int c = 0; c < NC; ++c) {
 #pragma unroll
 				for (int r = 0; r < 16; ++r) {
-					// written through (agent scope): a fence here would write back the XCD's whole L2
+					// Written through (agent scope = sc1 stores), then vmcnt(0), then the relaxed agent-scope arrival; the folding
+					// workgroup reads with agent-scope (sc1) loads, which are served past its L1: the CDNA guide's "sc1 payload ->
+					// drained vmcnt -> sc1 flag" hand-off (MI355X_MICROARCH.md, handoff-flag / valid forms).  That is a property of
+					// gfx942 / gfx950's write-through and cache-bypass behaviour, not a release/acquire pair of the memory model: a
+					// release fence here writes back the XCD's whole L2 (measured 70-400 us per launch).  Stress-tested over
+					// repeated launches at 2..8 ranges (tests/test_prefill_gemm.py); the counters are re-zeroed per prefill call.
 					__hip_atomic_store(mine + ((n * NC + c) * 16 + r) * 64, acc[n][c][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 			}

@@ -279,6 +279,19 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 	HIP_CHECK(hipMemcpy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
 }
 
+extern "C" void calm_hip_read_moe(struct Transformer* t, int layer, int* experts, float* weights) {
+	// routing of the LAST decode step at `layer`: the n_experts_ac expert ids in rank order and their softmax weights, as
+	// k_ffn_up left them (src/infer.c:277-305) -- from state.exp: [layer][CALM_MAX_EXPERTS] weights, then as many expert ids
+	CALM_REQUIRE(layer >= 0 && layer < t->config.n_layers && t->config.n_experts > 0, "calm_hip_read_moe: no such layer / not a mixture-of-experts model");
+	CALM_REQUIRE(t->state.exp, "calm_hip_read_moe: transformer not prepared by the hip backend on one device (a model split over CALM_HIP_DEVICES stages keeps its routing per stage)");
+	const int n = t->config.n_experts_ac;
+	const float* w = t->state.exp + (size_t)layer * CALM_MAX_EXPERTS;
+	const int* e = (const int*)(t->state.exp + (size_t)t->config.n_layers * CALM_MAX_EXPERTS) + (size_t)layer * CALM_MAX_EXPERTS;
+	HIP_CHECK(hipDeviceSynchronize());
+	HIP_CHECK(hipMemcpy(experts, e, n * sizeof(int), hipMemcpyDeviceToHost));
+	HIP_CHECK(hipMemcpy(weights, w, n * sizeof(float), hipMemcpyDeviceToHost));
+}
+
 namespace {
 template <bool NT>
 __global__ __launch_bounds__(256) void k_membench(const u32x4* src, size_t n16, unsigned* sink) {

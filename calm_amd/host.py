@@ -32,7 +32,7 @@ EXPORTS = [
     "free_hip", "download_hip", "decode_greedy_hip", "decode_sample_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip",
 ]
 # include/calm_hip_test.h: libcalm_hip_test.so, tests and tools only
-TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_test_sample", "calm_hip_test_pf_gemm", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_membench"]
+TEST_EXPORTS = ["calm_hip_test_matvec", "calm_hip_test_norm_matvec", "calm_hip_test_attn", "calm_hip_test_argmax", "calm_hip_test_sample", "calm_hip_test_pf_gemm", "calm_hip_read_kv", "calm_hip_write_kv", "calm_hip_read_moe", "calm_hip_membench"]
 
 
 class _Libs:
@@ -65,6 +65,7 @@ class _Libs:
                 "calm_hip_test_pf_gemm": (None, [C.c_int, C.c_void_p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int]),
                 "calm_hip_read_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
                 "calm_hip_write_kv": (None, [T, C.c_int, C.c_int, C.c_void_p]),
+                "calm_hip_read_moe": (None, [T, C.c_int, C.POINTER(C.c_int), fp]),
                 "calm_hip_membench": (C.c_double, [C.c_size_t, C.c_int, C.c_int]),
             }
             for n, (res, args) in protos.items():
@@ -364,6 +365,14 @@ class HipBackend:
         out = np.empty((c.seq_len, c.head_dim * c.n_kv_heads), dtype=np.uint16)
         self.lib.calm_hip_read_kv(C.byref(self.t), layer, which, out.ctypes.data)
         return out.view(np.float16)
+
+    def read_moe(self, layer: int):
+        """routing of the last decode step at `layer`: (expert ids in rank order, their weights) -- test hook"""
+        n = self.model.config.n_experts_ac
+        e = (C.c_int * n)()
+        w = np.empty(n, dtype=np.float32)
+        self.lib.calm_hip_read_moe(C.byref(self.t), layer, e, fptr(w))
+        return np.array(e[:], dtype=np.int64), w
 
     def write_kv(self, layer: int, which: int, rows: np.ndarray) -> None:
         """rows: (seq_len, kv_dim) float16 -> this layer's K (0) or V (1) cache (test hook)"""

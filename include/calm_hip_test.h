@@ -50,6 +50,11 @@ void calm_hip_read_kv(struct Transformer* transformer, int layer, int which, uin
  * byte), so that a test can start deep inside a long context */
 void calm_hip_write_kv(struct Transformer* transformer, int layer, int which, const uint16_t* host);
 
+/* Routing of the LAST decode step at one layer of a mixture-of-experts model prepared by libcalm_hip.so: the n_experts_ac expert
+ * ids in rank order and their weights (what src/infer.c:277-305 leaves in moe_experts / moe_weights for that layer).  Read from
+ * state.exp (include/calm_hip.h: prepare_hip); a model split over CALM_HIP_DEVICES stages keeps its routing per stage and has none there. */
+void calm_hip_read_moe(struct Transformer* transformer, int layer, int* experts, float* weights);
+
 /* Streaming-read micro-benchmark: sums `bytes` of device memory with 16-byte loads
  * (nt != 0: non-temporal) `iters` times; returns GB/s.  bytes <= 128 MiB stays in the 256 MiB
  * Infinity Cache after the first pass, bytes >= 1 GiB measures HBM. */

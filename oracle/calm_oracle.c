@@ -350,6 +350,16 @@ void oracle_kv_slots(int pos, int seq_len, int* kv_sink, int* kv_pos, int* kv_le
 
 /* ---------------------------------------------------------------- whole step --------------- */
 
+/* Test hook: where oracle_forward leaves EVERY layer's routing -- expert ids in rank order [layer][n_experts_ac], their weights,
+ * and the gate logits [layer][n_experts] -- for the full-depth routed-expert identity tests.  The reference keeps only the last
+ * layer's in state.exp (src/infer.c:423-432); NULL pointers switch the trace off. */
+static int* trace_experts;
+static float* trace_weights;
+static float* trace_logits;
+void oracle_trace_moe(int* experts, float* weights, float* logits) {
+	trace_experts = experts, trace_weights = weights, trace_logits = logits;
+}
+
 /* allocate activations + fp16 KV cache on the host; src/infer.c:142-181 */
 void oracle_prepare(struct Transformer* t) {
 	struct Config* p = &t->config;
@@ -477,6 +487,11 @@ float* oracle_forward_stage(struct Transformer* t, int token, int pos, unsigned 
 		if (p->n_experts) { /* :425-432 */
 			oracle_matvec(s->exp, s->xb, w->moegate[l], NULL, dim, p->n_experts, dbits);
 			oracle_moe_gate(moe_weights, moe_experts, s->exp, p->n_experts, p->n_experts_ac);
+			if (trace_experts) {
+				memcpy(trace_experts + (size_t)l * nact, moe_experts, nact * sizeof(int));
+				memcpy(trace_weights + (size_t)l * nact, moe_weights, nact * sizeof(float));
+				memcpy(trace_logits + (size_t)l * p->n_experts, s->exp, p->n_experts * sizeof(float));
+			}
 		} else {
 			moe_weights[0] = 1.0f;
 			moe_experts[0] = 0;

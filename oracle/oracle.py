@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
         L.oracle_forward.argtypes = [_T, C.c_int, C.c_int, C.c_uint]
         L.oracle_forward_stage.restype = _fp
         L.oracle_forward_stage.argtypes = [_T, C.c_int, C.c_int, C.c_uint, C.c_uint]
+        L.oracle_trace_moe.restype = None
+        L.oracle_trace_moe.argtypes = [C.POINTER(C.c_int), _fp, _fp]
         L.oracle_argmax.restype = C.c_int
         L.oracle_argmax.argtypes = [_fp, C.c_int]
         L.oracle_sample.restype = C.c_int
@@ -205,6 +207,21 @@ class OracleBackend(_CpuBackend):
         them (src/infer.cu:473-482,150-180; calm_oracle.c: kv_store) -- the checker of the HIP backend's fp8 cache"""
         L = lib()
         super().__init__(model, L.oracle_prepare, L.oracle_forward, L.oracle_release, kvbits)
+
+    def forward_traced(self, token: int, pos: int):
+        """forward() of a mixture-of-experts model that also returns every layer's routing:
+        (logits, experts [n_layers][n_active], weights [n_layers][n_active], gate logits [n_layers][n_experts])"""
+        c = self.model.config
+        e = np.zeros((c.n_layers, c.n_experts_ac), dtype=np.int32)
+        w = np.zeros((c.n_layers, c.n_experts_ac), dtype=np.float32)
+        g = np.zeros((c.n_layers, c.n_experts), dtype=np.float32)
+        L = lib()
+        L.oracle_trace_moe(e.ctypes.data_as(C.POINTER(C.c_int)), _f(w), _f(g))
+        try:
+            lg = self.forward(token, pos, 0)
+        finally:
+            L.oracle_trace_moe(None, None, None)
+        return lg, e, w, g
 
     # the pipeline-stage surface of calm_amd.host.HipBackend, on host memory (tests of the stage protocol)
     def forward_stage(self, token: int, pos: int, flags: int, stage_flags: int):

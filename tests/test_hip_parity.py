@@ -351,6 +351,67 @@ def test_pipeline_stages_on_one_gpu_equal_the_unsharded_step(hiplib, case):
         b1.close()
 
 
+def test_pipeline_stage_class_with_device_tensors(hiplib):
+    """calm_amd.pipeline.PipelineStage itself on the GPU: its hand-off buffers are torch DEVICE tensors whose data_ptr() goes
+    through copy_hip (import_x / export_x), torch's stream and the backend's being ordered by the synchronisations the class
+    places.  One process and one GPU cannot hold two RCCL ranks, so the transport is a loop-back object with torch.distributed's
+    send / recv / broadcast signatures (the real rendezvous is covered over gloo in tests/test_pipeline_gloo.py): what is under
+    test is the device-pointer path the CPU tests cannot reach.  Greedy stream == the unsharded backend's."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("torch sees no GPU on a box where the HIP backend does")
+    from calm_amd.pipeline import PipelineStage, stage_model
+
+    class Loopback:
+        """two stages in one process: rank / world are set per stage, messages are queued tensors"""
+
+        def __init__(self):
+            self.box = {}
+            self.rank = 0
+
+        def get_rank(self):
+            return self.rank
+
+        def get_world_size(self):
+            return 2
+
+        def send(self, t, dst):
+            self.box[dst] = t.clone()
+
+        def recv(self, t, src):
+            t.copy_(self.box.pop(self.rank))
+
+        def broadcast(self, t, src):
+            if self.rank == src:
+                self.box["tok"] = t.clone()
+            else:
+                t.copy_(self.box["tok"])
+
+    model, z = load_golden("moe_fp8")
+    whole = HipBackend(model)
+    want = [int(t) for t in generate(whole, model, [int(z["tokens"][0])], 12)[0]]
+    whole.close()
+    link = Loopback()
+    stages = []
+    for r in range(2):
+        sm, flags = stage_model(model, r, 2)
+        link.rank = r
+        stages.append(PipelineStage(HipBackend(sm), sm.config.dim, flags, link, "cuda"))
+    try:
+        tok, got = int(z["tokens"][0]), []
+        for pos in range(12):
+            link.rank = 0
+            assert stages[0].step(tok, pos) is None
+            link.rank = 1
+            logits = stages[1].step(tok, pos)
+            tok = int(np.argmax(logits))
+            got.append(tok)
+        assert got == want
+    finally:
+        for st in stages:
+            st.b.close()
+
+
 @pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip not built")
 def test_reference_cli_perplexity_mode_on_the_hip_backend():
     """`run -x file` (study(), src/run.c:258-316) through the unmodified reference CLI on the HIP backend:
@@ -401,22 +462,77 @@ def test_prefill_equals_the_serial_prompt_loop(hiplib, case, kvbits):
     T = len(toks)
     serial = HipBackend(model, kvbits=kvbits)
     batched = HipBackend(model, kvbits=kvbits)
+    # the checker: the reference's own logits for the fp16 cache (golden), the oracle's fp8-KV mode for the e5m2 cache (the
+    # reference's CPU path has none, src/infer.c:161; oracle/calm_oracle.c: kv_store restates the CUDA path's storage)
+    o8 = oracle.OracleBackend(model, kvbits=8) if kvbits == 8 else None
     try:
         for pos, tok in enumerate(toks[: T - 1]):
             serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         ls = serial.forward(toks[T - 1], T - 1, 0).copy()
         batched.prefill(toks[: T - 1], 0)
         lb = batched.forward(toks[T - 1], T - 1, 0).copy()
-        # (an e5m2 cache amplifies last-bit differences of the fp32 sums into whole rounding steps of a cached element)
-        assert rel_err(lb, ls) < (2e-4 if kvbits == 16 else 3e-2), rel_err(lb, ls)
         if kvbits == 16:
-            assert rel_err(lb, z["logits"][T - 1]) < LOGIT_TOL
+            want = z["logits"][T - 1]
+            assert rel_err(lb, ls) < 2e-4, rel_err(lb, ls)
+        else:
+            for pos, tok in enumerate(toks[: T - 1]):
+                o8.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+            want = o8.forward(toks[T - 1], T - 1, 0).copy()
+        assert rel_err(lb, want) < LOGIT_TOL, rel_err(lb, want)
+        assert rel_err(ls, want) < LOGIT_TOL, rel_err(ls, want)
         for ks, kb in zip(_kv_floats(hiplib, serial, kvbits), _kv_floats(hiplib, batched, kvbits)):
             # the same values up to one rounding step of the cache format (fp32 sums differ in their last bits)
             assert np.abs(ks - kb).max() <= (2e-3 if kvbits == 16 else 0.26) * max(np.abs(ks).max(), 1e-6)
     finally:
         serial.close()
         batched.close()
+        if o8 is not None:
+            o8.close()
+
+
+def test_prefill_falls_back_to_the_serial_path_when_an_activation_leaves_binary16(hiplib):
+    """The prompt GEMMs carry fp32 activations as hi + lo binary16 (range +-65504).  A model whose FFN hidden values exceed that
+    (weights 100 x the usual scale: act(w1 x) * (w3 x) ~ 1e5..1e6) must not silently saturate: the chunk raises the range flag
+    and is redone by the serial fp32 decode path, so cache rows and logits are THE SERIAL PATH'S, bit for bit -- and the
+    oracle's within the usual tolerance."""
+    spec = cf.tiny_spec("pfrange", max_seq_len=96, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=300)
+    tensors, md = cf.synth_model(spec, "fp16", seed=5, sigma=12.0)
+    model = HostModel(tensors, md)
+    rng = np.random.default_rng(8)
+    toks = [int(t) for t in rng.integers(0, 300, size=41)]
+    o = oracle.OracleBackend(model)
+    serial = HipBackend(model)
+    batched = HipBackend(model)
+    try:
+        biggest = 0.0
+        for pos, tok in enumerate(toks[:-1]):
+            o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+            biggest = max(biggest, float(np.abs(o.state("hb", spec.hidden_dim)).max()))  # (the last layer's FFN hidden values)
+            serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        lo = o.forward(toks[-1], 40, 0).copy()
+        assert biggest > 65504.0, "the fixture no longer leaves the binary16 range"
+        ls = serial.forward(toks[-1], 40, 0).copy()
+        before = hiplib.calm_hip_configure(b"pf_redone", -1)
+        batched.prefill(toks[:-1], 0)
+        assert hiplib.calm_hip_configure(b"pf_redone", -1) == before + 40, "the chunk was not sent back through the serial path"
+        lb = batched.forward(toks[-1], 40, 0).copy()
+        assert np.array_equal(lb, ls)
+        assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
+        lp = batched.prefill_logprobs(toks, 0)  # scoring takes the same way out
+        assert np.isfinite(lp).all()
+        # ... and a model of the usual scale does not take it
+        before = hiplib.calm_hip_configure(b"pf_redone", -1)
+    finally:
+        o.close()
+        serial.close()
+        batched.close()
+    model2, z = load_golden("tiny_fp8")
+    b2 = HipBackend(model2)
+    try:
+        b2.prefill([int(t) for t in z["tokens"]][:-1], 0)
+        assert hiplib.calm_hip_configure(b"pf_redone", -1) == before
+    finally:
+        b2.close()
 
 
 def test_prefill_in_two_calls_and_odd_chunks(hiplib):
@@ -476,7 +592,9 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
         finally:
             hiplib.calm_hip_configure(b"pf_attn_mfma", 1)
         lv = v.forward(toks[-1], 333, 0).copy()
-        assert rel_err(lb, lv) < (2e-5 if kvbits == 16 else 3e-2), rel_err(lb, lv)
+        assert rel_err(lv, lo) < LOGIT_TOL, rel_err(lv, lo)  # (lo: the oracle with THIS cache format, fp8-KV mode included)
+        if kvbits == 16:
+            assert rel_err(lb, lv) < 2e-5, rel_err(lb, lv)
         for km, kv in zip(_kv_floats(hiplib, b, kvbits), _kv_floats(hiplib, v, kvbits)):
             assert np.abs(km - kv).max() <= (2e-3 if kvbits == 16 else 0.26) * max(np.abs(kv).max(), 1e-6)
     finally:

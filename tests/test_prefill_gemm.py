@@ -55,7 +55,10 @@ def test_ranges_fold_in_a_fixed_order(hiplib, form):
     w = _rand_w(rng, M, K, "fp8")
     x = rng.standard_normal((nb, K)).astype(np.float32)
     a = gemm(hiplib, "fp8", w, x, M, K, FORMS[form])
-    for _ in range(3):
+    # Repeated: the hand-off of the partial tiles is write-through (sc1) stores, a drained vmcnt and a relaxed agent-scope
+    # counter, the reader's loads agent-scope too -- the CDNA guide's "drained sc1 flag" form, a contract of gfx942 / gfx950's
+    # caches rather than of the memory model (prefill.hip.h: k_pf_gemm_wide).  A stale partial would show as a bit difference.
+    for _ in range(24):
         assert np.array_equal(a, gemm(hiplib, "fp8", w, x, M, K, FORMS[form]))
 
 

@@ -39,3 +39,31 @@ def test_two_rank_replica_aggregation(tmp_path):
     assert out["world"] == 2
     assert abs(out["elapsed"] - 0.25) < 1e-9          # max over ranks
     assert abs(out["value"] - 2 * 50 / 0.25) < 1e-6   # whole-job steps / slowest rank's time
+
+
+def _bench(*flags):
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags, "--dry-run", "--steps", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout  # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus 2` with no launcher around it: it starts its own torch.distributed.run and reports n_gpus = 2
+    (round-2 verdict: --gpus was parsed and never read).  --dry-run: the rendezvous / barrier / max-over-ranks protocol over gloo,
+    no device work."""
+    out = _bench("--gpus", "2")
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["dry_run"] is True
+    assert abs(out["value"] - 2 * 4 / (1e-3 * 4 * 1.1)) < 1e-2  # whole-job steps over the slower rank's time
+    assert _bench()["n_gpus"] == 1
+
+
+def test_bench_pipeline_mode_is_config_5():
+    """--gpus N --pipeline: one process, DBRX-132B over P = N in-library stages, "capacity" scaling -- not N replicas"""
+    out = _bench("--gpus", "4", "--pipeline")
+    assert out["n_gpus"] == 4 and out["scaling"] == "capacity"
+    assert out["config"]["workload"].startswith("dbrx-132b") and "4-stage layer pipeline" in out["config"]["parallelism"]

@@ -91,6 +91,15 @@ def main():
                      + (f"{fmb / mb:.3f}" if fmb is not None and mb else "") + " |")
     open(os.path.join(root, "profiles", f"{tag}_kernel_stats.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
+    # the same table for programs (bench.py quotes the dominant kernel's rocprof average beside its own event timing), stamped
+    # with the hash of the kernel sources it was taken on
+    sys.path.insert(0, root)
+    from calm_amd.build import csrc_sha as _sha
+
+    js = {k: {"calls": len(v), "avg_us": sum(v) / len(v), "median_us": statistics.median(v), "min_us": min(v)} for k, v in durs.items() if k}
+    js["_csrc_sha"] = _sha()
+    js["_workload"] = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "mistral-7b fp8"
+    json.dump(js, open(os.path.join(root, "profiles", f"{tag}_kernel_stats.json"), "w"), indent=1)
     if fetch:
         res = {}
         for k, v in fetch.items():
