@@ -21,7 +21,11 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 REFERENCE = os.environ.get("CALM_REFERENCE", "/root/reference")
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# -amdgpu-kernarg-preload-count: the dispatcher hands a wave the first dwords of its kernel arguments in SGPRs (gfx940+) instead of
+# the wave loading them -- one memory round trip less at the head of every launch; kernels.hip.h orders its arguments for it
+PRELOAD_FLAGS = ["-mllvm", "-amdgpu-kernarg-preload-count=14"]
+BASE_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+HIP_FLAGS = BASE_FLAGS + PRELOAD_FLAGS
 
 
 def _newer(target: str, sources) -> bool:
@@ -68,6 +72,15 @@ def build_hip(force: bool = False) -> str:
         if p.wait() != 0:
             raise subprocess.CalledProcessError(p.returncode, cmd)
     return LIB_HIP
+
+
+def build_variant(tag: str, extra=(), base=None) -> str:
+    """an A/B build of the product library for tools/ (calm_amd/libcalm_hip_<tag>.so, loaded through CALM_HIP_LIB): the same
+    source with other flags / -D switches"""
+    out = os.path.join(ROOT, "calm_amd", f"libcalm_hip_{tag}.so")
+    if not _newer(out, hip_sources() + [os.path.abspath(__file__)]):
+        _run([HIPCC, *(BASE_FLAGS if base is None else base), *extra, "-shared", "-o", out, os.path.join(CSRC, "infer_hip.hip")])
+    return out
 
 
 def build_oracle(force: bool = False) -> str:

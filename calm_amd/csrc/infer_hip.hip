@@ -314,7 +314,8 @@ void launch_qkv(Ctx* c, int l) {
 	size_t lds = lds_bytes<DB>(c->dim);
 	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a);
+			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.wq, a.wk, a.wv, a.dim, a.q_dim,
+			                   a.kv_dim, a);
 		});
 	});
 }
@@ -332,18 +333,18 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
-		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a);
+		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
 		return;
 	}
 	// long context: K/V rows loaded once per kv head for up to 4 query heads, kv range split, then merged
 	const int qh = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
 	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
 	if (qh == 4) {
-		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 4>), grid, block, 0, g_stream, a);
+		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 	} else if (qh == 2) {
-		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 2>), grid, block, 0, g_stream, a);
+		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 2>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 	} else {
-		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1>), grid, block, 0, g_stream, a);
+		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 	}
 	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(256), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
 }
@@ -399,7 +400,8 @@ void launch_ffn_up(Ctx* c, int l) {
 	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			by_bool(c->n_experts > 0, [&](auto MOE) {
-				hipLaunchKernelGGL((k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(MOE)::value>), grid, block, lds, g_stream, a);
+				hipLaunchKernelGGL((k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(MOE)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.w1, a.w3,
+					                   a.moegate, a.dim, a.hidden, a.n_experts, a.n_active, a);
 			});
 		});
 	});

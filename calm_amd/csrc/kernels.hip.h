@@ -732,8 +732,13 @@ struct QkvArgs {
 
 // attention norm + fused q/k/v matvec + bias + clip + RoPE + KV append   (src/infer.c:352-381)
 // task = NR consecutive rows of the concatenated [wq; wk; wv]; rows come in RoPE pairs (2i, 2i+1).
+// The arguments a wave needs before it can ask for its first byte come FIRST and as scalars: with kernel-argument preloading
+// (hipcc -mllvm -amdgpu-kernarg-preload-count, calm_amd/build.py) the dispatcher delivers the leading dwords in SGPRs with the
+// wave instead of the wave fetching them from memory -- a round trip at the head of every launch.  The struct carries the rest
+// (and stale copies of the leading ones, which are overwritten here).
 template <int DB, int KVB, int V, bool FULL>
-__global__ __launch_bounds__(256) void k_qkv(QkvArgs a) {
+__global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w, const void* wq, const void* wk, const void* wv, int dim, int q_dim, int kv_dim, QkvArgs a) {
+	a.x = x, a.norm_w = norm_w, a.wq = wq, a.wk = wk, a.wv = wv, a.dim = dim, a.q_dim = q_dim, a.kv_dim = kv_dim;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -852,7 +857,8 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // loaded one ahead of the arithmetic.  (Issuing the first round before kv_len is known -- clamped to the cache instead
 // of the live range -- measured the same 4.7 us and fetched 4 MB per launch of rows nobody needs: not kept.)
 template <int KVB, int LPR>
-__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
+__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const float* q, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, AttnArgs a) {
+	a.ts = ts, a.q = q, a.kc = kc, a.vc = vc, a.head_dim = head_dim, a.kv_mul = kv_mul, a.seq_len = seq_len; // (leading scalars: see k_qkv)
 	constexpr int RPW = 64 / LPR; // positions per wave-load
 	constexpr int NW = ATTN_BLOCK / 64;
 	constexpr int UA = 4; // tiles in flight per wave
@@ -1016,7 +1022,8 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(AttnArgs a) {
 constexpr int ATTN_GQA_BLOCK = 256;
 
 template <int KVB, int LPR, int QH>
-__global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(AttnArgs a) {
+__global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts, const float* q, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
+	a.ts = ts, a.q = q, a.kc = kc, a.vc = vc, a.head_dim = head_dim, a.kv_mul = kv_mul, a.seq_len = seq_len, a.n_split = n_split; // (see k_qkv)
 	constexpr int RPW = 64 / LPR;
 	constexpr int NW = ATTN_GQA_BLOCK / 64;
 	constexpr int UA = 4;
@@ -1300,7 +1307,9 @@ __device__ __forceinline__ float act_gelu(float x) {
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
 template <int DB, int V, bool FULL, bool MOE>
-__global__ __launch_bounds__(256) void k_ffn_up(FfnUpArgs a) {
+__global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
+                                                 FfnUpArgs a) {
+	a.x = x, a.norm_w = norm_w, a.w1 = w1, a.w3 = w3, a.moegate = moegate, a.dim = dim, a.hidden = hidden, a.n_experts = n_experts, a.n_active = n_active; // (see k_qkv)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	constexpr int JP = NR / 2; // hidden units per task
