@@ -314,8 +314,7 @@ void launch_qkv(Ctx* c, int l) {
 	size_t lds = lds_bytes<DB>(c->dim);
 	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.wq, a.wk, a.wv, a.dim, a.q_dim,
-			                   a.kv_dim, a);
+			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.dim, a.q_dim, a.kv_dim, a);
 		});
 	});
 }

@@ -735,26 +735,26 @@ struct QkvArgs {
 // The arguments a wave needs before it can ask for its first byte come FIRST and as scalars: with kernel-argument preloading
 // (hipcc -mllvm -amdgpu-kernarg-preload-count, calm_amd/build.py) the dispatcher delivers the leading dwords in SGPRs with the
 // wave instead of the wave fetching them from memory -- a round trip at the head of every launch.  The struct carries the rest
-// (and stale copies of the leading ones, which are overwritten here).
+// (and copies of the leading ones, which the kernel does not read; the struct itself is never written: a modified by-value
+// struct argument is copied to scratch memory, +4 us per launch when that was tried).
 template <int DB, int KVB, int V, bool FULL>
-__global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w, const void* wq, const void* wk, const void* wv, int dim, int q_dim, int kv_dim, QkvArgs a) {
-	a.x = x, a.norm_w = norm_w, a.wq = wq, a.wk = wk, a.wv = wv, a.dim = dim, a.q_dim = q_dim, a.kv_dim = kv_dim;
+__global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
-	float* red = (float*)(xs4 + xs_slots<DB>(a.dim));
-	const int rows_total = a.q_dim + 2 * a.kv_dim;
+	float* red = (float*)(xs4 + xs_slots<DB>(dim));
+	const int rows_total = q_dim + 2 * kv_dim;
 	const int ntasks = rows_total / NR;
-	const size_t row_bytes = (size_t)a.dim * DB / 8;
+	const size_t row_bytes = (size_t)dim * DB / 8;
 	const int lane = lane_id();
 
 	auto row_ptr = [&](int j) -> const unsigned char* {
 		// j is wave-uniform: keep the three-way choice in scalar selects (an if-chain over the three
 		// kernel-argument pointers gets turned into a scratch-memory lookup table by the optimiser)
 		j = __builtin_amdgcn_readfirstlane(j);
-		const bool is_q = j < a.q_dim, is_k = j < a.q_dim + a.kv_dim;
-		const unsigned char* base = (const unsigned char*)(is_q ? a.wq : (is_k ? a.wk : a.wv));
-		const int jl = j - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim));
+		const bool is_q = j < q_dim, is_k = j < q_dim + kv_dim;
+		const unsigned char* base = (const unsigned char*)(is_q ? a.wq : (is_k ? a.wk : a.wv)); // (from the struct: as leading scalars the select became a scratch table)
+		const int jl = j - (is_q ? 0 : (is_k ? q_dim : q_dim + kv_dim));
 		return base + (size_t)jl * row_bytes;
 	};
 	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
@@ -764,15 +764,15 @@ __global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w
 		}
 	};
 	StageRegs<V, true> sr;
-	auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
-	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, a.xb_dump); };
+	auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
+	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump); };
 	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
 	// aux = (cos, sin) of each row pair's RoPE angle, fetched before the task's last multiply-add
 	auto aux_of = [&](int t, float(&aux)[NR]) {
 #pragma unroll
 		for (int r = 0; r < NR; r += 2) {
 			int j = t * NR + r;
-			int jl = j < a.q_dim ? j : j - a.q_dim;
+			int jl = j < q_dim ? j : j - q_dim;
 			float2 cs = a.rope_cs[(jl % a.head_dim) >> 1]; // v rows: an unused but in-bounds entry
 			aux[r] = cs.x;
 			aux[r + 1] = cs.y;
@@ -792,19 +792,19 @@ __global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w
 			}
 			v0 = clipf(v0, a.clip);
 			v1 = clipf(v1, a.clip);
-			if (j < a.q_dim + a.kv_dim) { // q or k: rotate the pair (src/infer.c:223-236)
+			if (j < q_dim + kv_dim) { // q or k: rotate the pair (src/infer.c:223-236)
 				float r0 = v0 * aux[r] - v1 * aux[r + 1];
 				float r1 = v0 * aux[r + 1] + v1 * aux[r];
 				v0 = r0;
 				v1 = r1;
 			}
-			if (j < a.q_dim) {
+			if (j < q_dim) {
 				*(float2*)(a.q + j) = make_float2(v0, v1);
 			} else {
-				int jl = j - a.q_dim;
+				int jl = j - q_dim;
 				void* cache = a.kc;
-				if (jl >= a.kv_dim) {
-					jl -= a.kv_dim;
+				if (jl >= kv_dim) {
+					jl -= kv_dim;
 					cache = a.vc;
 				}
 				size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + kv_pos) * a.head_dim + (jl % a.head_dim);
@@ -816,7 +816,7 @@ __global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -857,8 +857,7 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // loaded one ahead of the arithmetic.  (Issuing the first round before kv_len is known -- clamped to the cache instead
 // of the live range -- measured the same 4.7 us and fetched 4 MB per launch of rows nobody needs: not kept.)
 template <int KVB, int LPR>
-__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const float* q, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, AttnArgs a) {
-	a.ts = ts, a.q = q, a.kc = kc, a.vc = vc, a.head_dim = head_dim, a.kv_mul = kv_mul, a.seq_len = seq_len; // (leading scalars: see k_qkv)
+__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
 	constexpr int NW = ATTN_BLOCK / 64;
 	constexpr int UA = 4; // tiles in flight per wave
@@ -868,16 +867,16 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const f
 
 	const int lane = lane_id(), wave = wave_id();
 	const int h = blockIdx.x;
-	const int kvh = h / a.kv_mul;
+	const int kvh = h / kv_mul;
 	const int r = lane % LPR, g = lane / LPR;
-	const bool dvalid = r * 8 < a.head_dim;
+	const bool dvalid = r * 8 < head_dim;
 	const int d0 = dvalid ? r * 8 : 0; // lanes past head_dim (non power-of-two heads) shadow dims 0..7 and are masked
 
 	constexpr int EB = KVB / 8; // bytes per element
 	using Raw = std::conditional_t<KVB == 16, u32x4, u32x2>; // 8 cached elements
-	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const size_t rstride = (size_t)a.head_dim * EB;
+	const unsigned char* kbase = (const unsigned char*)kc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)vc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
+	const size_t rstride = (size_t)head_dim * EB;
 	Raw kw[UA], vw[UA];
 	auto load_round = [&](int tb, int last_row) { // always issued, clamped into [0, last_row]
 #pragma unroll
@@ -887,16 +886,16 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const f
 			vw[u] = *(const Raw*)(vbase + (size_t)t * rstride);
 		}
 	};
-	const int kv_len = a.ts->kv_len;
+	const int kv_len = ts->kv_len;
 	load_round(wave * RPW, kv_len - 1);
 
 	float qv[8];
 #pragma unroll
 	for (int i = 0; i < 8; ++i) {
-		float qi = a.q[h * a.head_dim + d0 + i];
+		float qi = qin[h * head_dim + d0 + i];
 		qv[i] = dvalid ? qi : 0.f;
 	}
-	const float sqrt_hd = sqrtf((float)a.head_dim);
+	const float sqrt_hd = sqrtf((float)head_dim);
 
 	float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
@@ -997,7 +996,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const f
 	// Merge the NW wave partials with one THREAD per output dim: the weights exp(m_w - M) are recomputed by every
 	// thread (NW exps), then one pass over the partials -- all of it parallel over head_dim threads.  (One lane group
 	// folding the waves in one after the other was a chain of NW dependent exp + rescale steps: ~1 us of this kernel.)
-	for (int d = threadIdx.x; d < a.head_dim; d += ATTN_BLOCK) {
+	for (int d = threadIdx.x; d < head_dim; d += ATTN_BLOCK) {
 		float M = sm_m[0];
 #pragma unroll
 		for (int w = 1; w < NW; ++w) {
@@ -1010,7 +1009,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const f
 			L = fmaf(sm_l[w], e, L);
 			O = fmaf(sm_o[w][d], e, O);
 		}
-		a.out[h * a.head_dim + d] = O / L;
+		a.out[h * head_dim + d] = O / L;
 	}
 }
 
@@ -1022,8 +1021,7 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const f
 constexpr int ATTN_GQA_BLOCK = 256;
 
 template <int KVB, int LPR, int QH>
-__global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts, const float* q, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
-	a.ts = ts, a.q = q, a.kc = kc, a.vc = vc, a.head_dim = head_dim, a.kv_mul = kv_mul, a.seq_len = seq_len, a.n_split = n_split; // (see k_qkv)
+__global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
 	constexpr int RPW = 64 / LPR;
 	constexpr int NW = ATTN_GQA_BLOCK / 64;
 	constexpr int UA = 4;
@@ -1031,16 +1029,16 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	__shared__ float sm_o[QH][NW][LPR * 8];
 
 	const int lane = lane_id(), wave = wave_id();
-	const int qgroups = a.kv_mul / QH;
-	const int split = blockIdx.x % a.n_split;
-	const int qg = (blockIdx.x / a.n_split) % qgroups;
-	const int kvh = blockIdx.x / (a.n_split * qgroups);
-	const int h0 = kvh * a.kv_mul + qg * QH; // first of this block's QH query heads
+	const int qgroups = kv_mul / QH;
+	const int split = blockIdx.x % n_split;
+	const int qg = (blockIdx.x / n_split) % qgroups;
+	const int kvh = blockIdx.x / (n_split * qgroups);
+	const int h0 = kvh * kv_mul + qg * QH; // first of this block's QH query heads
 	const int r = lane % LPR, g = lane / LPR;
-	const bool dvalid = r * 8 < a.head_dim;
+	const bool dvalid = r * 8 < head_dim;
 	const int d0 = dvalid ? r * 8 : 0;
-	const int kv_len = a.ts->kv_len;
-	const int chunk = (kv_len + a.n_split - 1) / a.n_split;
+	const int kv_len = ts->kv_len;
+	const int chunk = (kv_len + n_split - 1) / n_split;
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
 
@@ -1049,11 +1047,11 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	for (int q = 0; q < QH; ++q) {
 #pragma unroll
 		for (int i = 0; i < 8; ++i) {
-			float qi = a.q[(h0 + q) * a.head_dim + d0 + i];
+			float qi = qin[(h0 + q) * head_dim + d0 + i];
 			qv[q][i] = dvalid ? qi : 0.f;
 		}
 	}
-	const float inv_sqrt_hd = 1.0f / sqrtf((float)a.head_dim); // one rounding away from the reference's division (src/infer.c:247)
+	const float inv_sqrt_hd = 1.0f / sqrtf((float)head_dim); // one rounding away from the reference's division (src/infer.c:247)
 	float m[QH], l[QH], o[QH][8];
 #pragma unroll
 	for (int q = 0; q < QH; ++q) {
@@ -1065,9 +1063,9 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	}
 
 	constexpr int EB = KVB / 8;
-	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * a.head_dim + d0) * EB;
-	const size_t rstride = (size_t)a.head_dim * EB;
+	const unsigned char* kbase = (const unsigned char*)kc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)vc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
+	const size_t rstride = (size_t)head_dim * EB;
 
 	// Rounds are loaded one ahead: the raw rows of round n+1 are in flight while round n is multiplied out.  (With the
 	// loads at the top of each round and one 8-wave workgroup per CU -- 160 VGPRs -- nothing hid the load latency:
@@ -1179,8 +1177,8 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	}
 	__syncthreads();
 	// one thread per (query head, output dim) folds the NW wave partials (see k_attn)
-	for (int idx = threadIdx.x; idx < QH * a.head_dim; idx += ATTN_GQA_BLOCK) {
-		const int q = idx / a.head_dim, d = idx % a.head_dim;
+	for (int idx = threadIdx.x; idx < QH * head_dim; idx += ATTN_GQA_BLOCK) {
+		const int q = idx / head_dim, d = idx % head_dim;
 		float M = sm_m[q][0];
 #pragma unroll
 		for (int w = 1; w < NW; ++w) {
@@ -1193,11 +1191,11 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 			L = fmaf(sm_l[q][w], e, L);
 			O = fmaf(sm_o[q][w][d], e, O);
 		}
-		float* p = a.partial + ((size_t)(h0 + q) * a.n_split + split) * (a.head_dim + 2);
+		float* p = a.partial + ((size_t)(h0 + q) * n_split + split) * (head_dim + 2);
 		p[d] = O;
 		if (d == 0) {
-			p[a.head_dim] = M;
-			p[a.head_dim + 1] = L;
+			p[head_dim] = M;
+			p[head_dim + 1] = L;
 		}
 	}
 }
@@ -1309,30 +1307,29 @@ __device__ __forceinline__ float act_gelu(float x) {
 template <int DB, int V, bool FULL, bool MOE>
 __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
-	a.x = x, a.norm_w = norm_w, a.w1 = w1, a.w3 = w3, a.moegate = moegate, a.dim = dim, a.hidden = hidden, a.n_experts = n_experts, a.n_active = n_active; // (see k_qkv)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	constexpr int JP = NR / 2; // hidden units per task
 	float4* xs4 = (float4*)smem;
-	float* red = (float*)(xs4 + xs_slots<DB>(a.dim));
+	float* red = (float*)(xs4 + xs_slots<DB>(dim));
 	float* gate = red + 16;          // n_experts logits
 	float* sel_w = gate + 64;        // n_active
 	int* sel_e = (int*)(sel_w + 64); // n_active
-	const size_t row_bytes = (size_t)a.dim * DB / 8;
+	const size_t row_bytes = (size_t)dim * DB / 8;
 	const int lane = lane_id(), wave = wave_id();
-	const int nact = a.n_active > 0 ? a.n_active : 1;
-	const int per_expert = a.hidden / JP;
+	const int nact = n_active > 0 ? n_active : 1;
+	const int per_expert = hidden / JP;
 	const int ntasks = nact * per_expert;
 	constexpr bool moe = MOE;
 
 	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
 		int k = t / per_expert, j = (t % per_expert) * JP;
 		int e = moe ? sel_e[k] : 0;
-		size_t base = ((size_t)e * a.hidden + j) * row_bytes;
+		size_t base = ((size_t)e * hidden + j) * row_bytes;
 #pragma unroll
 		for (int p = 0; p < JP; ++p) {
-			rows[2 * p] = (const unsigned char*)a.w1 + base + p * row_bytes;
-			rows[2 * p + 1] = (const unsigned char*)a.w3 + base + p * row_bytes;
+			rows[2 * p] = (const unsigned char*)w1 + base + p * row_bytes;
+			rows[2 * p + 1] = (const unsigned char*)w3 + base + p * row_bytes;
 		}
 	};
 	auto no_aux = [&](int, float(&)[NR]) {};
@@ -1342,16 +1339,16 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 #pragma unroll
 			for (int p = 0; p < JP; ++p) {
 				float u = acc[2 * p], g = acc[2 * p + 1];
-				a.he[(size_t)k * a.hidden + j + p] = (a.gelu ? act_gelu(u) : act_silu(u)) * g; // src/infer.c:440-450
+				a.he[(size_t)k * hidden + j + p] = (a.gelu ? act_gelu(u) : act_silu(u)) * g; // src/infer.c:440-450
 			}
 		}
 	};
 
 	StageRegs<V, true> sr;
 	if constexpr (!MOE) {
-		auto pre = [&]() { stage_load<256>(sr, a.x, a.norm_w); };
-		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, pre, stage, no_aux, epi);
+		auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
+		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
+		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -1365,25 +1362,25 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 	// so that the norm prologue runs while they fly.  Wave w owns experts w, w + 4, ...; its loads are numbered
 	// j = (expert slot i) * chunks + (1-KiB chunk k of the row); the first GP of them are prefetched into registers.
 	constexpr int GP = 8; // (16 measured no better on the 8-expert shape: eight surplus loads per wave ahead of the weight stream)
-	const int nl = a.dim / Fmt<DB>::G;          // 16-byte lane-loads per row
+	const int nl = dim / Fmt<DB>::G;          // 16-byte lane-loads per row
 	const int chunks = (nl + 63) >> 6;          // wave-loads per row
-	const int per_wave = (a.n_experts + 3) >> 2; // expert slots of a wave
+	const int per_wave = (n_experts + 3) >> 2; // expert slots of a wave
 	const int total = per_wave * chunks;
 	auto gate_src = [&](int j, int& e, int& k) -> gptr16 {
 		const int i = j / chunks;
 		k = j - i * chunks;
 		e = wave + 4 * i;
-		const int ec = min(e, a.n_experts - 1), li = min(k * 64 + lane, nl - 1); // always in bounds; masked at use
-		return (gptr16)((const unsigned char*)a.moegate + (size_t)ec * row_bytes) + li;
+		const int ec = min(e, n_experts - 1), li = min(k * 64 + lane, nl - 1); // always in bounds; masked at use
+		return (gptr16)((const unsigned char*)moegate + (size_t)ec * row_bytes) + li;
 	};
-	stage_load<256>(sr, a.x, a.norm_w);
+	stage_load<256>(sr, x, norm_w);
 	u32x4 gw[GP];
 #pragma unroll
 	for (int j = 0; j < GP; ++j) {
 		int e, k;
 		gw[j] = *gate_src(min(j, total - 1), e, k);
 	}
-	stage_finish<DB, 256>(sr, xs4, red, a.x, a.norm_w, a.dim, a.eps, a.ln != 0, nullptr);
+	stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr);
 	{
 		f32x2 acc2 = {0.f, 0.f};
 		auto gate_step = [&](u32x4 w, int j) { // multiply-add load j; a row's last chunk reduces and files the logit
@@ -1397,7 +1394,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 			acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
 			if (k == chunks - 1) {
 				const float logit = wave_sum63(acc2[0] + acc2[1]);
-				if (lane == RED_LANE && e < a.n_experts) {
+				if (lane == RED_LANE && e < n_experts) {
 					gate[e] = logit;
 				}
 			}
@@ -1418,7 +1415,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 			// Routing, one expert per lane (n_experts <= 64): n_active rounds of a wave-wide arg-max over the logits not yet
 			// taken -- larger logit wins, equal logits go to the lower expert index -- then the softmax over the winners only,
 			// their exponentials summed in rank order (the semantics of src/infer.c:277-305; rank k ends up in lane k).
-			const bool valid = lane < a.n_experts;
+			const bool valid = lane < n_experts;
 			const float logit = valid ? gate[valid ? lane : 0] : 0.f;
 			float top = logit; // the largest logit overall: the softmax's reference point
 			{
@@ -1436,7 +1433,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 			bool open = valid; // this lane's expert can still be picked
 			float rank_logit = 0.f;
 			int rank_expert = 0;
-			for (int k = 0; k < a.n_active; ++k) {
+			for (int k = 0; k < n_active; ++k) {
 				float bv = logit;
 				int bi = lane;
 				bool ok = open;
@@ -1455,12 +1452,12 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 					rank_expert = bi;
 				}
 			}
-			const float ex = lane < a.n_active ? expf(rank_logit - top) : 0.f;
+			const float ex = lane < n_active ? expf(rank_logit - top) : 0.f;
 			float denom = 0.f;
-			for (int k = 0; k < a.n_active; ++k) {
+			for (int k = 0; k < n_active; ++k) {
 				denom += __shfl(ex, k);
 			}
-			if (lane < a.n_active) {
+			if (lane < n_active) {
 				sel_e[lane] = rank_expert;
 				sel_w[lane] = ex / denom;
 				if (blockIdx.x == 0) {
@@ -1472,7 +1469,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 		__syncthreads();
 	}
 	auto nothing = [&]() {};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, a.dim, xs4, a.x, rows_of, nothing, nothing, no_aux, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, dim, xs4, x, rows_of, nothing, nothing, no_aux, epi);
 }
 
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)

@@ -125,3 +125,30 @@ def test_product_never_touches_the_oracle():
                 if re.search(r"(from|import)\s+oracle|liboracle|libcalm_ref|oracle/", txt) and f != "build.py":
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_no_kernel_of_the_product_touches_scratch_memory(tmp_path):
+    """Every kernel of libcalm_hip.so must keep its state in registers and LDS: private (scratch) memory in a kernel this short is
+    a memory round trip at its head and, beside counted s_waitcnt vmcnt(N) waits, a hidden vmcnt(0).  It has crept in twice --
+    a by-value struct argument that the kernel modified, and a select between three pointer ARGUMENTS that the optimiser turned
+    into a stack table (+4 us per k_qkv launch) -- so the code object's own metadata is checked here, without a GPU."""
+    import re
+    import shutil
+    import subprocess
+
+    from calm_amd.build import LIB_HIP
+
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not (os.path.exists(objdump) and os.path.exists(readelf) and os.path.exists(LIB_HIP)):
+        pytest.skip("ROCm llvm tools or the built library missing")
+    so = shutil.copy(LIB_HIP, tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(so)], cwd=tmp_path, check=True, capture_output=True)
+    objs = [f for f in os.listdir(tmp_path) if "amdgcn" in f]
+    assert objs, "no device code object found in the library"
+    notes = subprocess.run([readelf, "--notes", str(tmp_path / objs[0])], capture_output=True, text=True, check=True).stdout
+    names = re.findall(r"^\s+\.name:\s+(\S+)", notes, re.M)
+    sizes = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", notes)]
+    assert len(names) == len(sizes) and len(names) > 100  # every template instantiation is a kernel
+    bad = {n: s for n, s in zip(names, sizes) if s}
+    assert not bad, f"kernels using scratch memory: {bad}"

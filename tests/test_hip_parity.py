@@ -351,65 +351,79 @@ def test_pipeline_stages_on_one_gpu_equal_the_unsharded_step(hiplib, case):
         b1.close()
 
 
+PIPELINE_STAGE_WORKER = """
+import json, os, sys
+import numpy as np
+import torch   # first: the wheel carries its own HIP runtime, which has to come up before libcalm_hip.so's
+sys.path.insert(0, os.environ["CALM_ROOT"])
+if not torch.cuda.is_available():
+    print(json.dumps({"torch_gpu": False})); sys.exit(0)
+from calm_amd.host import HipBackend, HostModel, generate
+from calm_amd.pipeline import PipelineStage, stage_model
+
+
+class Loopback:
+    # two stages in one process: rank is set per stage, messages are queued tensors (torch.distributed's signatures)
+    def __init__(self):
+        self.box, self.rank = {}, 0
+    def get_rank(self):
+        return self.rank
+    def get_world_size(self):
+        return 2
+    def send(self, t, dst):
+        self.box[dst] = t.clone()
+    def recv(self, t, src):
+        t.copy_(self.box.pop(self.rank))
+    def broadcast(self, t, src):
+        if self.rank == src:
+            self.box["tok"] = t.clone()
+        else:
+            t.copy_(self.box["tok"])
+
+
+model = HostModel.from_file(os.environ["CALM_MODEL"])
+first = int(os.environ["CALM_FIRST"])
+whole = HipBackend(model)
+want = [int(t) for t in generate(whole, model, [first], 12)[0]]
+whole.close()
+link = Loopback()
+stages = []
+for r in range(2):
+    sm, flags = stage_model(model, r, 2)
+    link.rank = r
+    stages.append(PipelineStage(HipBackend(sm), sm.config.dim, flags, link, "cuda"))
+tok, got = first, []
+for pos in range(12):
+    link.rank = 0
+    assert stages[0].step(tok, pos) is None
+    link.rank = 1
+    tok = int(np.argmax(stages[1].step(tok, pos)))
+    got.append(tok)
+print(json.dumps({"torch_gpu": True, "got": got, "want": want}))
+"""
+
+
 def test_pipeline_stage_class_with_device_tensors(hiplib):
     """calm_amd.pipeline.PipelineStage itself on the GPU: its hand-off buffers are torch DEVICE tensors whose data_ptr() goes
     through copy_hip (import_x / export_x), torch's stream and the backend's being ordered by the synchronisations the class
     places.  One process and one GPU cannot hold two RCCL ranks, so the transport is a loop-back object with torch.distributed's
     send / recv / broadcast signatures (the real rendezvous is covered over gloo in tests/test_pipeline_gloo.py): what is under
-    test is the device-pointer path the CPU tests cannot reach.  Greedy stream == the unsharded backend's."""
-    torch = pytest.importorskip("torch")
-    if not torch.cuda.is_available():
-        pytest.fail("torch sees no GPU on a box where the HIP backend does")
-    from calm_amd.pipeline import PipelineStage, stage_model
+    test is the device-pointer path the CPU tests cannot reach.  Greedy stream == the unsharded backend's.  Its own process:
+    torch's bundled HIP runtime and the system one libcalm_hip.so links must come up in that order."""
+    import json
+    import subprocess
+    import sys
 
-    class Loopback:
-        """two stages in one process: rank / world are set per stage, messages are queued tensors"""
-
-        def __init__(self):
-            self.box = {}
-            self.rank = 0
-
-        def get_rank(self):
-            return self.rank
-
-        def get_world_size(self):
-            return 2
-
-        def send(self, t, dst):
-            self.box[dst] = t.clone()
-
-        def recv(self, t, src):
-            t.copy_(self.box.pop(self.rank))
-
-        def broadcast(self, t, src):
-            if self.rank == src:
-                self.box["tok"] = t.clone()
-            else:
-                t.copy_(self.box["tok"])
+    from conftest import GOLDEN, ROOT
 
     model, z = load_golden("moe_fp8")
-    whole = HipBackend(model)
-    want = [int(t) for t in generate(whole, model, [int(z["tokens"][0])], 12)[0]]
-    whole.close()
-    link = Loopback()
-    stages = []
-    for r in range(2):
-        sm, flags = stage_model(model, r, 2)
-        link.rank = r
-        stages.append(PipelineStage(HipBackend(sm), sm.config.dim, flags, link, "cuda"))
-    try:
-        tok, got = int(z["tokens"][0]), []
-        for pos in range(12):
-            link.rank = 0
-            assert stages[0].step(tok, pos) is None
-            link.rank = 1
-            logits = stages[1].step(tok, pos)
-            tok = int(np.argmax(logits))
-            got.append(tok)
-        assert got == want
-    finally:
-        for st in stages:
-            st.b.close()
+    env = dict(os.environ, CALM_ROOT=ROOT, CALM_MODEL=os.path.join(GOLDEN, "moe_fp8.calm"), CALM_FIRST=str(int(z["tokens"][0])))
+    r = subprocess.run([sys.executable, "-c", PIPELINE_STAGE_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    if not out["torch_gpu"]:
+        pytest.skip("this box's torch build sees no GPU (torch.cuda.is_available() is False in a fresh process)")
+    assert out["got"] == out["want"]
 
 
 @pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip not built")

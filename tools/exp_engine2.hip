@@ -29,8 +29,19 @@ constexpr unsigned E2_SPIN = 1u << 21;
 struct E2Phase {
 	const void* w;
 	unsigned nslots; // 16 KiB slots of this phase (ntasks / 2)
-	unsigned K;      // slots per workgroup (ceil)
+	unsigned pad;
 };
+// Workgroup b takes slots b, b + grid, b + 2 grid, ... of a phase: at any moment the chip reads ONE moving window of consecutive
+// slots (every memory channel busy), as the launch-per-kernel chain does.  (First cut: a contiguous run of slots per workgroup --
+// 256 streams a fixed stride apart; it never got past 4.8 TB/s with the edges switched off.)
+__device__ __forceinline__ int e2_count(unsigned nslots, unsigned b, unsigned grid) {
+	return nslots > b ? (int)((nslots - b + grid - 1) / grid) : 0;
+}
+// task t of a phase with ntasks tasks writes entry ntasks - 1 - t of the next vector if that is < VEC: the LAST tasks of a phase
+// produce its outputs, so an edge completes when the phase does (as every row of a real matvec phase produces an output)
+__device__ __forceinline__ unsigned e2_out_index(unsigned t, unsigned ntasks) {
+	return ntasks - 1u - t;
+}
 
 typedef __attribute__((address_space(3))) void* e2_lds_t;
 __device__ __forceinline__ unsigned e2_lds_addr(const void* p) {
@@ -65,31 +76,31 @@ constexpr int E2_THIN = 2;   // flags bit 1: thin the loader to one fill in flig
 
 // the loader wave
 template <int R, int D>
-__device__ __forceinline__ void e2_loader(unsigned a_ph, unsigned a_cum, unsigned a_ring, unsigned a_landed, unsigned a_done, unsigned a_sweeping, unsigned a_gaveup, int G, int lane,
+__device__ __forceinline__ void e2_loader(unsigned a_ph, unsigned a_cum, unsigned a_ring, unsigned a_landed, unsigned a_done, unsigned a_sweeping, unsigned a_gaveup, unsigned a_stalls, int G, int lane,
                                           bool thin_on) {
 	int p = -1, p_end = 0, p_begin = 0;
 	const unsigned char* wbase = nullptr;
-	unsigned K = 0;
+	unsigned stalls = 0; // polls of a full ring (diagnostic)
 	for (int g = 0; g < G; ++g) {
 		while (g >= p_end) { // the next phase with slots of this workgroup
 			++p;
 			p_begin = e2_lds_read(a_cum + 4 * p);
 			p_end = e2_lds_read(a_cum + 4 * (p + 1));
 			wbase = (const unsigned char*)e2_lds_read64(a_ph + 16 * p);
-			K = (unsigned)e2_lds_read(a_ph + 16 * p + 12);
 		}
 		if (g >= R) { // the slot's previous tenant (slot g - R, consumer (g - R) % NC, its ((g - R) / NC)-th slot) must be consumed
 			const int c = (g - R) % E2_NC, j = (g - R) / E2_NC;
 			unsigned spins = 0;
 			while (e2_lds_read(a_done + 4 * c) <= j) {
 				__builtin_amdgcn_s_sleep(1);
+				++stalls;
 				if (++spins > E2_SPIN) {
 					e2_lds_write(a_gaveup, 5);
 					return;
 				}
 			}
 		}
-		const unsigned s = blockIdx.x * K + (unsigned)(g - p_begin);
+		const unsigned s = blockIdx.x + gridDim.x * (unsigned)(g - p_begin);
 		const unsigned char* src = wbase + (size_t)s * E2_SLOT + lane * 16;
 		const unsigned slot = a_ring + (unsigned)(g % R) * E2_SLOT;
 #pragma unroll
@@ -118,6 +129,7 @@ __device__ __forceinline__ void e2_loader(unsigned a_ph, unsigned a_cum, unsigne
 	e2_vmcnt<0>();
 	if (lane == 0) {
 		e2_lds_write(a_landed, G);
+		e2_lds_write(a_stalls, (int)stalls);
 	}
 }
 
@@ -140,10 +152,11 @@ struct E2C {
 	const uint2* x1;
 	unsigned tag_base;
 	int nphases, lane, noedge;
+	unsigned long long* stamps;
 };
 
 // -> false when the bounded spin gave up
-__device__ __forceinline__ bool e2_wait_ge(int* what, int target, int* gave_up, int code) {
+__device__ __forceinline__ bool e2_wait_ge(int* what, int target, int* gave_up, int code, unsigned* polls = nullptr) {
 	unsigned spins = 0;
 	while (__hip_atomic_load(what, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
 		__builtin_amdgcn_s_sleep(1);
@@ -151,6 +164,9 @@ __device__ __forceinline__ bool e2_wait_ge(int* what, int target, int* gave_up, 
 			*gave_up = code;
 			return false;
 		}
+	}
+	if (polls) {
+		*polls += spins;
 	}
 	return true;
 }
@@ -160,42 +176,45 @@ __device__ __forceinline__ bool e2_sweep(const E2C& C, int p) {
 	const uint2* xin = (p & 1) ? C.x1 : C.x0;
 	const unsigned nout_prev = p == 0 ? (unsigned)VEC : (2u * C.ph[p - 1].nslots < (unsigned)VEC ? 2u * C.ph[p - 1].nslots : (unsigned)VEC);
 	const int lane = C.lane;
+	const unsigned long long t_begin = C.stamps ? wall_clock64() : 0;
 	__hip_atomic_store(C.sweeping, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-	bool staged_ok = false; // xs may be overwritten only when every consumer has left phase p - 1
-#pragma unroll 1
-	for (int half = 0; half < 2; ++half) { // 2 passes of 32 granules per lane (16 KiB each)
-		unsigned gr[32];     // payloads of the granules that carried the expected tag
-		unsigned need = ~0u; // bit j: granule j of this lane still missing
-		unsigned rounds = 0;
-		do {
-			unsigned long long fresh[32]; // {payload, tag} (agent-scope relaxed 8-byte loads: global_load_dwordx2 sc1)
+	unsigned gr[64];              // payloads of the granules that carried the expected tag
+	unsigned long long need = ~0ull; // bit j: granule j of this lane still missing
+	unsigned rounds = 0;
+	for (;;) {
+		unsigned long long fresh[64]; // {payload, tag} (agent-scope relaxed 8-byte loads: global_load_dwordx2 sc1), missing ones only
 #pragma unroll
-			for (int j = 0; j < 32; ++j) {
-				fresh[j] = __hip_atomic_load((const unsigned long long*)(xin + (half * 32 + j) * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		for (int j = 0; j < 64; ++j) {
+			fresh[j] = 0;
+			if (need >> j & 1ull) {
+				fresh[j] = __hip_atomic_load((const unsigned long long*)(xin + j * 64 + lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			}
-#pragma unroll
-			for (int j = 0; j < 32; ++j) {
-				const int i = (half * 32 + j) * 64 + lane;
-				const bool ok = C.noedge || (unsigned)(fresh[j] >> 32) == e2_expected(i, p, nout_prev, C.tag_base);
-				const bool take = (need >> j & 1u) && ok;
-				gr[j] = take ? (unsigned)fresh[j] : gr[j];
-				need = take ? need & ~(1u << j) : need;
-			}
-			if (++rounds > (1u << 16)) {
-				*C.gave_up = 9;
-				return false;
-			}
-		} while (__builtin_amdgcn_ballot_w64(need != 0) != 0);
-		if (!staged_ok) {
-			if (p > 0 && !e2_wait_ge(&C.leftp[p - 1], E2_NC, C.gave_up, 10)) { // (phase p - 1 is over for every consumer: xs is free)
-				return false;
-			}
-			staged_ok = true;
 		}
 #pragma unroll
-		for (int j = 0; j < 32; ++j) {
-			C.xs[(half * 32 + j) * 64 + lane] = __builtin_bit_cast(float, gr[j]);
+		for (int j = 0; j < 64; ++j) {
+			const int i = j * 64 + lane;
+			const bool ok = C.noedge || (unsigned)(fresh[j] >> 32) == e2_expected(i, p, nout_prev, C.tag_base);
+			const bool take = (need >> j & 1ull) && ok;
+			gr[j] = take ? (unsigned)fresh[j] : gr[j];
+			need = take ? need & ~(1ull << j) : need;
 		}
+		++rounds;
+		if (__builtin_amdgcn_ballot_w64(need != 0) == 0) {
+			break;
+		}
+		if (rounds > (1u << 14)) {
+			*C.gave_up = 9;
+			return false;
+		}
+		__builtin_amdgcn_s_sleep(16); // ~0.4 us between polls: pollers beside a weight stream cost it bandwidth
+	}
+	const unsigned long long t_seen = C.stamps ? wall_clock64() : 0;
+	if (p > 0 && !e2_wait_ge(&C.leftp[p - 1], E2_NC, C.gave_up, 10)) { // (phase p - 1 is over for every consumer: xs is free)
+		return false;
+	}
+#pragma unroll
+	for (int j = 0; j < 64; ++j) {
+		C.xs[j * 64 + lane] = __builtin_bit_cast(float, gr[j]);
 	}
 	__hip_atomic_store(C.sweeping, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // xs is written (a wave's LDS operations complete in order)
@@ -213,6 +232,10 @@ __device__ __forceinline__ bool e2_sweep(const E2C& C, int p) {
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	if (lane == 0) {
 		__hip_atomic_store(C.xready, p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+		if (C.stamps) { // [phase][workgroup][4]: sweep begun, every tag seen, vector staged, polling rounds
+			unsigned long long* o = C.stamps + ((size_t)p * gridDim.x + blockIdx.x) * 4;
+			o[0] = t_begin, o[1] = t_seen, o[2] = wall_clock64(), o[3] = rounds;
+		}
 	}
 	return true;
 }
@@ -231,7 +254,8 @@ __device__ __forceinline__ bool e2_leave_phase(const E2C& C, int p) {
 }
 
 template <int R, int D, int REAL>
-__global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __restrict__ ph_global, int nphases, uint2* x0, uint2* x1, unsigned tag_base, unsigned* timeout, int flags) {
+__global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __restrict__ ph_global, int nphases, uint2* x0, uint2* x1, unsigned tag_base, unsigned* timeout, int flags,
+                                                              unsigned long long* stamps, unsigned* diag) {
 	extern __shared__ __attribute__((aligned(1024))) unsigned char e2_smem[];
 	unsigned char* ring = e2_smem;                          // R x 16 KiB
 	float* xs = (float*)(e2_smem + (size_t)R * E2_SLOT);    // VEC floats: the current phase's input vector
@@ -260,10 +284,7 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 		int c = 0;
 		for (int p = 0; p < nphases; ++p) {
 			cum[p] = c;
-			const long base = (long)blockIdx.x * ph[p].K;
-			long n = (long)ph[p].nslots - base;
-			n = n < 0 ? 0 : (n > (long)ph[p].K ? (long)ph[p].K : n);
-			c += (int)n;
+			c += e2_count(ph[p].nslots, blockIdx.x, gridDim.x);
 		}
 		cum[nphases] = c;
 	}
@@ -271,8 +292,11 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 	const int G = cum[nphases];
 
 	if (wave == 0) {
-		e2_loader<R, D>(e2_lds_addr(ph), e2_lds_addr(cum), e2_lds_addr(ring), e2_lds_addr(landed), e2_lds_addr(done), e2_lds_addr(sweeping), e2_lds_addr(gave_up), G, lane,
+		e2_loader<R, D>(e2_lds_addr(ph), e2_lds_addr(cum), e2_lds_addr(ring), e2_lds_addr(landed), e2_lds_addr(done), e2_lds_addr(sweeping), e2_lds_addr(gave_up), e2_lds_addr(ctl + 9), G, lane,
 		                (flags & E2_THIN) != 0);
+		if (lane == 0 && diag) {
+			diag[blockIdx.x * 8 + 0] = (unsigned)e2_lds_read(e2_lds_addr(ctl + 9)); // polls of a full ring
+		}
 		return;
 	}
 
@@ -281,6 +305,8 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 	E2C C;
 	C.xs = xs, C.ph = ph, C.leftp = leftp, C.xready = xready, C.sweeping = sweeping, C.gave_up = gave_up, C.scale_s = scale_s;
 	C.x0 = x0, C.x1 = x1, C.tag_base = tag_base, C.nphases = nphases, C.lane = lane, C.noedge = flags & E2_NOEDGE;
+	C.stamps = stamps;
+	unsigned waits_landed = 0, waits_vector = 0; // polls spent waiting for the loader / for the phase's vector (diagnostic)
 	bool alive = true;
 	if (c == 0) {
 		alive = e2_sweep(C, 0);
@@ -297,17 +323,18 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 			break;
 		}
 		if (scaled_for != p) {
-			if (!e2_wait_ge(xready, p + 1, gave_up, 7)) {
+			if (!e2_wait_ge(xready, p + 1, gave_up, 7, &waits_vector)) {
 				break;
 			}
 			scale = *scale_s;
 			scaled_for = p;
 		}
-		if (!e2_wait_ge(landed, g + 1, gave_up, 8)) {
+		if (!e2_wait_ge(landed, g + 1, gave_up, 8, &waits_landed)) {
 			break;
 		}
 		const unsigned k = (unsigned)(g - cum[p]);
-		const unsigned s = blockIdx.x * ph[p].K + k; // slot of the phase: tasks 2 s, 2 s + 1
+		const unsigned s = blockIdx.x + gridDim.x * k; // slot of the phase: tasks 2 s, 2 s + 1
+		const unsigned ntasks = 2u * ph[p].nslots;
 		const u32x4* slot = (const u32x4*)(ring + (size_t)(g % R) * E2_SLOT);
 		uint2* xout = (p & 1) ? x0 : x1;
 #pragma unroll
@@ -320,8 +347,9 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 			const unsigned t = 2 * s + h;
 			const float tv = tile_value<REAL>(tile, xs, lane);
 			const float v = wave_sum(tv) * scale * xs[(t * 7) % VEC];
-			if (lane == 0 && t < (unsigned)VEC) {
-				e2_publish(xout + t, v + (float)(t % 13), tag_base + 4u + (unsigned)p);
+			const unsigned oi = e2_out_index(t, ntasks);
+			if (lane == 0 && oi < (unsigned)VEC) {
+				e2_publish(xout + oi, v + (float)(t % 13), tag_base + 4u + (unsigned)p);
 			}
 		}
 		if (lane == 0) {
@@ -334,6 +362,10 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 	}
 	if (lane == 0 && *gave_up) {
 		*timeout = (unsigned)*gave_up;
+	}
+	if (lane == 0 && diag) {
+		diag[blockIdx.x * 8 + 1 + c] = waits_landed;
+		diag[blockIdx.x * 8 + 4 + c] = waits_vector;
 	}
 }
 
@@ -368,9 +400,10 @@ __global__ __launch_bounds__(BLOCK) void k_ref_phase(const void* w, unsigned nta
 		}
 		const float tv = tile_value<REAL>(tile, xs, lane);
 		const float v = wave_sum(tv) * scale * xs[(t * 7) % VEC];
-		if (lane == 0 && t < (unsigned)VEC) {
+		const unsigned oi = e2_out_index(t, ntasks);
+		if (lane == 0 && oi < (unsigned)VEC) {
 			const uint2 d = {__builtin_bit_cast(unsigned, v + (float)(t % 13)), tag};
-			xout[t] = d;
+			xout[oi] = d;
 		}
 	}
 }
@@ -389,6 +422,8 @@ struct E2Setup {
 	E2Phase* dp = nullptr;
 	uint2* x[2] = {nullptr, nullptr};
 	unsigned* timeout = nullptr;
+	unsigned long long* stamps = nullptr; // [phase][256][4]
+	unsigned* diag = nullptr;             // [256][8]
 	hipStream_t s = nullptr;
 	int total = 0;
 };
@@ -405,7 +440,7 @@ static void e2_setup(E2Setup& S, int n_layers) {
 		CK(hipMemset(S.w[i], 0x11 + i / 4 + i % 4, e2_sizes[i % 4] + 65536));
 		S.hp[i].w = S.w[i];
 		S.hp[i].nslots = (unsigned)(e2_sizes[i % 4] / E2_SLOT);
-		S.hp[i].K = (S.hp[i].nslots + 255) / 256;
+		S.hp[i].pad = 0;
 	}
 	CK(hipMalloc(&S.dp, sizeof(E2Phase) * S.total));
 	CK(hipMemcpy(S.dp, S.hp.data(), sizeof(E2Phase) * S.total, hipMemcpyHostToDevice));
@@ -413,6 +448,10 @@ static void e2_setup(E2Setup& S, int n_layers) {
 	CK(hipMalloc(&S.x[1], VEC * 8 + 65536));
 	CK(hipMalloc(&S.timeout, 4));
 	CK(hipMemset(S.timeout, 0, 4));
+	CK(hipMalloc(&S.stamps, (size_t)S.total * 256 * 4 * 8));
+	CK(hipMemset(S.stamps, 0, (size_t)S.total * 256 * 4 * 8));
+	CK(hipMalloc(&S.diag, 256 * 8 * 4));
+	CK(hipMemset(S.diag, 0, 256 * 8 * 4));
 }
 static void e2_teardown(E2Setup& S) {
 	for (void* p : S.w) {
@@ -422,6 +461,8 @@ static void e2_teardown(E2Setup& S) {
 	CK(hipFree(S.x[0]));
 	CK(hipFree(S.x[1]));
 	CK(hipFree(S.timeout));
+	CK(hipFree(S.stamps));
+	CK(hipFree(S.diag));
 	CK(hipStreamDestroy(S.s));
 }
 static double e2_checksum(E2Setup& S, std::vector<float>* keep) {
@@ -443,6 +484,7 @@ static double e2_checksum(E2Setup& S, std::vector<float>* keep) {
 }
 
 static int g_e2_flags = E2_THIN;
+static int g_e2_report = 0; // 1: the kernel stamps every sweep and counts its polls; e2_run prints a digest of the last launch
 static std::vector<float> g_e2_ref; // final vector of the launch-per-phase chain (the checker)
 
 // launch-per-phase over the granule buffers: us/layer (plain launches on one stream), fills g_e2_ref
@@ -496,7 +538,8 @@ static double e2_run(int n_layers, int iters, double* checksum, int* mismatches)
 	unsigned tag_base = 1u << 12;
 	auto run = [&]() {
 		hipLaunchKernelGGL(k_e2_init, dim3((VEC + 255) / 256), dim3(256), 0, S.s, S.x[0], S.x[1], tag_base);
-		hipLaunchKernelGGL(kern, dim3(256), dim3((E2_NC + 1) * 64), lds, S.s, (const E2Phase*)S.dp, S.total, S.x[0], S.x[1], tag_base, S.timeout, g_e2_flags);
+		hipLaunchKernelGGL(kern, dim3(256), dim3((E2_NC + 1) * 64), lds, S.s, (const E2Phase*)S.dp, S.total, S.x[0], S.x[1], tag_base, S.timeout, g_e2_flags,
+		                   g_e2_report ? S.stamps : (unsigned long long*)nullptr, g_e2_report ? S.diag : (unsigned*)nullptr);
 		tag_base += 1u << 12;
 	};
 	run();
@@ -536,13 +579,51 @@ static double e2_run(int n_layers, int iters, double* checksum, int* mismatches)
 		bad = -1;
 	}
 	*mismatches = bad;
+	if (g_e2_report) {
+		// digest of the LAST launch: per phase kind (qkv / wo / ffn_up / ffn_down inputs), over layers >= 1 and all workgroups:
+		// how long a sweep polls before every tag is there, and how long it then takes to stage the vector; who waits for whom
+		std::vector<unsigned long long> st((size_t)S.total * 256 * 4);
+		std::vector<unsigned> dg(256 * 8);
+		CK(hipMemcpy(st.data(), S.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(dg.data(), S.diag, dg.size() * 4, hipMemcpyDeviceToHost));
+		static const char* kind[4] = {"qkv", "wo", "ffn_up", "ffn_down"};
+		for (int k = 0; k < 4; ++k) {
+			double poll = 0, stage = 0, rounds = 0, span = 0;
+			int n = 0;
+			for (int p = 4 + k; p < S.total; p += 4) {
+				unsigned long long first_begin = ~0ull, last_ready = 0;
+				for (int b = 0; b < 256; ++b) {
+					const unsigned long long* o = &st[((size_t)p * 256 + b) * 4];
+					if (!o[2]) {
+						continue;
+					}
+					poll += (double)(o[1] - o[0]) * 0.01, stage += (double)(o[2] - o[1]) * 0.01, rounds += (double)o[3];
+					first_begin = o[0] < first_begin ? o[0] : first_begin, last_ready = o[2] > last_ready ? o[2] : last_ready;
+					++n;
+				}
+				span += (double)(last_ready - first_begin) * 0.01;
+			}
+			if (n) {
+				printf("    edge into %-8s: sweep polls %5.2f us (%4.1f rounds), then stages in %5.2f us; first sweep begun -> last vector staged %5.2f us\n", kind[k], poll / n,
+				       rounds / n, stage / n, span / (S.total / 4 - 1));
+			}
+		}
+		double full = 0, wl = 0, wv = 0;
+		for (int b = 0; b < 256; ++b) {
+			full += dg[b * 8];
+			wl += dg[b * 8 + 1] + dg[b * 8 + 2] + dg[b * 8 + 3];
+			wv += dg[b * 8 + 4] + dg[b * 8 + 5] + dg[b * 8 + 6];
+		}
+		printf("    polls per workgroup over the launch: loader on a full ring %.0f, consumers on the loader %.0f, consumers on the vector %.0f\n", full / 256, wl / 256, wv / 256);
+	}
 	fflush(stdout);
 	e2_teardown(S);
 	return us;
 }
 
-extern "C" void exp_engine2_knobs(int noedge, int thin) {
+extern "C" void exp_engine2_knobs(int noedge, int thin, int report) {
 	g_e2_flags = (noedge ? E2_NOEDGE : 0) | (thin ? E2_THIN : 0);
+	g_e2_report = report;
 }
 
 // config = R * 10 + D
