@@ -447,6 +447,53 @@ def test_reference_cli_perplexity_mode_on_the_hip_backend():
     assert abs(g[0] - w[0]) <= 5e-4 * w[0] and abs(g[1] - w[1]) <= 5e-3 * max(w[1], 1.0), (got, want)
 
 
+@pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip not built")
+def test_perplexity_of_the_reference_text_at_mistral_width(hiplib, tmp_path):
+    """SURVEY.md section 8 f3 at a BASELINE width: `run -x tools/pplx.txt` -- the reference's own perplexity text (stored here as
+    the byte values the toy tokenizer maps to token ids, tests/golden/pplx_bytes.npz) -- over a 4-layer Mistral-7B-width fp8 model
+    (dim 4096, hidden 14336, 32000-token classifier; rebuilt from its seed), 35161 tokens, positions wrapping every 1024:
+      (i)  through the UNMODIFIED reference CLI on the HIP backend (oracle/_ref/run_hip): its "# perplexity:" line against the line
+           the reference's CPU backend printed (tests/golden/make_pplx_golden.py, 16 minutes of CPU), within 5e-4;
+      (ii) the same tokens through prefill_logprobs_hip (host.perplexity: the arithmetic of study(), src/run.c:286-308, on top of
+           the batched scorer): the same perplexity within 1e-3."""
+    import re
+    import subprocess
+
+    from conftest import GOLDEN
+    from calm_amd.host import perplexity
+
+    want_lines = open(os.path.join(GOLDEN, "cli_mistral4_pplx_perplexity.txt")).read().splitlines()
+    w = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", want_lines[1])[:2]]
+    n_tokens = int(want_lines[0].split()[0])
+    text = np.load(os.path.join(GOLDEN, "pplx_bytes.npz"))["bytes"].tobytes()
+    txt = tmp_path / "pplx.txt"
+    txt.write_bytes(text)
+    model_path = str(tmp_path / "mistral4.calm")
+    cf.write_synth_big(model_path, cf.SPECS["mistral-7b"], "fp8", 5, 4)  # (seed and depth of the golden: make_pplx_golden.py)
+    env = dict(os.environ)
+    env.pop("CALM_CPU", None)
+    r = subprocess.run([oracle.RUN_HIP, model_path, "-x", str(txt), "-n", "1024"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f"{n_tokens} tokens" in r.stdout  # the reference tokenizer sees the same text
+    got = [l for l in r.stdout.splitlines() if l.startswith("# perplexity:")][0]
+    g = [float(x) for x in re.findall(r"[0-9]+\.[0-9]+", got)[:2]]
+    assert abs(g[0] - w[0]) <= 5e-4 * w[0] and abs(g[1] - w[1]) <= 5e-3 * max(w[1], 1.0), (got, want_lines[1])
+    # (ii) the toy tokenizer (calmfile._toy_tokenizer) through src/tokenizer.c:203-260: a printable ASCII character other than
+    # backslash and double quote is its own token id; everything else is not in the vocabulary, there are no byte-fallback
+    # tokens, and no two tokens concatenate to a third: dropped
+    tokens = [b for b in text if 32 <= b < 127 and b not in (0x5C, 0x22)]
+    assert len(tokens) == n_tokens
+    model = HostModel.from_file(model_path)
+    b = HipBackend(model)
+    try:
+        ppl, err = perplexity(b, tokens, 1024)
+    finally:
+        b.close()
+    print(f"perplexity of the reference text, 4-layer Mistral-7B width: reference CPU {w[0]:.3f} +- {w[1]:.3f}; reference CLI on HIP {g[0]:.3f} +- {g[1]:.3f}; "
+          f"prefill_logprobs_hip {ppl:.3f} +- {err:.3f}")
+    assert abs(ppl - w[0]) <= 1e-3 * w[0] and abs(err - w[1]) <= 1e-2 * max(w[1], 1.0), (ppl, err, w)
+
+
 # ---------------------------------------------------------------- batched prompt ingestion ------
 
 def _kv_floats(hiplib, b, kvbits):

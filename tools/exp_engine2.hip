@@ -641,3 +641,122 @@ extern "C" double exp_engine2(int config, int real, int n_layers, int iters, dou
 	fprintf(stderr, "exp_engine2: config %d not built\n", config);
 	return -1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Loader study: how fast can LDS-DMA alone stream a layer's weights, with NL loader waves per workgroup (one workgroup per CU),
+// D fills of 16 KiB in flight per wave, slots assigned in contiguous runs of RUN slots per workgroup (RUN = 0: one contiguous
+// block per workgroup; RUN = 1: fully interleaved), non-temporal or default cache policy?  Nobody consumes: a slot is free again as
+// soon as it has landed.  (The engine cannot beat its loader.)
+template <int NL, int D, int NT>
+__global__ __launch_bounds__(NL * 64) void k_loader_only(const E2Phase* __restrict__ ph, int nphases, int run, unsigned* sink) {
+	extern __shared__ __attribute__((aligned(1024))) unsigned char e2_smem[];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const unsigned a_ring = e2_lds_addr(e2_smem) + (unsigned)wave * (unsigned)(D * E2_SLOT); // each wave fills its own D slots
+	unsigned n = 0;
+	for (int p = 0; p < nphases; ++p) {
+		const unsigned char* wbase = (const unsigned char*)ph[p].w;
+		const unsigned nslots = ph[p].nslots, per = (nslots + gridDim.x - 1) / gridDim.x; // slots per workgroup
+		for (unsigned k = wave; k < per; k += NL, ++n) {
+			// k-th slot of this workgroup in the phase
+			unsigned s;
+			if (run <= 0) {
+				s = blockIdx.x * per + k;
+			} else {
+				s = ((k / run) * gridDim.x + blockIdx.x) * run + k % run;
+			}
+			if (s >= nslots) {
+				continue;
+			}
+			const unsigned char* src = wbase + (size_t)s * E2_SLOT + lane * 16;
+			const unsigned slot = a_ring + (n % D) * E2_SLOT;
+#pragma unroll
+			for (int q = 0; q < 4; ++q) {
+				const __attribute__((address_space(1))) void* gp = (const __attribute__((address_space(1))) void*)(src + q * 4096);
+				const e2_lds_t lp = (e2_lds_t)(size_t)(slot + q * 4096);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 0, NT ? 2 : 0);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, NT ? 2 : 0);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, NT ? 2 : 0);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, NT ? 2 : 0);
+			}
+			if (D == 1) {
+				e2_vmcnt<0>();
+			} else {
+				e2_vmcnt<16 * (D - 1) < 63 ? 16 * (D - 1) : 63>();
+			}
+		}
+	}
+	e2_vmcnt<0>();
+	if (sink && e2_lds_read(a_ring + lane * 4) == 0x9e3779b9) {
+		*sink = 1;
+	}
+}
+
+// the same stream through registers (global_load_dwordx4 nt, W waves per workgroup, 16 KiB in flight per wave, nothing kept)
+template <int W>
+__global__ __launch_bounds__(W * 64) void k_reg_stream(const E2Phase* __restrict__ ph, int nphases, unsigned* sink) {
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	unsigned acc = 0;
+	for (int p = 0; p < nphases; ++p) {
+		const gptr16 w = (gptr16)ph[p].w;
+		const unsigned nslots = ph[p].nslots;
+		for (unsigned s = blockIdx.x * W + wave; s < nslots; s += gridDim.x * W) {
+			u32x4 t[16];
+#pragma unroll
+			for (int u = 0; u < 16; ++u) {
+				t[u] = __builtin_nontemporal_load(w + (size_t)s * 1024 + u * 64 + lane);
+			}
+#pragma unroll
+			for (int u = 0; u < 16; ++u) {
+				acc += t[u][0] ^ t[u][3];
+			}
+		}
+	}
+	if (acc == 0x9e3779b9u) {
+		*sink = acc;
+	}
+}
+
+// config = NL * 100 + D * 10 + NT;  run: slots per contiguous run (0 = one block per workgroup); NL = 9: the register stream (8 waves)
+extern "C" double exp_loader_only(int config, int run, int n_layers, int iters) {
+	E2Setup S;
+	e2_setup(S, n_layers);
+	auto go = [&](auto kern, int threads, size_t lds, bool has_run) {
+		if (lds > 48 * 1024) {
+			CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+		}
+		(void)has_run;
+		hipLaunchKernelGGL(kern, dim3(256), dim3(threads), lds, S.s, (const E2Phase*)S.dp, S.total, run, S.timeout);
+	};
+	auto timed = [&](auto launch) {
+		launch();
+		CK(hipGetLastError());
+		CK(hipDeviceSynchronize());
+		hipEvent_t e0, e1;
+		CK(hipEventCreate(&e0));
+		CK(hipEventCreate(&e1));
+		CK(hipEventRecord(e0, S.s));
+		for (int i = 0; i < iters; ++i) {
+			launch();
+		}
+		CK(hipEventRecord(e1, S.s));
+		CK(hipDeviceSynchronize());
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, e0, e1));
+		return (double)ms * 1e3 / ((double)iters * n_layers);
+	};
+	double us = -1;
+#define LO(nl, d, nt)                                                                                                     \
+	if (config == nl * 100 + d * 10 + nt) {                                                                               \
+		us = timed([&]() { go(k_loader_only<nl, d, nt>, nl * 64, (size_t)nl * d * E2_SLOT, true); });                      \
+	}
+	LO(1, 2, 1) LO(1, 3, 1) LO(1, 4, 1) LO(1, 3, 0) LO(2, 2, 1) LO(2, 3, 1) LO(2, 4, 1) LO(4, 2, 1) LO(4, 1, 1) LO(2, 3, 0) LO(3, 3, 1)
+#undef LO
+	if (config == 900) {
+		us = timed([&]() { hipLaunchKernelGGL(k_reg_stream<8>, dim3(256), dim3(512), 0, S.s, (const E2Phase*)S.dp, S.total, S.timeout); });
+	}
+	if (config == 901) {
+		us = timed([&]() { hipLaunchKernelGGL(k_reg_stream<4>, dim3(512), dim3(256), 0, S.s, (const E2Phase*)S.dp, S.total, S.timeout); });
+	}
+	e2_teardown(S);
+	return us;
+}
