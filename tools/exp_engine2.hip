@@ -73,62 +73,85 @@ __device__ __forceinline__ void e2_publish(uint2* g, float v, unsigned tag) { //
 
 constexpr int E2_NOEDGE = 1; // flags bit 0: tags are not checked (diagnostic: wrong results; the in-phase rate only)
 constexpr int E2_THIN = 2;   // flags bit 1: thin the loader to one fill in flight while the workgroup sweeps
+constexpr int E2_TREE = 4;   // flags bit 2: two-level gather -- workgroup g < 8 sweeps the producers' granules for group g (the workgroups
+                             // b with b % 8 == g: one XCD, as blocks are observed to be placed) and re-publishes the vector into the
+                             // group's staging buffer, which the other 31 sweep: 8 readers of the hot 32 KiB instead of 256, and 31
+                             // readers each of a copy their own L2 holds
 
-// the loader wave
+// the loader wave.  Two cursors: `issued` fills handed to the DMA, `published` fills whose landing the consumers have been told
+// about.  A fill is issued whenever its ring slot is free and fewer than D are in flight; otherwise the loader waits for its
+// OLDEST fill in flight (counted vmcnt) and publishes it.  (First form: a landing was only published on the way to the next issue,
+// so a loader held up by a full ring also held back the last D - 1 landed fills from the consumers it was waiting for.)
 template <int R, int D>
 __device__ __forceinline__ void e2_loader(unsigned a_ph, unsigned a_cum, unsigned a_ring, unsigned a_landed, unsigned a_done, unsigned a_sweeping, unsigned a_gaveup, unsigned a_stalls, int G, int lane,
                                           bool thin_on) {
+	static_assert(D >= 1 && D <= 4, "vmcnt holds 63: at most 3 older fills of 16 pieces behind the newest");
 	int p = -1, p_end = 0, p_begin = 0;
 	const unsigned char* wbase = nullptr;
 	unsigned stalls = 0; // polls of a full ring (diagnostic)
-	for (int g = 0; g < G; ++g) {
-		while (g >= p_end) { // the next phase with slots of this workgroup
-			++p;
-			p_begin = e2_lds_read(a_cum + 4 * p);
-			p_end = e2_lds_read(a_cum + 4 * (p + 1));
-			wbase = (const unsigned char*)e2_lds_read64(a_ph + 16 * p);
+	int issued = 0, published = 0;
+	unsigned spins = 0;
+	while (published < G) {
+		bool can_issue = issued < G && issued - published < D;
+		if (can_issue && thin_on && issued - published >= 1 && e2_lds_read(a_sweeping) != 0) {
+			can_issue = false; // one fill in flight only while this CU sweeps granules
 		}
-		if (g >= R) { // the slot's previous tenant (slot g - R, consumer (g - R) % NC, its ((g - R) / NC)-th slot) must be consumed
-			const int c = (g - R) % E2_NC, j = (g - R) / E2_NC;
-			unsigned spins = 0;
-			while (e2_lds_read(a_done + 4 * c) <= j) {
-				__builtin_amdgcn_s_sleep(1);
+		if (can_issue && issued >= R) { // the slot's previous tenant (fill issued - R, consumer (issued - R) % NC, its ((issued - R) / NC)-th) must be consumed
+			const int c = (issued - R) % E2_NC, j = (issued - R) / E2_NC;
+			if (e2_lds_read(a_done + 4 * c) <= j) {
+				can_issue = false;
 				++stalls;
-				if (++spins > E2_SPIN) {
-					e2_lds_write(a_gaveup, 5);
-					return;
+				if (issued == published) { // nothing in flight to wait for: poll
+					__builtin_amdgcn_s_sleep(1);
+					if (++spins > E2_SPIN) {
+						e2_lds_write(a_gaveup, 5);
+						return;
+					}
+					continue;
 				}
 			}
 		}
-		const unsigned s = blockIdx.x + gridDim.x * (unsigned)(g - p_begin);
-		const unsigned char* src = wbase + (size_t)s * E2_SLOT + lane * 16;
-		const unsigned slot = a_ring + (unsigned)(g % R) * E2_SLOT;
+		if (can_issue) {
+			const int g = issued;
+			while (g >= p_end) { // the next phase with slots of this workgroup
+				++p;
+				p_begin = e2_lds_read(a_cum + 4 * p);
+				p_end = e2_lds_read(a_cum + 4 * (p + 1));
+				wbase = (const unsigned char*)e2_lds_read64(a_ph + 16 * p);
+			}
+			const unsigned s = blockIdx.x + gridDim.x * (unsigned)(g - p_begin);
+			const unsigned char* src = wbase + (size_t)s * E2_SLOT + lane * 16;
+			const unsigned slot = a_ring + (unsigned)(g % R) * E2_SLOT;
 #pragma unroll
-		for (int q = 0; q < 4; ++q) { // four pieces per M0 value: the instruction offset moves the global AND the LDS address
-			const __attribute__((address_space(1))) void* gp = (const __attribute__((address_space(1))) void*)(src + q * 4096);
-			const e2_lds_t lp = (e2_lds_t)(size_t)(slot + q * 4096);
-			__builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
-			__builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
-			__builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 2);
-			__builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 2);
+			for (int q = 0; q < 4; ++q) { // four pieces per M0 value: the instruction offset moves the global AND the LDS address
+				const __attribute__((address_space(1))) void* gp = (const __attribute__((address_space(1))) void*)(src + q * 4096);
+				const e2_lds_t lp = (e2_lds_t)(size_t)(slot + q * 4096);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 2 /* nt */);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 2);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 2);
+				__builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 2);
+			}
+			++issued;
+			spins = 0;
+			continue;
 		}
-		// all but the latest D - 1 fills have landed; one fill in flight only while this CU sweeps granules
-		const bool thin = thin_on && e2_lds_read(a_sweeping) != 0;
-		if (thin || D == 1) {
+		// wait for the oldest fill in flight: issued - published of them are, each 16 DMA pieces
+		const int inflight = issued - published;
+		if (inflight >= 4) {
+			e2_vmcnt<48>();
+		} else if (inflight == 3) {
+			e2_vmcnt<32>();
+		} else if (inflight == 2) {
+			e2_vmcnt<16>();
+		} else {
 			e2_vmcnt<0>();
-			if (lane == 0) {
-				e2_lds_write(a_landed, g + 1);
-			}
-		} else if (g + 1 >= D) {
-			e2_vmcnt<16 * (D - 1)>();
-			if (lane == 0) {
-				e2_lds_write(a_landed, g + 2 - D);
-			}
+		}
+		++published;
+		if (lane == 0) {
+			e2_lds_write(a_landed, published);
 		}
 	}
-	e2_vmcnt<0>();
 	if (lane == 0) {
-		e2_lds_write(a_landed, G);
 		e2_lds_write(a_stalls, (int)stalls);
 	}
 }
@@ -153,6 +176,7 @@ struct E2C {
 	unsigned tag_base;
 	int nphases, lane, noedge;
 	unsigned long long* stamps;
+	uint2* stage; // [8 groups][2][VEC] granules, or nullptr: flat gather
 };
 
 // -> false when the bounded spin gave up
@@ -174,9 +198,18 @@ __device__ __forceinline__ bool e2_wait_ge(int* what, int target, int* gave_up, 
 // sweep the granule vector that feeds phase p into xs (this wave alone), then the sum of squares in k_stream's order
 __device__ __forceinline__ bool e2_sweep(const E2C& C, int p) {
 	const uint2* xin = (p & 1) ? C.x1 : C.x0;
-	const unsigned nout_prev = p == 0 ? (unsigned)VEC : (2u * C.ph[p - 1].nslots < (unsigned)VEC ? 2u * C.ph[p - 1].nslots : (unsigned)VEC);
+	unsigned nout_prev = p == 0 ? (unsigned)VEC : (2u * C.ph[p - 1].nslots < (unsigned)VEC ? 2u * C.ph[p - 1].nslots : (unsigned)VEC);
 	const int lane = C.lane;
 	const unsigned long long t_begin = C.stamps ? wall_clock64() : 0;
+	// two-level gather: followers read their group's staging copy, every entry of which carries the staging tag of phase p
+	const bool tree = C.stage != nullptr, leader = tree && blockIdx.x < 8;
+	uint2* const stage = tree ? C.stage + ((size_t)(blockIdx.x % 8) * 2 + (p & 1)) * VEC : nullptr;
+	unsigned tag_base = C.tag_base;
+	if (tree && !leader) {
+		xin = stage;
+		nout_prev = (unsigned)VEC;
+		tag_base = C.tag_base + 0x800u + 1u; // e2_expected(i < VEC, p) = tag_base + 4 + p - 1  ==  C.tag_base + 0x800 + 4 + p
+	}
 	__hip_atomic_store(C.sweeping, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 	unsigned gr[64];              // payloads of the granules that carried the expected tag
 	unsigned long long need = ~0ull; // bit j: granule j of this lane still missing
@@ -193,7 +226,7 @@ __device__ __forceinline__ bool e2_sweep(const E2C& C, int p) {
 #pragma unroll
 		for (int j = 0; j < 64; ++j) {
 			const int i = j * 64 + lane;
-			const bool ok = C.noedge || (unsigned)(fresh[j] >> 32) == e2_expected(i, p, nout_prev, C.tag_base);
+			const bool ok = C.noedge || (unsigned)(fresh[j] >> 32) == e2_expected(i, p, nout_prev, tag_base);
 			const bool take = (need >> j & 1ull) && ok;
 			gr[j] = take ? (unsigned)fresh[j] : gr[j];
 			need = take ? need & ~(1ull << j) : need;
@@ -207,6 +240,13 @@ __device__ __forceinline__ bool e2_sweep(const E2C& C, int p) {
 			return false;
 		}
 		__builtin_amdgcn_s_sleep(16); // ~0.4 us between polls: pollers beside a weight stream cost it bandwidth
+	}
+	if (leader) { // the group's copy: the same payloads under the staging tag (write-through, never waited for)
+#pragma unroll
+		for (int j = 0; j < 64; ++j) {
+			__hip_atomic_store((unsigned long long*)(stage + j * 64 + lane), (unsigned long long)gr[j] | ((unsigned long long)(C.tag_base + 0x800u + 4u + (unsigned)p) << 32),
+			                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 	}
 	const unsigned long long t_seen = C.stamps ? wall_clock64() : 0;
 	if (p > 0 && !e2_wait_ge(&C.leftp[p - 1], E2_NC, C.gave_up, 10)) { // (phase p - 1 is over for every consumer: xs is free)
@@ -255,7 +295,7 @@ __device__ __forceinline__ bool e2_leave_phase(const E2C& C, int p) {
 
 template <int R, int D, int REAL>
 __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __restrict__ ph_global, int nphases, uint2* x0, uint2* x1, unsigned tag_base, unsigned* timeout, int flags,
-                                                              unsigned long long* stamps, unsigned* diag) {
+                                                              unsigned long long* stamps, unsigned* diag, uint2* stage) {
 	extern __shared__ __attribute__((aligned(1024))) unsigned char e2_smem[];
 	unsigned char* ring = e2_smem;                          // R x 16 KiB
 	float* xs = (float*)(e2_smem + (size_t)R * E2_SLOT);    // VEC floats: the current phase's input vector
@@ -306,6 +346,7 @@ __global__ __launch_bounds__((E2_NC + 1) * 64) void k_engine2(const E2Phase* __r
 	C.xs = xs, C.ph = ph, C.leftp = leftp, C.xready = xready, C.sweeping = sweeping, C.gave_up = gave_up, C.scale_s = scale_s;
 	C.x0 = x0, C.x1 = x1, C.tag_base = tag_base, C.nphases = nphases, C.lane = lane, C.noedge = flags & E2_NOEDGE;
 	C.stamps = stamps;
+	C.stage = (flags & E2_TREE) ? stage : nullptr;
 	unsigned waits_landed = 0, waits_vector = 0; // polls spent waiting for the loader / for the phase's vector (diagnostic)
 	bool alive = true;
 	if (c == 0) {
@@ -424,6 +465,7 @@ struct E2Setup {
 	unsigned* timeout = nullptr;
 	unsigned long long* stamps = nullptr; // [phase][256][4]
 	unsigned* diag = nullptr;             // [256][8]
+	uint2* stage = nullptr;               // [8][2][VEC]
 	hipStream_t s = nullptr;
 	int total = 0;
 };
@@ -452,6 +494,8 @@ static void e2_setup(E2Setup& S, int n_layers) {
 	CK(hipMemset(S.stamps, 0, (size_t)S.total * 256 * 4 * 8));
 	CK(hipMalloc(&S.diag, 256 * 8 * 4));
 	CK(hipMemset(S.diag, 0, 256 * 8 * 4));
+	CK(hipMalloc(&S.stage, (size_t)8 * 2 * VEC * 8 + 65536));
+	CK(hipMemset(S.stage, 0, (size_t)8 * 2 * VEC * 8));
 }
 static void e2_teardown(E2Setup& S) {
 	for (void* p : S.w) {
@@ -463,6 +507,7 @@ static void e2_teardown(E2Setup& S) {
 	CK(hipFree(S.timeout));
 	CK(hipFree(S.stamps));
 	CK(hipFree(S.diag));
+	CK(hipFree(S.stage));
 	CK(hipStreamDestroy(S.s));
 }
 static double e2_checksum(E2Setup& S, std::vector<float>* keep) {
@@ -539,7 +584,7 @@ static double e2_run(int n_layers, int iters, double* checksum, int* mismatches)
 	auto run = [&]() {
 		hipLaunchKernelGGL(k_e2_init, dim3((VEC + 255) / 256), dim3(256), 0, S.s, S.x[0], S.x[1], tag_base);
 		hipLaunchKernelGGL(kern, dim3(256), dim3((E2_NC + 1) * 64), lds, S.s, (const E2Phase*)S.dp, S.total, S.x[0], S.x[1], tag_base, S.timeout, g_e2_flags,
-		                   g_e2_report ? S.stamps : (unsigned long long*)nullptr, g_e2_report ? S.diag : (unsigned*)nullptr);
+		                   g_e2_report ? S.stamps : (unsigned long long*)nullptr, g_e2_report ? S.diag : (unsigned*)nullptr, S.stage);
 		tag_base += 1u << 12;
 	};
 	run();
@@ -621,8 +666,8 @@ static double e2_run(int n_layers, int iters, double* checksum, int* mismatches)
 	return us;
 }
 
-extern "C" void exp_engine2_knobs(int noedge, int thin, int report) {
-	g_e2_flags = (noedge ? E2_NOEDGE : 0) | (thin ? E2_THIN : 0);
+extern "C" void exp_engine2_knobs(int noedge, int thin, int report, int tree) {
+	g_e2_flags = (noedge ? E2_NOEDGE : 0) | (thin ? E2_THIN : 0) | (tree ? E2_TREE : 0);
 	g_e2_report = report;
 }
 

@@ -23,9 +23,9 @@ lib.exp_engine2_ref.restype = C.c_double
 lib.exp_engine2_ref.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]
 lib.exp_engine2.restype = C.c_double
 lib.exp_engine2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
-lib.exp_engine2_knobs.argtypes = [C.c_int, C.c_int, C.c_int]
+lib.exp_engine2_knobs.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
 L = 8
-cfgs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [83, 84, 82, 63, 42]
+cfgs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [83, 84, 82]
 for real in (0, 1):
     what = "fp8 loop" if real else "touch   "
     lib.exp_set_real(real)
@@ -34,13 +34,12 @@ for real in (0, 1):
     print(f"[{what}] launch per kernel (exp_chain, graph)                : {us:8.2f} us/layer ({218.1/us:5.2f} TB/s)", flush=True)
     us = lib.exp_engine2_ref(real, L, 10, C.byref(cs))
     print(f"[{what}] launch per phase over the granule buffers (checker) : {us:8.2f} us/layer   checksum {cs.value:.6f}", flush=True)
-    for noedge in ((0, 1) if "noedge" in sys.argv else (0,)):
-        for thin in (1, 0):
-            lib.exp_engine2_knobs(noedge, thin, 0 if noedge else 1)
-            for cfg in cfgs:
-                cs, bad = C.c_double(0), C.c_int(0)
-                us = lib.exp_engine2(cfg, real, L, 10, C.byref(cs), C.byref(bad))
-                tagl = "NO EDGES (diagnostic, wrong results)" if noedge else f"values differing from the checker: {bad.value}"
-                print(f"[{what}] engine ring {cfg // 10} x 16 KiB, {cfg % 10} fills in flight, thinning {'on ' if thin else 'off'}: {us:8.2f} us/layer "
-                      f"({218.1/us if us > 0 else 0:5.2f} TB/s)   checksum {cs.value:.6f}   {tagl}", flush=True)
-lib.exp_engine2_knobs(0, 1, 0)
+    for noedge, thin, tree in ((0, 1, 0), (0, 1, 1), (0, 0, 1)) + (((1, 1, 0),) if "noedge" in sys.argv else ()):
+        lib.exp_engine2_knobs(noedge, thin, 0 if noedge else 1, tree)
+        for cfg in cfgs:
+            cs, bad = C.c_double(0), C.c_int(0)
+            us = lib.exp_engine2(cfg, real, L, 10, C.byref(cs), C.byref(bad))
+            tagl = "NO EDGES (diagnostic, wrong results)" if noedge else f"values differing from the checker: {bad.value}"
+            print(f"[{what}] engine ring {cfg // 10} x 16 KiB, {cfg % 10} fills in flight, thinning {'on ' if thin else 'off'}, {'two-level' if tree else 'flat     '} gather: "
+                  f"{us:8.2f} us/layer ({218.1/us if us > 0 else 0:5.2f} TB/s)   {tagl}", flush=True)
+lib.exp_engine2_knobs(0, 1, 0, 0)
