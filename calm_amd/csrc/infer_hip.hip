@@ -46,7 +46,7 @@ using namespace calm;
 namespace {
 
 constexpr int LDS_EXTRA = 1024; // reduction scratch + MoE routing scratch behind the activation image
-constexpr int MAX_SPLIT = 64;
+constexpr int MAX_SPLIT = ATTN_MAX_SPLIT; // (k_attn_merge holds one partial per split in registers)
 
 hipStream_t g_stream; // the CURRENT device's decode stream (multi-device: switched by use_dev)
 int g_device = -1;
@@ -79,6 +79,7 @@ int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
+int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
@@ -194,6 +195,7 @@ struct Ctx {
 	TokState* ts = nullptr;
 	void *kc = nullptr, *vc = nullptr;
 	size_t kv_layer_bytes = 0;
+	int attn_chunk = 1 << 30; // cached positions per attention split of the step being enqueued (launch_attn_lpr)
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
 	// batched prompt ingestion (allocated on first use): token-major [PF_NT][...] activations of one chunk
@@ -332,20 +334,33 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
-		hipLaunchKernelGGL((k_attn<KVB, LPR>), dim3(c->n_heads), dim3(ATTN_BLOCK), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
+		if (g_attn_waves == 4) {
+			hipLaunchKernelGGL((k_attn<KVB, LPR, 4>), dim3(c->n_heads), dim3(256), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
+		} else if (g_attn_waves == 8) {
+			hipLaunchKernelGGL((k_attn<KVB, LPR, 8>), dim3(c->n_heads), dim3(512), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
+		} else {
+			hipLaunchKernelGGL((k_attn<KVB, LPR, 16>), dim3(c->n_heads), dim3(1024), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
+		}
 		return;
 	}
 	// long context: K/V rows loaded once per kv head for up to 4 query heads, kv range split, then merged
 	const int qh = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
 	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
-	if (qh == 4) {
-		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
-	} else if (qh == 2) {
-		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 2>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
-	} else {
-		hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
-	}
-	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3(256), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	// a split of at most two rounds (4 waves x 64 / LPR positions x 4 tiles each) asks for all its rows at once; the split length
+	// of THIS step (Ctx::attn_chunk, set by run_step from kv_len; part of the graph key through attn_two)
+	const int step = (ATTN_GQA_BLOCK / 64) * (64 / LPR) * 4;
+	const bool two = c->attn_chunk <= 2 * step;
+	by_bool(two, [&](auto TWO) {
+		constexpr bool T = decltype(TWO)::value;
+		if (qh == 4) {
+			hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 4, T>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+		} else if (qh == 2) {
+			hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 2, T>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+		} else {
+			hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1, T>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+		}
+	});
+	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3((c->head_dim + 63) / 64 * 64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
 }
 
 template <int KVB>
@@ -644,6 +659,8 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 	sp.sink = kv_sink > 0;
 	sp.n_split = attn_splits(kv_len);
+	c->attn_chunk = (kv_len + sp.n_split - 1) / sp.n_split;
+	const int attn_two = c->attn_chunk <= 2 * 4 * (64 / c->lpr) * 4; // the split kernel's two-round form (launch_attn_lpr): a different graph
 	sp.chained = tok_src != nullptr;
 	if (g_prof_json) {
 		account_step(c, sp, kv_len);
@@ -658,7 +675,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	c->ba.kv_len = kv_len;
 
 	auto replay = [&]() { // the step from its hipGraph (captured on first use), begin-token arguments patched
-		auto key = std::make_tuple(sp.n_split, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.sample * 4 + (int)sp.argmax * 2 + (int)sp.copy_logits);
+		auto key = std::make_tuple(sp.n_split * 2 + attn_two, (int)sp.kv_only, (int)sp.sink, (int)sp.chained, (int)sp.sample * 4 + (int)sp.argmax * 2 + (int)sp.copy_logits);
 		GraphEntry& ge = c->graphs[key];
 		if (!ge.exec) {
 			HIP_CHECK(hipStreamBeginCapture(g_stream, hipStreamCaptureModeThreadLocal));
@@ -1045,6 +1062,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_t;
 	} else if (!strcmp(key, "split_min")) {
 		slot = &g_split_min;
+	} else if (!strcmp(key, "attn_waves")) {
+		slot = &g_attn_waves;
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
 	} else if (!strcmp(key, "pf_attn_mfma")) {
@@ -1146,6 +1165,7 @@ extern "C" void init_hip(void) {
 	}
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
+	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
@@ -1820,6 +1840,7 @@ extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, ui
 		*bytes_per_launch = stage_bytes(c, stage, kv_len);
 	}
 	int n_split = attn_splits(kv_len);
+	c->attn_chunk = (kv_len + n_split - 1) / n_split;
 	auto one = [&](int l) {
 #define ST(db, kvb)                                  \
 	if (c->dbits == db && c->kvbits == kvb) {        \

@@ -846,7 +846,7 @@ __device__ __forceinline__ void sm_merge(float& m, float& l, float (&o)[8], floa
 	m = M;
 }
 
-constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions in flight per round
+constexpr int ATTN_ROUND_TILES = 64; // wave-tiles of 64/LPR positions per round of the workgroup: NW waves x 64 / NW tiles each
 
 // Short-context attention: one workgroup (16 waves) per query head, the whole cached range in one or two rounds, no
 // merge pass (longer contexts: k_attn_gqa + k_attn_merge).  LPR lanes cover one cached row (8 dims per lane, one
@@ -856,11 +856,13 @@ constexpr int ATTN_BLOCK = 1024; // 16 waves: 16 x 4 tiles x (64/LPR) positions 
 // The kernel is latency, not bandwidth: its K/V rows were last touched a token ago and come from HBM.  Rounds are
 // loaded one ahead of the arithmetic.  (Issuing the first round before kv_len is known -- clamped to the cache instead
 // of the live range -- measured the same 4.7 us and fetched 4 MB per launch of rows nobody needs: not kept.)
-template <int KVB, int LPR>
-__global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, AttnArgs a) {
+// NW: waves per workgroup (16 / 8 / 4), each holding 64 / NW tiles in flight -- the same 256 positions (at head size 128) per
+// round either way; fewer, fatter waves start and merge faster, more waves hide more latency (picked by measurement, infer_hip.hip).
+template <int KVB, int LPR, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, AttnArgs a) {
 	constexpr int RPW = 64 / LPR; // positions per wave-load
-	constexpr int NW = ATTN_BLOCK / 64;
-	constexpr int UA = 4; // tiles in flight per wave
+	constexpr int ATTN_BLOCK = NW * 64;
+	constexpr int UA = ATTN_ROUND_TILES / NW; // tiles in flight per wave
 	constexpr int STEP = NW * RPW * UA; // positions per round of the workgroup
 	__shared__ float sm_m[NW], sm_l[NW];
 	__shared__ float sm_o[NW][LPR * 8];
@@ -1018,9 +1020,12 @@ __global__ __launch_bounds__(ATTN_BLOCK) void k_attn(const TokState* ts, const f
 // (GQA): a 4096-position context is 8 kv heads x 32 splits = 256 workgroups, each walking its 128 positions in two
 // rounds of 4 K + 4 V wave-loads per wave.  Always writes split partials (o, m, l per query head) for
 // k_attn_merge.  Same arithmetic as k_attn.
+// TWO: the split is at most two rounds long (contexts up to 32 splits x 2 rounds: 4096 positions at head size 128) -- both rounds'
+// rows are asked for at once, unconditionally, and multiplied out as they land: one exposed load latency instead of two
+// (8.2 -> us at 4096 positions, profiles/r03_long_context.txt).  Otherwise rounds are loaded one ahead of the arithmetic.
 constexpr int ATTN_GQA_BLOCK = 256;
 
-template <int KVB, int LPR, int QH>
+template <int KVB, int LPR, int QH, bool TWO>
 __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
 	constexpr int RPW = 64 / LPR;
 	constexpr int NW = ATTN_GQA_BLOCK / 64;
@@ -1042,6 +1047,30 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
 
+	constexpr int EB = KVB / 8;
+	const unsigned char* kbase = (const unsigned char*)kc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)vc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
+	const size_t rstride = (size_t)head_dim * EB;
+	constexpr int STEP = NW * RPW * UA;
+	using Raw = std::conditional_t<KVB == 16, u32x4, u32x2>; // 8 cached elements
+	struct Round {
+		Raw k[UA], v[UA];
+	};
+	auto load_round = [&](Round& rd, int tb) { // clamped into the live range, masked at use
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			const int t = min(tb + u * NW * RPW + g, kv_len - 1);
+			rd.k[u] = *(const Raw*)(kbase + (size_t)t * rstride);
+			rd.v[u] = *(const Raw*)(vbase + (size_t)t * rstride);
+		}
+	};
+	// the cached rows go out before anything else this wave needs (q, below, is an L2 hit and small)
+	Round ra, rb;
+	if constexpr (TWO) {
+		load_round(ra, t0 + wave * RPW);
+		load_round(rb, t0 + wave * RPW + STEP);
+	}
+
 	float qv[QH][8];
 #pragma unroll
 	for (int q = 0; q < QH; ++q) {
@@ -1062,54 +1091,37 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 		}
 	}
 
-	constexpr int EB = KVB / 8;
-	const unsigned char* kbase = (const unsigned char*)kc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
-	const unsigned char* vbase = (const unsigned char*)vc + ((size_t)kvh * seq_len * head_dim + d0) * EB;
-	const size_t rstride = (size_t)head_dim * EB;
-
-	// Rounds are loaded one ahead: the raw rows of round n+1 are in flight while round n is multiplied out.  (With the
-	// loads at the top of each round and one 8-wave workgroup per CU -- 160 VGPRs -- nothing hid the load latency:
-	// 32.5 us per layer at a 32k context; round-ahead loads and 4-wave workgroups: 27.1, 8k: 19.7 -> 12.8.)
-	constexpr int STEP = NW * RPW * UA;
-	using Raw = std::conditional_t<KVB == 16, u32x4, u32x2>; // 8 cached elements
-	Raw kw[UA], vw[UA];
-	auto load_round = [&](int tb) { // clamped into the live range, masked at use
-#pragma unroll
-		for (int u = 0; u < UA; ++u) {
-			const int t = min(tb + u * NW * RPW + g, kv_len - 1);
-			kw[u] = *(const Raw*)(kbase + (size_t)t * rstride);
-			vw[u] = *(const Raw*)(vbase + (size_t)t * rstride);
-		}
-	};
-	if (t0 + wave * RPW < t1) { // wave-uniform
-		load_round(t0 + wave * RPW);
-	}
-	for (int tb = t0 + wave * RPW; tb < t1; tb += STEP) {
+	// one round: decode the raw rows, then per query head scores -> running (max, sum, out)
+	struct Decoded {
 		float kf[UA][8], vf[UA][8];
-		bool valid[UA];
+	};
+	auto decode = [&](Decoded& dc, const Round& rd) {
 #pragma unroll
 		for (int u = 0; u < UA; ++u) {
-			valid[u] = tb + u * NW * RPW + g < t1;
 			if constexpr (KVB == 16) {
 #pragma unroll
 				for (int i = 0; i < 4; ++i) {
-					kf[u][2 * i] = half_bits_to_float((unsigned short)(kw[u][i] & 0xffff));
-					kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(kw[u][i] >> 16));
-					vf[u][2 * i] = half_bits_to_float((unsigned short)(vw[u][i] & 0xffff));
-					vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(vw[u][i] >> 16));
+					dc.kf[u][2 * i] = half_bits_to_float((unsigned short)(rd.k[u][i] & 0xffff));
+					dc.kf[u][2 * i + 1] = half_bits_to_float((unsigned short)(rd.k[u][i] >> 16));
+					dc.vf[u][2 * i] = half_bits_to_float((unsigned short)(rd.v[u][i] & 0xffff));
+					dc.vf[u][2 * i + 1] = half_bits_to_float((unsigned short)(rd.v[u][i] >> 16));
 				}
 			} else {
 #pragma unroll
 				for (int i = 0; i < 2; ++i) {
-					f32x2 k0 = bf8x2_lo(kw[u][i]), k1 = bf8x2_hi(kw[u][i]);
-					f32x2 v0 = bf8x2_lo(vw[u][i]), v1 = bf8x2_hi(vw[u][i]);
-					kf[u][4 * i] = k0[0], kf[u][4 * i + 1] = k0[1], kf[u][4 * i + 2] = k1[0], kf[u][4 * i + 3] = k1[1];
-					vf[u][4 * i] = v0[0], vf[u][4 * i + 1] = v0[1], vf[u][4 * i + 2] = v1[0], vf[u][4 * i + 3] = v1[1];
+					f32x2 k0 = bf8x2_lo(rd.k[u][i]), k1 = bf8x2_hi(rd.k[u][i]);
+					f32x2 v0 = bf8x2_lo(rd.v[u][i]), v1 = bf8x2_hi(rd.v[u][i]);
+					dc.kf[u][4 * i] = k0[0], dc.kf[u][4 * i + 1] = k0[1], dc.kf[u][4 * i + 2] = k1[0], dc.kf[u][4 * i + 3] = k1[1];
+					dc.vf[u][4 * i] = v0[0], dc.vf[u][4 * i + 1] = v0[1], dc.vf[u][4 * i + 2] = v1[0], dc.vf[u][4 * i + 3] = v1[1];
 				}
 			}
 		}
-		if (tb + STEP < t1) { // wave-uniform
-			load_round(tb + STEP);
+	};
+	auto accumulate = [&](const Decoded& dc, int tb) {
+		bool valid[UA];
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			valid[u] = tb + u * NW * RPW + g < t1;
 		}
 #pragma unroll
 		for (int q = 0; q < QH; ++q) {
@@ -1119,7 +1131,7 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 				float d = 0.f;
 #pragma unroll
 				for (int i = 0; i < 8; ++i) {
-					d = fmaf(qv[q][i], kf[u][i], d);
+					d = fmaf(qv[q][i], dc.kf[u][i], d);
 				}
 				d = group_sum<LPR>(d);
 				sc[u] = valid[u] ? d * inv_sqrt_hd : -INFINITY;
@@ -1142,11 +1154,36 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 					l[q] += p;
 #pragma unroll
 					for (int i = 0; i < 8; ++i) {
-						o[q][i] = fmaf(p, vf[u][i], o[q][i]);
+						o[q][i] = fmaf(p, dc.vf[u][i], o[q][i]);
 					}
 				}
 				m[q] = mn;
 			}
+		}
+	};
+
+	if constexpr (TWO) {
+		Decoded dc;
+		decode(dc, ra);
+		accumulate(dc, t0 + wave * RPW);
+		if (t0 + wave * RPW + STEP < t1) { // wave-uniform
+			decode(dc, rb);
+			accumulate(dc, t0 + wave * RPW + STEP);
+		}
+	} else {
+		// Rounds are loaded one ahead: the raw rows of round n+1 are in flight while round n is multiplied out.  (With the
+		// loads at the top of each round and one 8-wave workgroup per CU -- 160 VGPRs -- nothing hid the load latency:
+		// 32.5 us per layer at a 32k context; round-ahead loads and 4-wave workgroups: 27.1, 8k: 19.7 -> 12.8.)
+		if (t0 + wave * RPW < t1) { // wave-uniform
+			load_round(ra, t0 + wave * RPW);
+		}
+		for (int tb = t0 + wave * RPW; tb < t1; tb += STEP) {
+			Decoded dc;
+			decode(dc, ra);
+			if (tb + STEP < t1) { // wave-uniform
+				load_round(ra, tb + STEP);
+			}
+			accumulate(dc, tb);
 		}
 	}
 
@@ -1200,50 +1237,43 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	}
 }
 
-// merge the kv splits of every head: grid = n_heads, block = 256; n_split <= 64.
-// Wave 0 fetches all (m, l) pairs at once (one lane per split) and turns them into weights; then one
-// thread per output dim sums the split partials with 8 independent loads in flight (a serial loop of
-// dependent L2 round trips made this kernel cost 1 us PER SPLIT).
-__global__ __launch_bounds__(256) void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
-	__shared__ float wgt[64];
-	__shared__ float inv_l;
-	const int h = blockIdx.x;
+// merge the kv splits of every head: grid = n_heads, one thread per output dim (block = head_dim rounded up to whole waves),
+// n_split <= 64.  ONE round trip: every thread asks at once for its column of all 64 possible partials (indices past n_split
+// re-read the last one and get weight 0) and -- through the scalar cache, the addresses are wave-uniform -- for all (m, l) pairs,
+// then forms the weights exp(m_s - M) itself and folds.  (First form: wave 0 fetched the (m, l) pairs, a barrier, then eight
+// loads at a time: three dependent round trips, 5.1 us per launch for 130 KB -- profiles/r03_long_context.txt.)
+constexpr int ATTN_MAX_SPLIT = 64;
+__global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
+	const int h = blockIdx.x, d = threadIdx.x;
 	const int stride = head_dim + 2;
 	const float* p = partial + (size_t)h * n_split * stride;
-	if (threadIdx.x < 64) {
-		const int s = threadIdx.x;
-		float ms = -INFINITY, ls = 0.f;
-		if (s < n_split) {
-			ms = p[s * stride + head_dim];
-			ls = p[s * stride + head_dim + 1];
-		}
-		const float M = wave_max(ms);
-		const float w = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-		const float L = wave_sum(ls * w);
-		wgt[s] = w;
-		if (s == 0) {
-			inv_l = 1.0f / L;
-		}
+	const int dc = d < head_dim ? d : 0;
+	float v[ATTN_MAX_SPLIT], ms[ATTN_MAX_SPLIT], ls[ATTN_MAX_SPLIT];
+#pragma unroll
+	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
+		const int sc = s < n_split ? s : n_split - 1;
+		v[s] = p[sc * stride + dc];
 	}
-	__syncthreads();
-	for (int d = threadIdx.x; d < head_dim; d += 256) {
-		float acc = 0.f;
-		int s = 0;
-		for (; s + 8 <= n_split; s += 8) {
-			float v[8];
 #pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				v[u] = p[(s + u) * stride + d];
-			}
+	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
+		const int sc = s < n_split ? s : n_split - 1;
+		ms[s] = p[sc * stride + head_dim];
+		ls[s] = p[sc * stride + head_dim + 1];
+	}
+	float M = -INFINITY;
 #pragma unroll
-			for (int u = 0; u < 8; ++u) {
-				acc = fmaf(v[u], wgt[s + u], acc);
-			}
-		}
-		for (; s < n_split; ++s) {
-			acc = fmaf(p[s * stride + d], wgt[s], acc);
-		}
-		out[h * head_dim + d] = acc * inv_l;
+	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
+		M = fmaxf(M, ms[s]);
+	}
+	float L = 0.f, acc = 0.f;
+#pragma unroll
+	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
+		const float w = (s < n_split && ms[s] != -INFINITY) ? __expf(ms[s] - M) : 0.f; // (a split without positions)
+		L = fmaf(ls[s], w, L);
+		acc = fmaf(v[s], w, acc);
+	}
+	if (d < head_dim) {
+		out[h * head_dim + d] = acc / L;
 	}
 }
 

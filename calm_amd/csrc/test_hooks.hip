@@ -108,6 +108,7 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	while (c.lpr * 8 < head_dim) {
 		c.lpr *= 2;
 	}
+	c.attn_chunk = (kv_len + n_split - 1) / n_split;
 	launch_attn<16>(&c, 0, n_split);
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, c.att, q_dim * sizeof(float));
