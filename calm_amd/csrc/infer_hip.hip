@@ -79,6 +79,7 @@ int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
+int g_attn_mfma = 0;   // 1: split attention on the matrix cores where the head size is 128 (k_attn_mfma; measured no faster than k_attn_gqa: profiles/r03_long_context.txt)
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -321,6 +322,17 @@ void launch_qkv(Ctx* c, int l) {
 	});
 }
 
+void launch_attn_merge(Ctx* c, int n_split) {
+	const dim3 mblock((c->head_dim + 63) / 64 * 64);
+	if (n_split <= 16) {
+		hipLaunchKernelGGL(k_attn_merge<16>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	} else if (n_split <= 32) {
+		hipLaunchKernelGGL(k_attn_merge<32>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	} else {
+		hipLaunchKernelGGL(k_attn_merge<64>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	}
+}
+
 template <int KVB, int LPR>
 void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	AttnArgs a;
@@ -348,6 +360,17 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
 	// a split of at most two rounds (4 waves x 64 / LPR positions x 4 tiles each) asks for all its rows at once; the split length
 	// of THIS step (Ctx::attn_chunk, set by run_step from kv_len; part of the graph key through attn_two)
+	if (g_attn_mfma && c->head_dim == 128) { // the matrix-core form: a wave per 32-key tile, all qh query heads at once
+		if (qh == 4) {
+			hipLaunchKernelGGL((k_attn_mfma<KVB, 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+		} else if (qh == 2) {
+			hipLaunchKernelGGL((k_attn_mfma<KVB, 2>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+		} else {
+			hipLaunchKernelGGL((k_attn_mfma<KVB, 1>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+		}
+		launch_attn_merge(c, n_split);
+		return;
+	}
 	const int step = (ATTN_GQA_BLOCK / 64) * (64 / LPR) * 4;
 	const bool two = c->attn_chunk <= 2 * step;
 	by_bool(two, [&](auto TWO) {
@@ -360,7 +383,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 			hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1, T>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 		}
 	});
-	hipLaunchKernelGGL(k_attn_merge, dim3(c->n_heads), dim3((c->head_dim + 63) / 64 * 64), 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+	launch_attn_merge(c, n_split);
 }
 
 template <int KVB>
@@ -1064,6 +1087,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_min;
 	} else if (!strcmp(key, "attn_waves")) {
 		slot = &g_attn_waves;
+	} else if (!strcmp(key, "attn_mfma")) {
+		slot = &g_attn_mfma;
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
 	} else if (!strcmp(key, "pf_attn_mfma")) {
@@ -1166,6 +1191,7 @@ extern "C" void init_hip(void) {
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
+	g_attn_mfma = env_int("CALM_HIP_ATTN_MFMA", g_attn_mfma);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {

@@ -1173,7 +1173,9 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	} else {
 		// Rounds are loaded one ahead: the raw rows of round n+1 are in flight while round n is multiplied out.  (With the
 		// loads at the top of each round and one 8-wave workgroup per CU -- 160 VGPRs -- nothing hid the load latency:
-		// 32.5 us per layer at a 32k context; round-ahead loads and 4-wave workgroups: 27.1, 8k: 19.7 -> 12.8.)
+		// 32.5 us per layer at a 32k context; round-ahead loads and 4-wave workgroups: 27.1, 8k: 19.7 -> 12.8.  TWO rounds ahead,
+		// every load unconditional so that the waits are counted: 24.4 us at 32k against 24.3, 17.6 against 16.3 at 16k -- the
+		// kernel is bound by its lane arithmetic there, not by what is in flight; not kept.)
 		if (t0 + wave * RPW < t1) { // wave-uniform
 			load_round(ra, t0 + wave * RPW);
 		}
@@ -1237,40 +1239,259 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	}
 }
 
+// ---- the same split attention on the matrix cores (head size 128) -------------------------------------------------------
+// k_attn_gqa is bound by its lane arithmetic from a few thousand positions on (65.6 MB of an fp8 cache at 32k in 24 us: 2.7 TB/s,
+// every score a 16-lane DPP reduction).  Here a WAVE owns a tile of 32 keys and all QH query heads of the kv head at once:
+//   S^T[key][query] = K[key][:] . q[query][:]      v_mfma_f32_16x16x32_f16: A = K rows (binary16 as cached; e5m2 widened, exact),
+//                                                  B = q as hi + lo binary16 (the fp32 query to 22 significant bits; columns
+//                                                  beyond QH are zero), two 16-key row blocks x four k-steps of 32 dims
+//   online softmax down the columns: a lane holds 8 keys of ONE query (C layout: column = lane & 15, rows 4 (lane >> 4) + e), so
+//   maximum and sum are in-lane reductions plus two exchanges (lane ^ 16, lane ^ 32)
+//   O^T[d][query] += V^T[d][key] . P[key][query]   A = V transposed through the wave's LDS image, B = P as hi + lo binary16 taken
+//   from S^T's accumulator registers as they are: slot e of k-block kb is key 16 (e >> 2) + 4 kb + (e & 3), and the V^T image is
+//   written in that key order
+// Every product is exact in fp32, accumulation is fp32; the result agrees with k_attn_gqa to fp32 rounding (same tolerance in the
+// tests).  The four waves of a workgroup take different tiles of the split (wave-private LDS images: no barrier in the loop; a
+// wave's LDS operations execute in order), rows are fetched coalesced (16 lanes per row) one tile ahead, and the wave states
+// are folded through LDS at the end exactly as in k_attn_gqa (same partial format, same k_attn_merge).
+// LDS per wave: K [32 keys][16 chunks of 8 halfs], chunk index XOR (key & 15); V^T [128 d][4 chunks of 8 keys], chunk index
+// XOR ((d >> 2) & 3): both make the ds_read_b128 operand fetches conflict-free for the hardware's 16-lane groups.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void att_split2(float a, float b, unsigned& hi, unsigned& lo) { // x = hi + lo, binary16 each (|x| < 65504)
+	const __half2 h = __floats2half2_rn(a, b);
+	const float2 hf = __half22float2(h);
+	hi = __builtin_bit_cast(unsigned, h);
+	lo = __builtin_bit_cast(unsigned, __floats2half2_rn(a - hf.x, b - hf.y));
+}
+
+template <int KVB, int QH>
+__global__ __launch_bounds__(256) void k_attn_mfma(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
+	constexpr int HD = 128, NW = 4;
+	__shared__ u32x4 kst[NW][32 * 16];
+	__shared__ u32x4 vst[NW][HD * 4];
+	__shared__ float sm_m[QH][NW], sm_l[QH][NW];
+	__shared__ float sm_o[QH][NW][HD];
+
+	const int lane = lane_id(), wave = wave_id();
+	const int qgroups = kv_mul / QH;
+	const int split = blockIdx.x % n_split;
+	const int qg = (blockIdx.x / n_split) % qgroups;
+	const int kvh = blockIdx.x / (n_split * qgroups);
+	const int h0 = kvh * kv_mul + qg * QH;
+	const int n = lane & 15, kb = lane >> 4; // MFMA column (query) / row (key, d) index, k-block = C row group
+	const int kv_len = ts->kv_len;
+	const int chunk = (kv_len + n_split - 1) / n_split;
+	const int t0 = split * chunk;
+	const int t1 = min(kv_len, t0 + chunk);
+
+	// staging: every lane fetches 16 bytes of a cached row -- 8 binary16 elements (16 lanes per row, 4 rows per wave-load, 8 loads
+	// per 32-key tile) or 16 e5m2 elements (8 lanes per row, 8 rows per wave-load, 4 loads per tile).  (8-byte loads of an e5m2
+	// row kept the split kernels at 2.6 TB/s: a CU's memory path counts wave-loads in flight, not bytes.)
+	constexpr int EB = KVB / 8;
+	constexpr int NLD = KVB == 16 ? 8 : 4; // wave-loads per tile and matrix
+	constexpr int RPL = 32 / NLD;          // rows per wave-load
+	constexpr int LPRW = 64 / RPL;         // lanes per row
+	const int c = lane % LPRW, rr = lane / LPRW;
+	const unsigned char* kbase = (const unsigned char*)kc + (size_t)kvh * seq_len * HD * EB + c * 16;
+	const unsigned char* vbase = (const unsigned char*)vc + (size_t)kvh * seq_len * HD * EB + c * 16;
+	const size_t rstride = (size_t)HD * EB;
+	u32x4 kreg[NLD], vreg[NLD];
+	auto fetch = [&](int tb) { // rows tb .. tb + 31, clamped into the live range (masked at use)
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int row = min(tb + RPL * i + rr, kv_len - 1);
+			kreg[i] = *(const u32x4*)(kbase + (size_t)row * rstride);
+			vreg[i] = *(const u32x4*)(vbase + (size_t)row * rstride);
+		}
+	};
+	// e5m2 -> binary16: the byte becomes the upper byte (exact); two cached dwords -> four
+	auto widen = [](unsigned w0, unsigned w1) -> u32x4 {
+		return (u32x4){__builtin_amdgcn_perm(w0, w0, 0x050c040cu), __builtin_amdgcn_perm(w0, w0, 0x070c060cu), __builtin_amdgcn_perm(w1, w1, 0x050c040cu),
+		               __builtin_amdgcn_perm(w1, w1, 0x070c060cu)};
+	};
+	auto stage = [&]() {
+		unsigned short* vt = (unsigned short*)vst[wave];
+#pragma unroll
+		for (int i = 0; i < NLD; ++i) {
+			const int key = RPL * i + rr; // within the tile
+			const int pos = ((key >> 2) & 3) * 8 + (key >> 4) * 4 + (key & 3); // the key's place in the MFMA's k order
+			constexpr int NCH = KVB == 16 ? 1 : 2; // 8-element chunks this lane holds of the row
+#pragma unroll
+			for (int hc = 0; hc < NCH; ++hc) {
+				const int ch = NCH * c + hc; // chunk of 8 elements: d = 8 ch .. 8 ch + 7
+				const u32x4 k16 = KVB == 16 ? kreg[i] : widen(kreg[i][2 * hc], kreg[i][2 * hc + 1]);
+				const u32x4 v16 = KVB == 16 ? vreg[i] : widen(vreg[i][2 * hc], vreg[i][2 * hc + 1]);
+				kst[wave][key * 16 + (ch ^ (key & 15))] = k16;
+#pragma unroll
+				for (int e = 0; e < 8; ++e) {
+					const int d = 8 * ch + e;
+					const unsigned w = v16[e >> 1];
+					vt[d * 32 + ((((pos >> 3) ^ ((d >> 2) & 3)) << 3) | (pos & 7))] = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffff));
+				}
+			}
+		}
+	};
+	const int tb0 = t0 + wave * 32; // this wave's tiles: tb0, tb0 + 128, ...
+	if (tb0 < t1) {                 // wave-uniform
+		fetch(tb0);
+	}
+
+	// the queries as B operands: column n = head h0 + n, d = 32 t + 8 kb + e
+	u32x4 qh[4], ql[4];
+#pragma unroll
+	for (int t = 0; t < 4; ++t) {
+		const float* qsrc = qin + (size_t)(h0 + (n < QH ? n : 0)) * HD + 32 * t + 8 * kb;
+		const float4 q0 = *(const float4*)qsrc, q1 = *(const float4*)(qsrc + 4);
+		unsigned hi, lo;
+		att_split2(q0.x, q0.y, hi, lo), qh[t][0] = hi, ql[t][0] = lo;
+		att_split2(q0.z, q0.w, hi, lo), qh[t][1] = hi, ql[t][1] = lo;
+		att_split2(q1.x, q1.y, hi, lo), qh[t][2] = hi, ql[t][2] = lo;
+		att_split2(q1.z, q1.w, hi, lo), qh[t][3] = hi, ql[t][3] = lo;
+		if (n >= QH) {
+			qh[t] = (u32x4){0u, 0u, 0u, 0u}, ql[t] = (u32x4){0u, 0u, 0u, 0u};
+		}
+	}
+	const float inv_sqrt_hd = 1.0f / sqrtf((float)HD);
+	f32x4 o[8];
+#pragma unroll
+	for (int db = 0; db < 8; ++db) {
+		o[db] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	}
+	float m = -INFINITY, l = 0.f;
+
+	for (int tb = tb0; tb < t1; tb += 32 * NW) {
+		stage(); // (this tile's rows have landed: the loads were issued a tile ago)
+		if (tb + 32 * NW < t1) { // wave-uniform
+			fetch(tb + 32 * NW);
+		}
+		f32x4 s[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+#pragma unroll
+			for (int rb = 0; rb < 2; ++rb) {
+				const f16x8 kop = __builtin_bit_cast(f16x8, kst[wave][(16 * rb + n) * 16 + ((4 * t + kb) ^ n)]);
+				s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, qh[t]), s[rb], 0, 0, 0);
+				s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, ql[t]), s[rb], 0, 0, 0);
+			}
+		}
+		// scores of this lane's query against keys tb + 16 rb + 4 kb + e   (src/infer.c:244-248)
+		float mt = -INFINITY;
+#pragma unroll
+		for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				const int key = tb + 16 * rb + 4 * kb + e;
+				s[rb][e] = key < t1 ? s[rb][e] * inv_sqrt_hd : -INFINITY;
+				mt = fmaxf(mt, s[rb][e]);
+			}
+		}
+		mt = fmaxf(mt, __shfl_xor(mt, 16));
+		mt = fmaxf(mt, __shfl_xor(mt, 32));
+		const float mn = fmaxf(m, mt); // finite: the tile's first key is inside the split
+		const float cs = (m == -INFINITY) ? 0.f : __expf(m - mn);
+		float ls = 0.f;
+#pragma unroll
+		for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				s[rb][e] = __expf(s[rb][e] - mn); // masked: exp(-inf) = 0
+				ls += s[rb][e];
+			}
+		}
+		ls += __shfl_xor(ls, 16);
+		ls += __shfl_xor(ls, 32);
+		l = l * cs + ls;
+		m = mn;
+#pragma unroll
+		for (int db = 0; db < 8; ++db) {
+			o[db] *= cs;
+		}
+		u32x4 ph, pl; // P as the B operand: slot e = 4 rb + e'
+#pragma unroll
+		for (int rb = 0; rb < 2; ++rb) {
+			unsigned hi, lo;
+			att_split2(s[rb][0], s[rb][1], hi, lo), ph[2 * rb] = hi, pl[2 * rb] = lo;
+			att_split2(s[rb][2], s[rb][3], hi, lo), ph[2 * rb + 1] = hi, pl[2 * rb + 1] = lo;
+		}
+#pragma unroll
+		for (int db = 0; db < 8; ++db) {
+			const int d = 16 * db + n;
+			const f16x8 vop = __builtin_bit_cast(f16x8, vst[wave][d * 4 + (kb ^ ((d >> 2) & 3))]);
+			o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, ph), o[db], 0, 0, 0);
+			o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, pl), o[db], 0, 0, 0);
+		}
+	}
+
+	// wave states -> LDS: O^T[d = 16 db + 4 kb + e][query n]
+	if (n < QH) {
+		if (kb == 0) {
+			sm_m[n][wave] = m;
+			sm_l[n][wave] = l;
+		}
+#pragma unroll
+		for (int db = 0; db < 8; ++db) {
+#pragma unroll
+			for (int e = 0; e < 4; ++e) {
+				sm_o[n][wave][16 * db + 4 * kb + e] = o[db][e];
+			}
+		}
+	}
+	__syncthreads();
+	// one thread per (query head, output dim) folds the NW wave partials (see k_attn)
+	for (int idx = threadIdx.x; idx < QH * HD; idx += 256) {
+		const int q = idx / HD, d = idx % HD;
+		float M = sm_m[q][0];
+#pragma unroll
+		for (int w = 1; w < NW; ++w) {
+			M = fmaxf(M, sm_m[q][w]);
+		}
+		float L = 0.f, O = 0.f;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const float e = (sm_m[q][w] == -INFINITY) ? 0.f : __expf(sm_m[q][w] - M);
+			L = fmaf(sm_l[q][w], e, L);
+			O = fmaf(sm_o[q][w][d], e, O);
+		}
+		float* p = a.partial + ((size_t)(h0 + q) * n_split + split) * (HD + 2);
+		p[d] = O;
+		if (d == 0) {
+			p[HD] = M;
+			p[HD + 1] = L;
+		}
+	}
+}
+
 // merge the kv splits of every head: grid = n_heads, one thread per output dim (block = head_dim rounded up to whole waves),
-// n_split <= 64.  ONE round trip: every thread asks at once for its column of all 64 possible partials (indices past n_split
-// re-read the last one and get weight 0) and -- through the scalar cache, the addresses are wave-uniform -- for all (m, l) pairs,
-// then forms the weights exp(m_s - M) itself and folds.  (First form: wave 0 fetched the (m, l) pairs, a barrier, then eight
-// loads at a time: three dependent round trips, 5.1 us per launch for 130 KB -- profiles/r03_long_context.txt.)
+// n_split <= NS <= 64.  ONE round trip: every thread asks at once for its column of the partials (NS loads; the few indices past
+// n_split re-read the last one and get weight 0), and lane s of every wave for split s's (m, l) pair -- one wave-load; the weights
+// exp(m_s - M) are then one exponential per lane and reach the fold through v_readlane.  (First form: wave 0 fetched the (m, l)
+// pairs, a barrier, then eight partial loads at a time: three dependent round trips, 5.1 us per launch for 130 KB --
+// profiles/r03_long_context.txt.)
 constexpr int ATTN_MAX_SPLIT = 64;
+template <int NS>
 __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
-	const int h = blockIdx.x, d = threadIdx.x;
+	const int h = blockIdx.x, d = threadIdx.x, lane = lane_id();
 	const int stride = head_dim + 2;
 	const float* p = partial + (size_t)h * n_split * stride;
 	const int dc = d < head_dim ? d : 0;
-	float v[ATTN_MAX_SPLIT], ms[ATTN_MAX_SPLIT], ls[ATTN_MAX_SPLIT];
+	float v[NS];
 #pragma unroll
-	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
+	for (int s = 0; s < NS; ++s) {
 		const int sc = s < n_split ? s : n_split - 1;
 		v[s] = p[sc * stride + dc];
 	}
+	const int sl = lane < n_split ? lane : n_split - 1;
+	const float2 ml = *(const float2*)(p + sl * stride + head_dim); // (head_dim is even: 8-byte aligned)
+	const float ms = lane < n_split ? ml.x : -INFINITY;
+	const float M = wave_max(ms);
+	const float w = ms == -INFINITY ? 0.f : __expf(ms - M); // (a split without positions, or no split at all)
+	const float L = wave_sum(ml.y * w);
+	float acc = 0.f;
 #pragma unroll
-	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
-		const int sc = s < n_split ? s : n_split - 1;
-		ms[s] = p[sc * stride + head_dim];
-		ls[s] = p[sc * stride + head_dim + 1];
-	}
-	float M = -INFINITY;
-#pragma unroll
-	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
-		M = fmaxf(M, ms[s]);
-	}
-	float L = 0.f, acc = 0.f;
-#pragma unroll
-	for (int s = 0; s < ATTN_MAX_SPLIT; ++s) {
-		const float w = (s < n_split && ms[s] != -INFINITY) ? __expf(ms[s] - M) : 0.f; // (a split without positions)
-		L = fmaf(ls[s], w, L);
-		acc = fmaf(v[s], w, acc);
+	for (int s = 0; s < NS; ++s) {
+		const float ws = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w), s));
+		acc = fmaf(v[s], ws, acc);
 	}
 	if (d < head_dim) {
 		out[h * head_dim + d] = acc / L;

@@ -13,7 +13,7 @@ from calm_amd.host import STAGES, HipBackend, HostModel, generate, load_lib
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spec = cf.SPECS["mistral-7b"]
 lib = load_lib()
-for kvbits, ctx in ((16, 4096), (8, 32768)):
+for kvbits, ctx in ((16, 4096), (8, 32768)) if not os.environ.get("KV16_32K") else ((16, 32768),):
     md = cf.dataclasses.replace(spec, n_layers=L, max_seq_len=ctx).metadata("fp8")
     model = HostModel(cf.stub_tensors(spec, "fp8", L), md, context=ctx)
     be = HipBackend(model, kvbits=kvbits, stream=cf.synth_stream_big(spec, "fp8", 1, L))
