@@ -266,6 +266,17 @@ int pick_blocks(int ntasks, int wpb) {
 	return g_ncu * best_b;
 }
 
+// the matvec kernels with a dim-sized vector: WG_WAVES waves per workgroup (kernels.hip.h); 512-thread workgroups sit one per CU
+int pick_blocks_wg(int ntasks) {
+	const int cap = g_bpc;
+	if (WG_THREADS >= 512) {
+		g_bpc = 1;
+	}
+	const int n = pick_blocks(ntasks, WG_WAVES);
+	g_bpc = cap;
+	return n;
+}
+
 template <int DB>
 size_t lds_bytes(int n) {
 	return (size_t)xs_slots<DB>(n) * 16 + LDS_EXTRA;
@@ -313,9 +324,9 @@ void launch_qkv(Ctx* c, int l) {
 	a.dim = c->dim, a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len;
 	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
 	int ntasks = (c->q_dim + 2 * c->kv_dim) / Shape<DB>::NR;
-	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
-	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
+	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.dim, a.q_dim, a.kv_dim, a);
 		});
@@ -407,10 +418,10 @@ void launch_attn(Ctx* c, int l, int n_split) {
 template <int DB>
 void launch_attn_out(Ctx* c, int l) {
 	int ntasks = c->dim / Shape<DB>::NR;
-	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->q_dim);
 	const void* wo = c->t->weights.wo[l];
-	by_bool(stage_v4(c->q_dim, 256), [&](auto V4) {
+	by_bool(stage_v4(c->q_dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->q_dim), [&](auto FULL) {
 			hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim);
 		});
@@ -432,9 +443,9 @@ void launch_ffn_up(Ctx* c, int l) {
 	a.eps = p->norm_eps, a.ln = p->norm_ln, a.gelu = p->act_gelu;
 	int nact = c->n_active > 0 ? c->n_active : 1;
 	int ntasks = nact * (c->hidden / (Shape<DB>::NR / 2));
-	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
-	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
+	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			by_bool(c->n_experts > 0, [&](auto MOE) {
 				hipLaunchKernelGGL((k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(MOE)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.w1, a.w3,
@@ -494,9 +505,9 @@ template <int DB>
 void launch_output(Ctx* c) {
 	struct Config* p = &c->t->config;
 	int ntasks = (c->vocab + Shape<DB>::NR - 1) / Shape<DB>::NR;
-	dim3 grid(pick_blocks(ntasks, 4)), block(256);
+	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
-	by_bool(stage_v4(c->dim, 256), [&](auto V4) {
+	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			hipLaunchKernelGGL((k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
 			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);

@@ -649,6 +649,23 @@ __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int 
 	run_rows_impl<DB, NR, U, FULL>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
+// Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
+// workgroup; STAGE_FIRST: a workgroup barrier between the staging loads and the first weight-tile loads, so that every wave's
+// staging loads sit AHEAD of every tile load in the CU's memory queue (with one 512-thread workgroup per CU that is the whole CU).
+#ifndef CALM_WG_THREADS
+#define CALM_WG_THREADS 256
+#endif
+#ifndef CALM_STAGING_FIRST
+#define CALM_STAGING_FIRST 0
+#endif
+constexpr int WG_THREADS = CALM_WG_THREADS, WG_WAVES = WG_THREADS / 64;
+constexpr bool STAGE_FIRST = CALM_STAGING_FIRST != 0;
+__device__ __forceinline__ void stage_first_barrier() {
+	if constexpr (STAGE_FIRST) {
+		__syncthreads();
+	}
+}
+
 // rows per task / tile depth per weight format: 8 x 1 KiB loads in flight per wave in all cases
 template <int DB>
 struct Shape {
@@ -738,7 +755,7 @@ struct QkvArgs {
 // (and copies of the leading ones, which the kernel does not read; the struct itself is never written: a modified by-value
 // struct argument is copied to scratch memory, +4 us per launch when that was tried).
 template <int DB, int KVB, int V, bool FULL>
-__global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
+__global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -764,8 +781,8 @@ __global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w
 		}
 	};
 	StageRegs<V, true> sr;
-	auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
-	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump); };
+	auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
+	auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump); };
 	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
 	// aux = (cos, sin) of each row pair's RoPE angle, fetched before the task's last multiply-add
 	auto aux_of = [&](int t, float(&aux)[NR]) {
@@ -816,7 +833,7 @@ __global__ __launch_bounds__(256) void k_qkv(const float* x, const float* norm_w
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -1500,7 +1517,7 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 
 // ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
 template <int DB, int V, bool FULL>
-__global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
+__global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -1514,8 +1531,8 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 		}
 	};
 	StageRegs<V, false> sr;
-	auto pre = [&]() { stage_load<256>(sr, att, nullptr); };
-	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
+	auto pre = [&]() { stage_load<WG_THREADS>(sr, att, nullptr); stage_first_barrier(); };
+	auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
 	auto aux_of = [&](int t, float(&aux)[NR]) { // the residual values this task adds to
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
@@ -1530,7 +1547,7 @@ __global__ __launch_bounds__(256) void k_attn_out(float* x, const float* att, co
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * 4 + wave_id(), gridDim.x * 4, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
@@ -1556,7 +1573,7 @@ __device__ __forceinline__ float act_gelu(float x) {
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
 template <int DB, int V, bool FULL, bool MOE>
-__global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
+__global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
@@ -1597,9 +1614,9 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 
 	StageRegs<V, true> sr;
 	if constexpr (!MOE) {
-		auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
-		auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+		auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
+		auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
+		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -1610,28 +1627,28 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 	// MoE: the routing decides which rows to stream, so it has to come first.  Every workgroup recomputes the gate
 	// (n_experts short rows, L2-resident after the first workgroup) -- no cross-workgroup hand-off.  What does NOT depend
 	// on the routing is asked for up front: the vector and its norm weight, then the gate rows themselves (they are weights),
-	// so that the norm prologue runs while they fly.  Wave w owns experts w, w + 4, ...; its loads are numbered
+	// so that the norm prologue runs while they fly.  Wave w owns experts w, w + WG_WAVES, ...; its loads are numbered
 	// j = (expert slot i) * chunks + (1-KiB chunk k of the row); the first GP of them are prefetched into registers.
 	constexpr int GP = 8; // (16 measured no better on the 8-expert shape: eight surplus loads per wave ahead of the weight stream)
 	const int nl = dim / Fmt<DB>::G;          // 16-byte lane-loads per row
 	const int chunks = (nl + 63) >> 6;          // wave-loads per row
-	const int per_wave = (n_experts + 3) >> 2; // expert slots of a wave
+	const int per_wave = (n_experts + WG_WAVES - 1) / WG_WAVES; // expert slots of a wave
 	const int total = per_wave * chunks;
 	auto gate_src = [&](int j, int& e, int& k) -> gptr16 {
 		const int i = j / chunks;
 		k = j - i * chunks;
-		e = wave + 4 * i;
+		e = wave + WG_WAVES * i;
 		const int ec = min(e, n_experts - 1), li = min(k * 64 + lane, nl - 1); // always in bounds; masked at use
 		return (gptr16)((const unsigned char*)moegate + (size_t)ec * row_bytes) + li;
 	};
-	stage_load<256>(sr, x, norm_w);
+	stage_load<WG_THREADS>(sr, x, norm_w);
 	u32x4 gw[GP];
 #pragma unroll
 	for (int j = 0; j < GP; ++j) {
 		int e, k;
 		gw[j] = *gate_src(min(j, total - 1), e, k);
 	}
-	stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr);
+	stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr);
 	{
 		f32x2 acc2 = {0.f, 0.f};
 		auto gate_step = [&](u32x4 w, int j) { // multiply-add load j; a row's last chunk reduces and files the logit
@@ -1720,7 +1737,7 @@ __global__ __launch_bounds__(256) void k_ffn_up(const float* x, const float* nor
 		__syncthreads();
 	}
 	auto nothing = [&]() {};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave, gridDim.x * 4, dim, xs4, x, rows_of, nothing, nothing, no_aux, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, nothing, nothing, no_aux, epi);
 }
 
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
@@ -1753,7 +1770,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 			}
 		};
 		StageRegs<V, false> sr;
-		auto pre = [&]() { stage_load<BLOCK>(sr, hk, nullptr); };
+		auto pre = [&]() { stage_load<BLOCK>(sr, hk, nullptr); stage_first_barrier(); };
 		auto stage = [&]() {
 			if (k > 0) {
 				__syncthreads(); // everyone is done reading the previous expert's image
@@ -1780,7 +1797,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 
 // ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
 template <int DB, int V, bool FULL>
-__global__ __launch_bounds__(256) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
+__global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
 	float4* xs4 = (float4*)smem;
@@ -1796,8 +1813,8 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 		}
 	};
 	StageRegs<V, true> sr;
-	auto pre = [&]() { stage_load<256>(sr, x, norm_w); };
-	auto stage = [&]() { stage_finish<DB, 256>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
+	auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
+	auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
 	auto no_aux = [&](int, float(&)[NR]) {};
 	auto epi = [&](int t, float(&acc)[NR], float(&)[NR]) {
 		if (lane == RED_LANE) {
@@ -1809,7 +1826,7 @@ __global__ __launch_bounds__(256) void k_output(float* logits, const float* x, c
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * 4 + wave_id(), gridDim.x * 4, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----

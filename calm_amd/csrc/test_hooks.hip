@@ -41,11 +41,11 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 	HIP_CHECK(hipMemset(dout, 0, d * sizeof(float)));
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		by_bool(stage_v4(n, 256), [&](auto V4) {
+		by_bool(stage_v4(n, WG_THREADS), [&](auto V4) {
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks(d / Shape<DB>::NR, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(d / Shape<DB>::NR)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
 			});
 		});
 	});
@@ -65,11 +65,11 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
 		int ntasks = (d + Shape<DB>::NR - 1) / Shape<DB>::NR;
-		by_bool(stage_v4(n, 256), [&](auto V4) {
+		by_bool(stage_v4(n, WG_THREADS), [&](auto V4) {
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks(ntasks, 4)), dim3(256), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(ntasks)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
 			});
 		});
 	});

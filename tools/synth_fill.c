@@ -11,6 +11,7 @@
  *
  * build: gcc -O3 -fopenmp -fPIC -shared -o tools/libsynth_fill.so tools/synth_fill.c
  */
+#include <omp.h>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -25,7 +26,13 @@ void synth_fill(void* out, size_t n, int kind, const void* lut, uint64_t seed) {
 	const size_t chunk = 1 << 20;
 	const size_t nchunks = (n + chunk - 1) / chunk;
 	long c;
-#pragma omp parallel for schedule(dynamic, 4)
+	/* at most 32 threads, and no more than there are chunks: with the runtime's default team (256 on the GPU hosts) the 291 small
+	 * parallel regions of a model spent 28 s waking and spinning threads for 7 GB of table look-ups (0.3 s of upload behind them) */
+	int team = omp_get_max_threads();
+	team = team > 32 ? 32 : team;
+	team = (size_t)team > nchunks ? (int)nchunks : team;
+	team = team < 1 ? 1 : team;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(team)
 	for (c = 0; c < (long)nchunks; ++c) {
 		uint64_t s = seed * 0x2545f4914f6cdd1dull + (uint64_t)c * 0x9e3779b97f4a7c15ull + 1;
 		size_t a = (size_t)c * chunk, b = a + chunk < n ? a + chunk : n;

@@ -14,11 +14,13 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PRELOAD = "--no-preload" not in sys.argv  # kernel-argument preloading, as the product is built (calm_amd/build.py)
-SO = os.path.join(ROOT, "tools", "libcalm_hip_tl.so" if PRELOAD else "libcalm_hip_tl_nopreload.so")
+DEFS = os.environ.get("TL_DEFS", "").split()  # further -D switches of an A/B variant (TL_TAG names its library)
+TAG = os.environ.get("TL_TAG", "")
+SO = os.path.join(ROOT, "tools", f"libcalm_hip_tl{'_' + TAG if TAG else ''}{'' if PRELOAD else '_nopreload'}.so")
 src = os.path.join(ROOT, "calm_amd", "csrc", "infer_hip.hip")
 deps = [os.path.join(ROOT, "calm_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "calm_amd", "csrc"))]
 if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(d) for d in deps):
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCALM_TIMELINE", *(["-mllvm", "-amdgpu-kernarg-preload-count=14"] if PRELOAD else []),
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DCALM_TIMELINE", *DEFS, *(["-mllvm", "-amdgpu-kernarg-preload-count=14"] if PRELOAD else []),
                     "-shared", "-o", SO, src], check=True)
 if "--build-only" in sys.argv:
     sys.exit(0)
