@@ -79,6 +79,7 @@ int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
+int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_mfma = 0;   // 1: split attention on the matrix cores where the head size is 128 (k_attn_mfma; measured no faster than k_attn_gqa: profiles/r03_long_context.txt)
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
@@ -486,17 +487,28 @@ void launch_ffn_down(Ctx* c, int l) {
 	const int cols = ffn_down_cols<DB>(c->hidden);
 	for (int k0 = 0; k0 < c->hidden; k0 += cols) {
 		const int kn = c->hidden - k0 < cols ? c->hidden - k0 : cols;
-		const bool u7 = ffn_down_u7(kn, DB);
-		int ntasks = c->dim / (u7 ? 2 : Shape<DB>::NR);
+		// tile depth: the format's shape, or 2 rows x 7 / 2 chunks (ffn_down_u7; g_down_u = 2: rows of 4 n + 2 chunks -- hidden 14336
+		// at fp8 = 14 -- walked in exact steps of 2 instead of 4 + 4 + 4 + a half-empty 4)
+		const int chunks = kn / (64 * (128 / DB));
+		const int uo = ffn_down_u7(kn, DB) ? 7 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0);
+		int ntasks = c->dim / (uo ? 2 : Shape<DB>::NR);
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 		size_t lds = lds_bytes<DB>(kn);
+		auto go = [&](auto kern) {
+			hipLaunchKernelGGL(kern, grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
+			                   c->hidden, c->n_active, k0, kn);
+		};
 		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
-			by_bool(u7, [&](auto U7) {
-				by_bool(rows_full<DB>(kn), [&](auto FULL) {
-					hipLaunchKernelGGL((k_ffn_down<DB, BLOCK, decltype(V4)::value ? 4 : 8, decltype(U7)::value, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->he,
-					                   w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim, c->hidden, c->n_active, k0, kn);
-				});
-			});
+			constexpr int V = decltype(V4)::value ? 4 : 8;
+			if (uo == 7) {
+				go(k_ffn_down<DB, BLOCK, V, 7, true>);
+			} else if (uo == 2) {
+				go(k_ffn_down<DB, BLOCK, V, 2, true>);
+			} else if (rows_full<DB>(kn)) {
+				go(k_ffn_down<DB, BLOCK, V, 0, true>);
+			} else {
+				go(k_ffn_down<DB, BLOCK, V, 0, false>);
+			}
 		});
 	}
 }
@@ -1050,12 +1062,14 @@ void set_lds_attrs(Ctx* c) {
 	// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
 	by_bool(true, [&](auto) {
 		size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
-		allow_lds(k_ffn_down<DB, 512, 4, false, false>, big);
-		allow_lds(k_ffn_down<DB, 512, 4, false, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 4, true, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 8, false, false>, big);
-		allow_lds(k_ffn_down<DB, 512, 8, false, true>, big);
-		allow_lds(k_ffn_down<DB, 512, 8, true, true>, big);
+		by_bool(true, [&](auto) {
+			auto all = [&](auto V) {
+				constexpr int v = decltype(V)::value;
+				allow_lds(k_ffn_down<DB, 512, v, 7, true>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true>, big);
+				allow_lds(k_ffn_down<DB, 512, v, 0, true>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false>, big);
+			};
+			all(std::integral_constant<int, 4>()), all(std::integral_constant<int, 8>());
+		});
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
 		if (d > 48 * 1024) {
 			allow_lds(k_qkv<DB, 16, 8, true>, d), allow_lds(k_qkv<DB, 16, 8, false>, d), allow_lds(k_qkv<DB, 8, 8, true>, d), allow_lds(k_qkv<DB, 8, 8, false>, d);
@@ -1100,6 +1114,9 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_attn_waves;
 	} else if (!strcmp(key, "attn_mfma")) {
 		slot = &g_attn_mfma;
+	} else if (!strcmp(key, "down_u")) {
+		slot = &g_down_u;
+
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
 	} else if (!strcmp(key, "pf_attn_mfma")) {

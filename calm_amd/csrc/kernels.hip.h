@@ -1743,16 +1743,22 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 // ---- FFN down + weighted residual:  x += sum_k moe_w[k] * (w2[e_k] . he[k])  (src/infer.c:452-456)
 // Experts are added in rank order (k = 0, 1, ...) by the same lane, so the sum order is the
 // reference's and is deterministic (the CUDA path's atomicAdd, src/infer.cu:618, is not).
-// U7: rows of 7k KiB (hidden 14336 at fp8 = 14 chunks, fp16 = 28, gf4 = 7): tiles of 2 rows x 7 chunks, so a
+// UO (tile depth override): rows whose chunk count the format's tile depth does not divide waste the surplus loads of their last
+// step (a clamped re-read: no HBM bytes, but a slot of the CU's memory queue each).  UO = 2: 2 rows x 2 chunks for fp8 / fp16 rows
+// of 4 n + 2 chunks (hidden 14336 at fp8 = 14: 7 exact steps instead of 4 + 4 + 4 + 2 of 4; Mistral-7B 12.9 -> 12.0 us per launch).
+// UO = 7: rows of 7k KiB (hidden 14336 at fp8 = 14 chunks, fp16 = 28, gf4 = 7): tiles of 2 rows x 7 chunks, so a
 // wave's first two steps -- issued before the prologue -- already cover 28 KiB, the whole task at fp8;
 // the long prologue of this kernel (staging the hidden-sized vector) then hides behind the full stream.
 // k0 / kn: the columns [k0, k0 + kn) of w2 this launch covers.  Normally all of them; a hidden_dim whose fp32 image does not fit
 // the CU's LDS is covered by several launches over whole-KiB column ranges, each adding its partial products onto x.
-template <int DB, int BLOCK, int V, bool U7, bool FULL>
+// (Tried for mixture-of-experts models: asking for expert k + 1's hidden vector while expert k's rows stream, so that a later expert
+// starts with a barrier and LDS stores only -- Mixtral-8x7B 25.0 us per launch against 23.1 without: the eight extra loads per
+// wave sit in the queue ahead of the next tiles.  Not kept.)
+template <int DB, int BLOCK, int V, int UO, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = U7 ? 2 : Shape<DB>::NR, U = U7 ? 7 : Shape<DB>::U;
+	constexpr int NR = UO ? 2 : Shape<DB>::NR, U = UO ? UO : Shape<DB>::U; // UO: tiles of 2 rows x UO chunks instead of the format's shape
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(kn));
