@@ -79,6 +79,7 @@ int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
+int g_down_u4 = 7;     // gf4 rows of 7 chunks: 7 = one 2 x 7 tile per task, else the format's shape
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_mfma = 0;   // 1: split attention on the matrix cores where the head size is 128 (k_attn_mfma; measured no faster than k_attn_gqa: profiles/r03_long_context.txt)
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
@@ -141,7 +142,9 @@ void staged_upload(void* dst, const void* src, size_t size) {
 		HIP_CHECK(hipEventRecord(st.done[b], g_stream));
 		st.busy[b] = true;
 	}
-	// the caller may reuse `src` at once (tests stream tensors through one host buffer): everything has left it already
+	// complete on return, like the hipMemcpy it replaces (src/infer.cu:69-71): a host that runs kernels of its own on another
+	// stream over the uploaded tensor (tools/synth_fill_hip.hip's quantiser) must find it there; the copies WITHIN a tensor overlap
+	HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 
 void* dev_alloc(size_t size) {
@@ -490,7 +493,7 @@ void launch_ffn_down(Ctx* c, int l) {
 		// tile depth: the format's shape, or 2 rows x 7 / 2 chunks (ffn_down_u7; g_down_u = 2: rows of 4 n + 2 chunks -- hidden 14336
 		// at fp8 = 14 -- walked in exact steps of 2 instead of 4 + 4 + 4 + a half-empty 4)
 		const int chunks = kn / (64 * (128 / DB));
-		const int uo = ffn_down_u7(kn, DB) ? 7 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0);
+		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0);
 		int ntasks = c->dim / (uo ? 2 : Shape<DB>::NR);
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 		size_t lds = lds_bytes<DB>(kn);
@@ -1116,6 +1119,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_attn_mfma;
 	} else if (!strcmp(key, "down_u")) {
 		slot = &g_down_u;
+	} else if (!strcmp(key, "down_u4")) {
+		slot = &g_down_u4;
 
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;

@@ -667,10 +667,38 @@ __device__ __forceinline__ void stage_first_barrier() {
 }
 
 // rows per task / tile depth per weight format: 8 x 1 KiB loads in flight per wave in all cases
+#ifndef CALM_GF4_NR
+#define CALM_GF4_NR 4
+#endif
+#ifndef CALM_GF4_U
+#define CALM_GF4_U 2
+#endif
 template <int DB>
 struct Shape {
-	static constexpr int NR = DB == 4 ? 4 : 2;
-	static constexpr int U = DB == 4 ? 2 : 4;
+	static constexpr int NR = DB == 4 ? CALM_GF4_NR : 2;
+	static constexpr int U = DB == 4 ? CALM_GF4_U : 4;
+};
+// ... and the tile DEPTH each kernel walks fp8 / fp16 rows with (gf4 keeps 4 rows x 2 chunks everywhere).  Two tiles are in flight per
+// wave whatever the depth; shallower tiles start multiplying sooner and leave no half-empty last step on rows of 4 n + 2 chunks,
+// deeper ones keep more bytes in flight.  Measured per kernel on the Mistral-7B fp8 shape (profiles/r03_startup_experiments.txt):
+// k_qkv is best at 4 (7.7 us; 8.1-8.4 at 2; 10.0 at 1), k_attn_out at 1 or 2 (5.2-5.3 against 5.9; at 1 DBRX's 6-chunk rows lose:
+// 11.9 against 9.9 us), k_ffn_up and k_output at 2 (20.3 / 21.8 against 21.1 / 22.3).  Whole step, old depths -> these: Mistral-7B
+// fp8 +1.7 %, Mixtral-8x7B +3.1 %, TinyLlama fp16 +2.8 %.  (The CALM_U_* macros are for A/B builds.)
+#ifndef CALM_U_QKV
+#define CALM_U_QKV 4
+#endif
+#ifndef CALM_U_ATTN_OUT
+#define CALM_U_ATTN_OUT 2
+#endif
+#ifndef CALM_U_FFN_UP
+#define CALM_U_FFN_UP 2
+#endif
+#ifndef CALM_U_OUTPUT
+#define CALM_U_OUTPUT 2
+#endif
+template <int DB, int U816>
+struct ShapeU {
+	static constexpr int U = DB == 4 ? CALM_GF4_U : U816;
 };
 
 __device__ __forceinline__ float clipf(float x, float v) {
@@ -757,7 +785,7 @@ struct QkvArgs {
 template <int DB, int KVB, int V, bool FULL>
 __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_QKV>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
 	const int rows_total = q_dim + 2 * kv_dim;
@@ -1519,7 +1547,7 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 template <int DB, int V, bool FULL>
 __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_ATTN_OUT>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(q_dim));
 	const size_t row_bytes = (size_t)q_dim * DB / 8;
@@ -1576,7 +1604,7 @@ template <int DB, int V, bool FULL, bool MOE>
 __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_FFN_UP>::U;
 	constexpr int JP = NR / 2; // hidden units per task
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
@@ -1805,7 +1833,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 template <int DB, int V, bool FULL>
 __global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = Shape<DB>::U;
+	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_OUTPUT>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
 	const size_t row_bytes = (size_t)dim * DB / 8;
