@@ -74,12 +74,13 @@ std::map<const void*, size_t> g_pending_uploads;
 // ... unless the host says where it belongs first: calm_hip_configure("stage", s) routes the following upload_hip / alloc_hip
 // calls to stage s's device at once (-1: back to deferring) -- for hosts that know tensor names, or fill tensors on the device
 int g_alloc_stage = -1;
-int g_bpc = 2;       // cap on resident 256-thread workgroups per CU when sizing grids (measured: 2 beats 3 and 4)
+int g_bpc = 0;       // cap on resident 256-thread workgroups per CU when sizing grids; 0: each kernel's default (2 -- measured: 2 beats 3 and 4 --
+                     // except where kernels.hip.h KShape names another)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
-int g_down_u4 = 7;     // gf4 rows of 7 chunks: 7 = one 2 x 7 tile per task, else the format's shape
+int g_down_u4 = 0;     // gf4 rows of 7 chunks: 7 = one 2 x 7 tile per task (12.8 us on the Llama-3-8B shape), else the kernel's shape (2 x 2: 9.7)
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_mfma = 0;   // 1: split attention on the matrix cores where the head size is 128 (k_attn_mfma; measured no faster than k_attn_gqa: profiles/r03_long_context.txt)
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
@@ -251,14 +252,15 @@ Ctx* ctx_of(struct Transformer* t) {
 // in the last round (rounds * waves / ntasks) and too few waves to keep HBM busy (a wave holds 16 KiB
 // in flight; 4 waves per CU measured latency-bound: gf4 FFN-up ran at 2.6 TB/s on a "perfectly
 // balanced" b = 1 grid) -- so the waste is weighted by (1 + 1/(2b)).
-int pick_blocks(int ntasks, int wpb) {
+int pick_blocks(int ntasks, int wpb, int kernel_bpc = 0) {
+	const int bpc = g_bpc > 0 ? g_bpc : (kernel_bpc > 0 ? kernel_bpc : 2);
 	int need = (ntasks + wpb - 1) / wpb;
-	if (need <= g_ncu * g_bpc) {
+	if (need <= g_ncu * bpc) {
 		return need > 0 ? need : 1;
 	}
 	int best_b = 1;
 	double best = 1e30;
-	for (int b = 1; b <= g_bpc; ++b) {
+	for (int b = 1; b <= bpc; ++b) {
 		long waves = (long)g_ncu * b * wpb;
 		long rounds = (ntasks + waves - 1) / waves;
 		double cost = (double)(rounds * waves) / ntasks * (1.0 + 0.5 / b);
@@ -271,12 +273,12 @@ int pick_blocks(int ntasks, int wpb) {
 }
 
 // the matvec kernels with a dim-sized vector: WG_WAVES waves per workgroup (kernels.hip.h); 512-thread workgroups sit one per CU
-int pick_blocks_wg(int ntasks) {
+int pick_blocks_wg(int ntasks, int kernel_bpc = 0) {
 	const int cap = g_bpc;
 	if (WG_THREADS >= 512) {
 		g_bpc = 1;
 	}
-	const int n = pick_blocks(ntasks, WG_WAVES);
+	const int n = pick_blocks(ntasks, WG_WAVES, kernel_bpc);
 	g_bpc = cap;
 	return n;
 }
@@ -327,8 +329,8 @@ void launch_qkv(Ctx* c, int l) {
 	a.rope_cs = c->rope_cs;
 	a.dim = c->dim, a.q_dim = c->q_dim, a.kv_dim = c->kv_dim, a.head_dim = c->head_dim, a.seq_len = c->seq_len;
 	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
-	int ntasks = (c->q_dim + 2 * c->kv_dim) / Shape<DB>::NR;
-	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
+	int ntasks = (c->q_dim + 2 * c->kv_dim) / KShape<DB, KS_QKV>::NR;
+	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_QKV>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
@@ -421,8 +423,8 @@ void launch_attn(Ctx* c, int l, int n_split) {
 
 template <int DB>
 void launch_attn_out(Ctx* c, int l) {
-	int ntasks = c->dim / Shape<DB>::NR;
-	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
+	int ntasks = c->dim / KShape<DB, KS_ATTN_OUT>::NR;
+	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_ATTN_OUT>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->q_dim);
 	const void* wo = c->t->weights.wo[l];
 	by_bool(stage_v4(c->q_dim, WG_THREADS), [&](auto V4) {
@@ -446,8 +448,8 @@ void launch_ffn_up(Ctx* c, int l) {
 	a.dim = c->dim, a.hidden = c->hidden, a.n_experts = c->n_experts, a.n_active = c->n_active;
 	a.eps = p->norm_eps, a.ln = p->norm_ln, a.gelu = p->act_gelu;
 	int nact = c->n_active > 0 ? c->n_active : 1;
-	int ntasks = nact * (c->hidden / (Shape<DB>::NR / 2));
-	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
+	int ntasks = nact * (c->hidden / (KShape<DB, KS_FFN_UP>::NR / 2));
+	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_FFN_UP>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
@@ -459,9 +461,10 @@ void launch_ffn_up(Ctx* c, int l) {
 	});
 }
 
-// gf4 rows of exactly 7 KiB chunks (hidden 14336) take the 2 x 7 tile shape: one exact step per task instead
-// of four half-empty 4 x 2 steps (measured 15.4 vs 17.9 us).  For fp8 / fp16 rows the 2 x 7 shape measured
-// SLOWER than 2 x 4 (14.0 vs 13.0 us at fp8, 223 VGPRs), so it stays off there.
+// gf4 rows of exactly 7 KiB chunks (hidden 14336) CAN take a 2 x 7 tile shape (knob "down_u4" = 7): one exact step per task.  It
+// was the default until round 3 (15.4 us against 17.9 for four half-empty 4 x 2 steps); tiles of 2 rows x 2 KiB measure 9.7 us
+// against its 12.8 -- with 14-KiB tiles every wave asks for the whole matrix before the hidden vector it needs first
+// (kernels.hip.h KShape).  For fp8 / fp16 rows the 2 x 7 shape measured SLOWER than 2 x 4 (14.0 vs 13.0 us at fp8, 223 VGPRs).
 inline bool ffn_down_u7(int hidden, int dbits) {
 	int nl = hidden / (128 / dbits);
 	return dbits == 4 && nl % 64 == 0 && (nl / 64) % 7 == 0;
@@ -494,7 +497,7 @@ void launch_ffn_down(Ctx* c, int l) {
 		// at fp8 = 14 -- walked in exact steps of 2 instead of 4 + 4 + 4 + a half-empty 4)
 		const int chunks = kn / (64 * (128 / DB));
 		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0);
-		int ntasks = c->dim / (uo ? 2 : Shape<DB>::NR);
+		int ntasks = c->dim / (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR);
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 		size_t lds = lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
@@ -519,8 +522,8 @@ void launch_ffn_down(Ctx* c, int l) {
 template <int DB>
 void launch_output(Ctx* c) {
 	struct Config* p = &c->t->config;
-	int ntasks = (c->vocab + Shape<DB>::NR - 1) / Shape<DB>::NR;
-	dim3 grid(pick_blocks_wg(ntasks)), block(WG_THREADS);
+	int ntasks = (c->vocab + KShape<DB, KS_OUTPUT>::NR - 1) / KShape<DB, KS_OUTPUT>::NR;
+	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_OUTPUT>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {

@@ -661,29 +661,27 @@ __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int 
 constexpr int WG_THREADS = CALM_WG_THREADS, WG_WAVES = WG_THREADS / 64;
 constexpr bool STAGE_FIRST = CALM_STAGING_FIRST != 0;
 __device__ __forceinline__ void stage_first_barrier() {
-	if constexpr (STAGE_FIRST) {
+	if constexpr (CALM_STAGING_FIRST == 2) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // A/B: the vector has LANDED before the first tile is asked for
+	} else if constexpr (STAGE_FIRST) {
 		__syncthreads();
 	}
 }
 
-// rows per task / tile depth per weight format: 8 x 1 KiB loads in flight per wave in all cases
-#ifndef CALM_GF4_NR
-#define CALM_GF4_NR 4
-#endif
-#ifndef CALM_GF4_U
-#define CALM_GF4_U 2
-#endif
-template <int DB>
-struct Shape {
-	static constexpr int NR = DB == 4 ? CALM_GF4_NR : 2;
-	static constexpr int U = DB == 4 ? CALM_GF4_U : 4;
-};
-// ... and the tile DEPTH each kernel walks fp8 / fp16 rows with (gf4 keeps 4 rows x 2 chunks everywhere).  Two tiles are in flight per
-// wave whatever the depth; shallower tiles start multiplying sooner and leave no half-empty last step on rows of 4 n + 2 chunks,
-// deeper ones keep more bytes in flight.  Measured per kernel on the Mistral-7B fp8 shape (profiles/r03_startup_experiments.txt):
-// k_qkv is best at 4 (7.7 us; 8.1-8.4 at 2; 10.0 at 1), k_attn_out at 1 or 2 (5.2-5.3 against 5.9; at 1 DBRX's 6-chunk rows lose:
-// 11.9 against 9.9 us), k_ffn_up and k_output at 2 (20.3 / 21.8 against 21.1 / 22.3).  Whole step, old depths -> these: Mistral-7B
-// fp8 +1.7 %, Mixtral-8x7B +3.1 %, TinyLlama fp16 +2.8 %.  (The CALM_U_* macros are for A/B builds.)
+// Tile shape per kernel and weight format: NR rows per task x U 1-KiB chunks of each per step, two tiles in flight per wave.
+// Shallower tiles start multiplying sooner, put fewer weight bytes ahead of the activation vector in the start-up burst (every wave
+// asks for its first two tiles before it builds the LDS image: with 8-KiB tiles that is 32 MB chip-wide, which takes 4-5 us to
+// deliver and the vector arrives inside it) and leave no half-empty last step on rows of 4 n + 2 chunks; deeper ones keep more
+// bytes in flight, more rows share one read of the image.
+//   fp8 / fp16 (2 rows; Mistral-7B fp8 shape, profiles/r03_startup_experiments.txt): k_qkv is best at 4 chunks (7.7 us; 8.1-8.4 at
+//     2; 10.0 at 1), k_attn_out at 1 or 2 (5.2-5.3 against 5.9; at 1 DBRX's 6-chunk rows lose: 11.9 against 9.9 us), k_ffn_up and
+//     k_output at 2 (20.3 / 21.8 against 21.1 / 22.3); k_ffn_down: 2 on rows of 4 n + 2 chunks (infer_hip.hip), else 4.
+//   gf4 (Llama-3-8B shape, profiles/r03_gf4_tables.txt; rows x chunks -> us): its kernels move half the bytes, so the start-up
+//     burst weighs twice as much.  k_qkv 4x2 8.6, 4x1 7.9, 2x2 6.8, 2x1 7.3-8.2; k_attn_out 4.9, 4.7, 4.5, 4.45; k_ffn_up 15.5, 13.9,
+//     15.8, 14.9-16.5; k_ffn_down (7-chunk rows) 2x7 12.8, 4x2 14.2, 4x1 13.5, 2x2 9.7, 2x1 10.0; k_output (up to 4 workgroups per CU)
+//     48.9, 45.2, 44.2, 47.2.
+// (The CALM_* macros are for A/B builds.)
+enum KernelId { KS_QKV, KS_ATTN_OUT, KS_FFN_UP, KS_FFN_DOWN, KS_OUTPUT };
 #ifndef CALM_U_QKV
 #define CALM_U_QKV 4
 #endif
@@ -696,9 +694,39 @@ struct Shape {
 #ifndef CALM_U_OUTPUT
 #define CALM_U_OUTPUT 2
 #endif
-template <int DB, int U816>
-struct ShapeU {
-	static constexpr int U = DB == 4 ? CALM_GF4_U : U816;
+#ifndef CALM_GF4_QKV
+#define CALM_GF4_QKV 2, 2
+#endif
+#ifndef CALM_GF4_ATTN_OUT
+#define CALM_GF4_ATTN_OUT 2, 1
+#endif
+#ifndef CALM_GF4_FFN_UP
+#define CALM_GF4_FFN_UP 4, 1
+#endif
+#ifndef CALM_GF4_FFN_DOWN
+#define CALM_GF4_FFN_DOWN 2, 2
+#endif
+#ifndef CALM_GF4_OUTPUT
+#define CALM_GF4_OUTPUT 2, 2
+#endif
+#ifndef CALM_GF4_OUTPUT_BPC
+#define CALM_GF4_OUTPUT_BPC 4
+#endif
+template <int NR_, int U_>
+struct ShapeOf {
+	static constexpr int NR = NR_, U = U_;
+};
+template <int DB, int K>
+struct KShape {
+	using S = std::conditional_t<DB != 4,
+	                             ShapeOf<2, K == KS_QKV ? CALM_U_QKV : (K == KS_ATTN_OUT ? CALM_U_ATTN_OUT : (K == KS_FFN_UP ? CALM_U_FFN_UP : (K == KS_OUTPUT ? CALM_U_OUTPUT : 4)))>,
+	                             std::conditional_t<K == KS_QKV, ShapeOf<CALM_GF4_QKV>,
+	                                                std::conditional_t<K == KS_ATTN_OUT, ShapeOf<CALM_GF4_ATTN_OUT>,
+	                                                                   std::conditional_t<K == KS_FFN_UP, ShapeOf<CALM_GF4_FFN_UP>,
+	                                                                                      std::conditional_t<K == KS_FFN_DOWN, ShapeOf<CALM_GF4_FFN_DOWN>, ShapeOf<CALM_GF4_OUTPUT>>>>>>;
+	static constexpr int NR = S::NR, U = S::U;
+	// resident 256-thread workgroups per CU the kernel's grid is sized for, when the "bpc" knob is at its default (0: the default)
+	static constexpr int BPC = (DB == 4 && K == KS_OUTPUT) ? CALM_GF4_OUTPUT_BPC : 0;
 };
 
 __device__ __forceinline__ float clipf(float x, float v) {
@@ -785,7 +813,7 @@ struct QkvArgs {
 template <int DB, int KVB, int V, bool FULL>
 __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_QKV>::U;
+	constexpr int NR = KShape<DB, KS_QKV>::NR, U = KShape<DB, KS_QKV>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
 	const int rows_total = q_dim + 2 * kv_dim;
@@ -1547,7 +1575,7 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 template <int DB, int V, bool FULL>
 __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_ATTN_OUT>::U;
+	constexpr int NR = KShape<DB, KS_ATTN_OUT>::NR, U = KShape<DB, KS_ATTN_OUT>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(q_dim));
 	const size_t row_bytes = (size_t)q_dim * DB / 8;
@@ -1604,7 +1632,7 @@ template <int DB, int V, bool FULL, bool MOE>
 __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_FFN_UP>::U;
+	constexpr int NR = KShape<DB, KS_FFN_UP>::NR, U = KShape<DB, KS_FFN_UP>::U;
 	constexpr int JP = NR / 2; // hidden units per task
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
@@ -1786,7 +1814,7 @@ template <int DB, int BLOCK, int V, int UO, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = UO ? 2 : Shape<DB>::NR, U = UO ? UO : Shape<DB>::U; // UO: tiles of 2 rows x UO chunks instead of the format's shape
+	constexpr int NR = UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR, U = UO ? UO : KShape<DB, KS_FFN_DOWN>::U; // UO: tiles of 2 rows x UO chunks instead of the format's shape
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(kn));
@@ -1833,7 +1861,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 template <int DB, int V, bool FULL>
 __global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = Shape<DB>::NR, U = ShapeU<DB, CALM_U_OUTPUT>::U;
+	constexpr int NR = KShape<DB, KS_OUTPUT>::NR, U = KShape<DB, KS_OUTPUT>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
 	const size_t row_bytes = (size_t)dim * DB / 8;

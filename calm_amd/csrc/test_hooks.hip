@@ -45,7 +45,7 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(d / Shape<DB>::NR)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(d / KShape<DB, KS_ATTN_OUT>::NR)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
 			});
 		});
 	});
@@ -64,7 +64,7 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 	float* dout = (float*)dev_alloc(d * sizeof(float));
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		int ntasks = (d + Shape<DB>::NR - 1) / Shape<DB>::NR;
+		int ntasks = (d + KShape<DB, KS_OUTPUT>::NR - 1) / KShape<DB, KS_OUTPUT>::NR;
 		by_bool(stage_v4(n, WG_THREADS), [&](auto V4) {
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;

@@ -158,7 +158,7 @@ const char* calm_hip_device_name(void);
 /* Run-time knobs (same as the CALM_HIP_* environment variables read by init_hip):
  *   "graph"   1 = replay each step from a hipGraph (default), 0 = eager launches
  *   "prof"    1 = eager launches bracketed by per-stage events, reported by perf_hip
- *   "bpc"     cap on resident 256-thread workgroups per CU when sizing grids (default 2)
+ *   "bpc"     cap on resident 256-thread workgroups per CU when sizing grids (default 0: each kernel's own -- 2, the gf4 classifier 4)
  *   "split_t" cached positions per attention KV split (default 128)
  *   "split_min" contexts up to this many positions are not split (default 384)
  * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.
