@@ -81,6 +81,9 @@ int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
 int g_down_u4 = 0;     // gf4 rows of 7 chunks: 7 = one 2 x 7 tile per task (12.8 us on the Llama-3-8B shape), else the kernel's shape (2 x 2: 9.7)
+int g_qkv_half = 0;    // k_qkv tiles half as deep: 0 = when a wave's share of the matrix is less than one tile (launch_qkv), 1 = always, 2 = never
+int g_out_one = 0;     // k_attn_out one row per task: 0 = by the same rule (rows_balance_one), 1 = always, 2 = never
+int g_down_one = 0;    // k_ffn_down one row per task: 0 = when row pairs would leave a full grid's last round markedly emptier (rows_balance_one), 1 = always, 2 = never
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_mfma = 0;   // 1: split attention on the matrix cores where the head size is 128 (k_attn_mfma; measured no faster than k_attn_gqa: profiles/r03_long_context.txt)
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
@@ -332,9 +335,16 @@ void launch_qkv(Ctx* c, int l) {
 	int ntasks = (c->q_dim + 2 * c->kv_dim) / KShape<DB, KS_QKV>::NR;
 	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_QKV>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
+	// a matrix so small that a wave's share of it (all 2 x 4 x ncu waves of a full grid) is less than one tile is walked in tiles half as
+	// deep: the wave starts multiplying after half the bytes
+	const size_t per_wave = (size_t)(c->q_dim + 2 * c->kv_dim) * c->dim * DB / 8 / ((size_t)g_ncu * 2 * WG_WAVES);
+	const bool half = g_qkv_half ? g_qkv_half == 1 : per_wave < (size_t)KShape<DB, KS_QKV>::NR * KShape<DB, KS_QKV>::U * 1024;
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.dim, a.q_dim, a.kv_dim, a);
+			by_bool(half, [&](auto HALF) {
+				hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(HALF)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.dim, a.q_dim,
+				                   a.kv_dim, a);
+			});
 		});
 	});
 }
@@ -421,15 +431,32 @@ void launch_attn(Ctx* c, int l, int n_split) {
 	}
 }
 
+// Should a matrix of `rows` rows be walked ONE row per task instead of `nr` (2)?  Yes when the row groups leave the last round of a
+// full grid (`waves` waves) markedly emptier than single rows would: DBRX's 6144 rows are 3072 pairs = 1.5 rounds of 2048 waves
+// (a quarter of the wave-slots idle) but exactly 3 rounds of single rows; TinyLlama's 2048 rows are half a round of pairs.
+inline bool rows_balance_one(int rows, int nr, int waves, int knob) {
+	if (knob) {
+		return knob == 1;
+	}
+	auto eff = [&](int n) {
+		const int tasks = rows / n, rounds = (tasks + waves - 1) / waves;
+		return (double)tasks / ((double)rounds * waves);
+	};
+	return nr > 1 && eff(1) > eff(nr) + 0.1;
+}
+
 template <int DB>
 void launch_attn_out(Ctx* c, int l) {
-	int ntasks = c->dim / KShape<DB, KS_ATTN_OUT>::NR;
+	const bool one = rows_balance_one(c->dim, KShape<DB, KS_ATTN_OUT>::NR, g_ncu * 2 * WG_WAVES, g_out_one);
+	int ntasks = c->dim / (one ? 1 : KShape<DB, KS_ATTN_OUT>::NR);
 	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_ATTN_OUT>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->q_dim);
 	const void* wo = c->t->weights.wo[l];
 	by_bool(stage_v4(c->q_dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->q_dim), [&](auto FULL) {
-			hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim);
+			by_bool(one, [&](auto ONE) {
+				hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(ONE)::value>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim);
+			});
 		});
 	});
 }
@@ -496,8 +523,10 @@ void launch_ffn_down(Ctx* c, int l) {
 		// tile depth: the format's shape, or 2 rows x 7 / 2 chunks (ffn_down_u7; g_down_u = 2: rows of 4 n + 2 chunks -- hidden 14336
 		// at fp8 = 14 -- walked in exact steps of 2 instead of 4 + 4 + 4 + a half-empty 4)
 		const int chunks = kn / (64 * (128 / DB));
-		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0);
-		int ntasks = c->dim / (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR);
+		// ... or ONE row x 4 chunks when the matrix has fewer row pairs than a full grid has waves (half of them would get no task)
+		const bool few_rows = rows_balance_one(c->dim, 2, g_ncu * (BLOCK / 64), g_down_one);
+		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : (few_rows ? 1 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0));
+		int ntasks = c->dim / (uo == 1 ? 1 : (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 		size_t lds = lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
@@ -508,6 +537,10 @@ void launch_ffn_down(Ctx* c, int l) {
 			constexpr int V = decltype(V4)::value ? 4 : 8;
 			if (uo == 7) {
 				go(k_ffn_down<DB, BLOCK, V, 7, true>);
+			} else if (uo == 1 && rows_full<DB>(kn)) {
+				go(k_ffn_down<DB, BLOCK, V, 1, true>);
+			} else if (uo == 1) {
+				go(k_ffn_down<DB, BLOCK, V, 1, false>);
 			} else if (uo == 2) {
 				go(k_ffn_down<DB, BLOCK, V, 2, true>);
 			} else if (rows_full<DB>(kn)) {
@@ -1071,15 +1104,16 @@ void set_lds_attrs(Ctx* c) {
 		by_bool(true, [&](auto) {
 			auto all = [&](auto V) {
 				constexpr int v = decltype(V)::value;
-				allow_lds(k_ffn_down<DB, 512, v, 7, true>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true>, big);
+				allow_lds(k_ffn_down<DB, 512, v, 7, true>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true>, big), allow_lds(k_ffn_down<DB, 512, v, 1, false>, big);
 				allow_lds(k_ffn_down<DB, 512, v, 0, true>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false>, big);
 			};
 			all(std::integral_constant<int, 4>()), all(std::integral_constant<int, 8>());
 		});
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
 		if (d > 48 * 1024) {
-			allow_lds(k_qkv<DB, 16, 8, true>, d), allow_lds(k_qkv<DB, 16, 8, false>, d), allow_lds(k_qkv<DB, 8, 8, true>, d), allow_lds(k_qkv<DB, 8, 8, false>, d);
-			allow_lds(k_attn_out<DB, 8, true>, d), allow_lds(k_attn_out<DB, 8, false>, d);
+			allow_lds(k_qkv<DB, 16, 8, true, false>, d), allow_lds(k_qkv<DB, 16, 8, false, false>, d), allow_lds(k_qkv<DB, 8, 8, true, false>, d), allow_lds(k_qkv<DB, 8, 8, false, false>, d);
+			allow_lds(k_qkv<DB, 16, 8, true, true>, d), allow_lds(k_qkv<DB, 16, 8, false, true>, d), allow_lds(k_qkv<DB, 8, 8, true, true>, d), allow_lds(k_qkv<DB, 8, 8, false, true>, d);
+			allow_lds(k_attn_out<DB, 8, true, false>, d), allow_lds(k_attn_out<DB, 8, false, false>, d), allow_lds(k_attn_out<DB, 8, true, true>, d), allow_lds(k_attn_out<DB, 8, false, true>, d);
 			allow_lds(k_ffn_up<DB, 8, true, true>, d), allow_lds(k_ffn_up<DB, 8, true, false>, d), allow_lds(k_ffn_up<DB, 8, false, true>, d), allow_lds(k_ffn_up<DB, 8, false, false>, d);
 			allow_lds(k_output<DB, 8, true>, d), allow_lds(k_output<DB, 8, false>, d);
 		}
@@ -1124,6 +1158,12 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_down_u;
 	} else if (!strcmp(key, "down_u4")) {
 		slot = &g_down_u4;
+	} else if (!strcmp(key, "qkv_half")) {
+		slot = &g_qkv_half;
+	} else if (!strcmp(key, "down_one")) {
+		slot = &g_down_one;
+	} else if (!strcmp(key, "out_one")) {
+		slot = &g_out_one;
 
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;

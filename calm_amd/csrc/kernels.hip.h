@@ -458,18 +458,19 @@ struct Tile {
 };
 
 // FULL: every row is a whole number of 1-KiB wave-loads (nl % 64 == 0), so no lane is ever masked.
-// Loads are always issued.  FULL rows clamp surplus chunks of a row's last step to the row's last KiB;
-// ragged rows (!FULL) may run up to U KiB past the row's end (into the next row, or into the DEV_PAD
-// slack behind the tensor) and zero that data in tile_fma.
+// Loads are always issued.  Surplus chunks of a row's last step are clamped to the row's last chunk (a cache hit instead of the
+// next row's first KiBs from HBM a second time: DBRX's 10.5-KiB w2 rows walked 4 chunks at a time asked for 12 KiB each);
+// a ragged row's (!FULL) last chunk runs up to 1 KiB past the row's end (into the next row, or into the DEV_PAD
+// slack behind the tensor) and tile_fma zeroes that data.
 template <int DB, int NR, int U, bool FULL>
 __device__ __forceinline__ void tile_load(Tile<NR, U>& t, const unsigned char* const (&rows)[NR], int k0, int nl, int lane) {
 #pragma unroll
 	for (int u = 0; u < U; ++u) {
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
-			// FULL: clamp the (wave-uniform) chunk index into the row -- a surplus chunk re-reads the row's
+			// clamp the (wave-uniform) chunk index into the row -- a surplus chunk re-reads the row's
 			// last KiB (cache hit) instead of pulling the next row's first KiB from HBM a second time
-			const int c = FULL ? min(k0 + u, (nl >> 6) - 1) : k0 + u;
+			const int c = min(k0 + u, ((nl + 63) >> 6) - 1);
 			t.w[u][r] = __builtin_nontemporal_load((gptr16)rows[r] + c * 64 + lane);
 		}
 	}
@@ -682,17 +683,35 @@ __device__ __forceinline__ void stage_first_barrier() {
 //     48.9, 45.2, 44.2, 47.2.
 // (The CALM_* macros are for A/B builds.)
 enum KernelId { KS_QKV, KS_ATTN_OUT, KS_FFN_UP, KS_FFN_DOWN, KS_OUTPUT };
-#ifndef CALM_U_QKV
-#define CALM_U_QKV 4
+#ifndef CALM_F8_QKV
+#define CALM_F8_QKV 2, 4
 #endif
-#ifndef CALM_U_ATTN_OUT
-#define CALM_U_ATTN_OUT 2
+#ifndef CALM_F8_ATTN_OUT
+#define CALM_F8_ATTN_OUT 2, 2
 #endif
-#ifndef CALM_U_FFN_UP
-#define CALM_U_FFN_UP 2
+#ifndef CALM_F8_FFN_UP
+#define CALM_F8_FFN_UP 2, 2
 #endif
-#ifndef CALM_U_OUTPUT
-#define CALM_U_OUTPUT 2
+#ifndef CALM_F8_FFN_DOWN
+#define CALM_F8_FFN_DOWN 2, 4
+#endif
+#ifndef CALM_F8_OUTPUT
+#define CALM_F8_OUTPUT 2, 2
+#endif
+#ifndef CALM_F16_QKV
+#define CALM_F16_QKV 2, 4
+#endif
+#ifndef CALM_F16_ATTN_OUT
+#define CALM_F16_ATTN_OUT 2, 2
+#endif
+#ifndef CALM_F16_FFN_UP
+#define CALM_F16_FFN_UP 2, 2
+#endif
+#ifndef CALM_F16_FFN_DOWN
+#define CALM_F16_FFN_DOWN 2, 4
+#endif
+#ifndef CALM_F16_OUTPUT
+#define CALM_F16_OUTPUT 2, 2
 #endif
 #ifndef CALM_GF4_QKV
 #define CALM_GF4_QKV 2, 2
@@ -712,21 +731,26 @@ enum KernelId { KS_QKV, KS_ATTN_OUT, KS_FFN_UP, KS_FFN_DOWN, KS_OUTPUT };
 #ifndef CALM_GF4_OUTPUT_BPC
 #define CALM_GF4_OUTPUT_BPC 4
 #endif
+#ifndef CALM_F8_OUTPUT_BPC
+#define CALM_F8_OUTPUT_BPC 0
+#endif
+#ifndef CALM_F16_OUTPUT_BPC
+#define CALM_F16_OUTPUT_BPC 0
+#endif
 template <int NR_, int U_>
 struct ShapeOf {
 	static constexpr int NR = NR_, U = U_;
 };
+template <int K, class Q, class A, class F, class D, class O>
+using ShapePick = std::conditional_t<K == KS_QKV, Q, std::conditional_t<K == KS_ATTN_OUT, A, std::conditional_t<K == KS_FFN_UP, F, std::conditional_t<K == KS_FFN_DOWN, D, O>>>>;
 template <int DB, int K>
 struct KShape {
-	using S = std::conditional_t<DB != 4,
-	                             ShapeOf<2, K == KS_QKV ? CALM_U_QKV : (K == KS_ATTN_OUT ? CALM_U_ATTN_OUT : (K == KS_FFN_UP ? CALM_U_FFN_UP : (K == KS_OUTPUT ? CALM_U_OUTPUT : 4)))>,
-	                             std::conditional_t<K == KS_QKV, ShapeOf<CALM_GF4_QKV>,
-	                                                std::conditional_t<K == KS_ATTN_OUT, ShapeOf<CALM_GF4_ATTN_OUT>,
-	                                                                   std::conditional_t<K == KS_FFN_UP, ShapeOf<CALM_GF4_FFN_UP>,
-	                                                                                      std::conditional_t<K == KS_FFN_DOWN, ShapeOf<CALM_GF4_FFN_DOWN>, ShapeOf<CALM_GF4_OUTPUT>>>>>>;
+	using S = std::conditional_t<DB == 4, ShapePick<K, ShapeOf<CALM_GF4_QKV>, ShapeOf<CALM_GF4_ATTN_OUT>, ShapeOf<CALM_GF4_FFN_UP>, ShapeOf<CALM_GF4_FFN_DOWN>, ShapeOf<CALM_GF4_OUTPUT>>,
+	                             std::conditional_t<DB == 8, ShapePick<K, ShapeOf<CALM_F8_QKV>, ShapeOf<CALM_F8_ATTN_OUT>, ShapeOf<CALM_F8_FFN_UP>, ShapeOf<CALM_F8_FFN_DOWN>, ShapeOf<CALM_F8_OUTPUT>>,
+	                                                ShapePick<K, ShapeOf<CALM_F16_QKV>, ShapeOf<CALM_F16_ATTN_OUT>, ShapeOf<CALM_F16_FFN_UP>, ShapeOf<CALM_F16_FFN_DOWN>, ShapeOf<CALM_F16_OUTPUT>>>>;
 	static constexpr int NR = S::NR, U = S::U;
-	// resident 256-thread workgroups per CU the kernel's grid is sized for, when the "bpc" knob is at its default (0: the default)
-	static constexpr int BPC = (DB == 4 && K == KS_OUTPUT) ? CALM_GF4_OUTPUT_BPC : 0;
+	// resident 256-thread workgroups per CU the kernel's grid is sized for while the "bpc" knob is 0 (0 here: the common default, 2)
+	static constexpr int BPC = K != KS_OUTPUT ? 0 : (DB == 4 ? CALM_GF4_OUTPUT_BPC : (DB == 8 ? CALM_F8_OUTPUT_BPC : CALM_F16_OUTPUT_BPC));
 };
 
 __device__ __forceinline__ float clipf(float x, float v) {
@@ -810,10 +834,12 @@ struct QkvArgs {
 // wave instead of the wave fetching them from memory -- a round trip at the head of every launch.  The struct carries the rest
 // (and copies of the leading ones, which the kernel does not read; the struct itself is never written: a modified by-value
 // struct argument is copied to scratch memory, +4 us per launch when that was tried).
-template <int DB, int KVB, int V, bool FULL>
+// HALF: tiles half as deep -- for matrices so small that a wave's share is less than one full tile (TinyLlama's 10.5 MB at fp16: 6.3 ->
+// 5.45 us; the host decides, launch_qkv)
+template <int DB, int KVB, int V, bool FULL, bool HALF>
 __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = KShape<DB, KS_QKV>::NR, U = KShape<DB, KS_QKV>::U;
+	constexpr int NR = KShape<DB, KS_QKV>::NR, U = (HALF && KShape<DB, KS_QKV>::U > 1) ? KShape<DB, KS_QKV>::U / 2 : KShape<DB, KS_QKV>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
 	const int rows_total = q_dim + 2 * kv_dim;
@@ -1572,10 +1598,15 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 }
 
 // ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
-template <int DB, int V, bool FULL>
+// ONE: one row per task (tiles of the same size: twice as deep) -- for row counts that leave a full grid's last round of row PAIRS
+// half empty (DBRX's 6144 rows = 3072 pairs over 2048 waves; the host decides: rows_balance)
+#ifndef CALM_ONE_U
+#define CALM_ONE_U 2
+#endif
+template <int DB, int V, bool FULL, bool ONE>
 __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = KShape<DB, KS_ATTN_OUT>::NR, U = KShape<DB, KS_ATTN_OUT>::U;
+	constexpr int NR = ONE ? 1 : KShape<DB, KS_ATTN_OUT>::NR, U = ONE ? CALM_ONE_U * KShape<DB, KS_ATTN_OUT>::U : KShape<DB, KS_ATTN_OUT>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(q_dim));
 	const size_t row_bytes = (size_t)q_dim * DB / 8;
@@ -1814,7 +1845,9 @@ template <int DB, int BLOCK, int V, int UO, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	constexpr int NR = UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR, U = UO ? UO : KShape<DB, KS_FFN_DOWN>::U; // UO: tiles of 2 rows x UO chunks instead of the format's shape
+	// UO: tiles of 2 rows x UO chunks instead of the format's shape; UO = 1: ONE row x 4 chunks, for matrices of fewer row pairs than
+	// the chip has waves (TinyLlama's 2048 rows: 7.9 -> 6.6 us)
+	constexpr int NR = UO == 1 ? 1 : (UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR), U = UO == 1 ? 4 : (UO ? UO : KShape<DB, KS_FFN_DOWN>::U);
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(kn));

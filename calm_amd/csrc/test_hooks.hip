@@ -43,7 +43,7 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 		constexpr int DB = decltype(DBT)::value;
 		by_bool(stage_v4(n, WG_THREADS), [&](auto V4) {
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
-				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
+				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, false>;
 				allow_lds(k, lds_bytes<DB>(n));
 				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(d / KShape<DB, KS_ATTN_OUT>::NR)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
 			});

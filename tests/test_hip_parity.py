@@ -180,6 +180,26 @@ def test_golden_logits_teacher_forced(hiplib, case, graph):
         hiplib.calm_hip_configure(b"graph", 1)
 
 
+@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4", "moe_gf4", "dbrx_like_fp8"])
+def test_alternative_tile_shapes_give_the_reference_logits(hiplib, case):
+    """the tile shapes the launchers pick by matrix size (k_qkv half-depth tiles for small matrices, one row per task in k_attn_out /
+    k_ffn_down when row pairs would leave a grid's last round half empty, gf4's old 2 x 7 shape) forced on: same logits"""
+    if case not in GOLDEN_CASES:
+        pytest.skip("no such golden case")
+    model, z = load_golden(case)
+    knobs = {b"qkv_half": 1, b"out_one": 1, b"down_one": 1}
+    for k, v in knobs.items():
+        assert hiplib.calm_hip_configure(k, v) == 0  # 0 = "by the rule" is the default
+    b = HipBackend(model)
+    try:
+        for pos, tok in enumerate(z["tokens"]):
+            assert rel_err(b.forward(int(tok), pos, 0), z["logits"][pos]) < LOGIT_TOL, pos
+    finally:
+        b.close()
+        for k in knobs:
+            hiplib.calm_hip_configure(k, 0)
+
+
 @pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4"])
 def test_greedy_stream_identical_and_device_decode_agrees(hiplib, case):
     """free-running greedy decode: forward_hip + host argmax, generate(), and the device-side
