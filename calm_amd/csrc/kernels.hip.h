@@ -987,7 +987,15 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const TokState* ts, const floa
 			vw[u] = *(const Raw*)(vbase + (size_t)t * rstride);
 		}
 	};
+#ifdef CALM_TIMELINE
+	unsigned long long tl[6];
+	tl[0] = wall_clock64();
+#endif
 	const int kv_len = ts->kv_len;
+#ifdef CALM_TIMELINE
+	asm volatile("" ::"s"(kv_len));
+	tl[1] = wall_clock64(); // the cache length is known
+#endif
 	load_round(wave * RPW, kv_len - 1);
 
 	float qv[8];
@@ -1070,6 +1078,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const TokState* ts, const floa
 		}
 	}
 
+#ifdef CALM_TIMELINE
+	asm volatile("" ::"v"(o[0]), "v"(l));
+	tl[2] = wall_clock64(); // the wave's positions are folded in
+#endif
 	// merge the RPW lane groups of the wave
 #pragma unroll
 	for (int ofs = LPR; ofs < 64; ofs <<= 1) {
@@ -1093,7 +1105,14 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const TokState* ts, const floa
 			}
 		}
 	}
+#ifdef CALM_TIMELINE
+	asm volatile("" ::"v"(o[0]), "v"(l));
+	tl[3] = wall_clock64(); // lane groups merged, partials in LDS
+#endif
 	__syncthreads();
+#ifdef CALM_TIMELINE
+	tl[4] = wall_clock64(); // every wave is here
+#endif
 	// Merge the NW wave partials with one THREAD per output dim: the weights exp(m_w - M) are recomputed by every
 	// thread (NW exps), then one pass over the partials -- all of it parallel over head_dim threads.  (One lane group
 	// folding the waves in one after the other was a chain of NW dependent exp + rescale steps: ~1 us of this kernel.)
@@ -1112,6 +1131,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const TokState* ts, const floa
 		}
 		a.out[h * head_dim + d] = O / L;
 	}
+#ifdef CALM_TIMELINE
+	{
+		tl[5] = wall_clock64();
+		const unsigned w = blockIdx.x * NW + wave;
+		if (lane == 0 && calm_tl_buf && w < calm_tl_waves) {
+			unsigned long long* ob = calm_tl_buf + (size_t)w * 8;
+			ob[0] = tl[0], ob[1] = tl[1], ob[2] = tl[2], ob[3] = tl[5], ob[4] = tl[3], ob[5] = tl[4];
+		}
+	}
+#endif
 }
 
 // Long-context attention: one workgroup (4 waves) per (kv head, group of QH query heads, kv split).

@@ -7,9 +7,10 @@
 #  3. bench lines of the other BASELINE shapes at full size, each WITH its CPU leg and parity (host copy of the model: 46.7 GB for
 #     Mixtral-8x7B, 131.6 GB for DBRX-132B); DBRX also as a 4-stage pipeline in one process (config 5's partitioning on one GPU)
 #  4. the reference CLI on this backend, first 32 / last 32 positions of a 4096 context (CALM_POSO), full 32-layer Mistral shape
+#  5. PMC counters of the gf4 kernels (tools/pmc_kernel.sh)
 #  SECTIONS="1 2 3" selects (default: all)
 TAG=${1:-r03}
-SECTIONS=${SECTIONS:-"0 2 1 3 4"}
+SECTIONS=${SECTIONS:-"0 2 1 3 4 5"}
 want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
@@ -60,5 +61,10 @@ if [ -x oracle/_ref/run_hip ]; then
   done
   rm -f /tmp/mistral7b_fp8.calm
 fi
+fi
+if want 5; then
+echo "== 5. counters of the gf4 kernels (Llama-3-8B shape, 8 layers; three separate passes)" | tee -a $OUT/summary.txt
+bash tools/pmc_kernel.sh ${TAG}_pmc_gf4 llama-3-8b gf4 8 > $OUT/pmc_gf4.log 2>&1
+cp gpurun_out/${TAG}_pmc_gf4/summary.txt $OUT/pmc_gf4_tables.txt 2>/dev/null; tail -12 $OUT/pmc_gf4_tables.txt | cut -c1-400 >> $OUT/summary.txt
 fi
 cat $OUT/summary.txt

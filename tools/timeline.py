@@ -48,6 +48,18 @@ print(f"{name} {dtype} L={L}; us after the launch's first wave started; stage ti
 print(f"{'kernel':9s} {'us/launch':>9s} {'waves':>6s} | last wave start | image built p50 / max | first tile done p50 / max | exits p1 / p10 / p50 / p90 / p99 / last")
 for i, st in enumerate(STAGES):
     if st == "attn":
+        # k_attn (contexts up to 384 positions): entry / cache length known / positions folded in / lane groups merged / barrier / exit
+        lib.calm_tl_arm(waves)
+        us, _ = b.stage_us(i, 2)
+        buf = np.zeros((waves, 8), dtype=np.uint64)
+        lib.calm_tl_read(buf.ctypes.data, waves)
+        t = buf.astype(np.int64) * 10
+        a = t[t[:, 3] > 0]
+        t0 = a[:, 0].min()
+        col = lambda k: (a[:, k] - t0) / 1e3
+        med = lambda k: float(np.median(col(k)))
+        print(f"{st:9s} {us:9.2f} {len(a):6d} | last wave start {col(0).max():5.2f} | p50: cache length known {med(1):5.2f}, positions folded in {med(2):5.2f}, lane groups merged "
+              f"{med(4):5.2f}, past the barrier {med(5):5.2f}, exit {med(3):5.2f} (last {col(3).max():5.2f})")
         continue
     lib.calm_tl_arm(waves)
     us, _ = b.stage_us(i, 2)
