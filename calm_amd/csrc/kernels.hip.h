@@ -56,9 +56,15 @@ template <int DB>
 struct Fmt {
 	static constexpr int G = 128 / DB; // fp16: 8, fp8: 16, gf4: 32
 	static constexpr int F4 = G / 4;
-	// float4 slots of the LDS activation image per 1-KiB chunk of a row: 64 lanes x F4, and for gf4 one more
-	// float4 per lane holding the activation sum of each of its four 8-weight words (see dot16<4>)
-	static constexpr int CS = 64 * F4 + (DB == 4 ? 64 : 0);
+	// The LDS activation image, per 1-KiB chunk of a row: F4 ROWS of float4 slots -- row i holds "float4 #i" of each of the 64 lanes --
+	// and for gf4 one more row holding the activation sum of each of a lane's four 8-weight words (see dot16<4>).  A row is 64 slots
+	// plus PAD: the staging threads write consecutive LOGICAL float4s, i.e. F4 rows at once, and with rows exactly 1 KiB apart the
+	// 8 lanes of one LDS pass (128 bytes) all fell into the same banks -- 32 cycles per 1-KiB store at fp8, 64 at gf4, where 8 would do
+	// (SQ_LDS_BANK_CONFLICT: 24 / 56 cycles per store instruction, profiles/r03_pmc_gf4_tables.txt).  PAD = 8 / F4 slots shifts row i by
+	// i x the bytes its lanes of a pass cover, so a pass covers 128 consecutive bank bytes; reads (a wave reads one row) stay contiguous.
+	static constexpr int PAD = 8 / F4;
+	static constexpr int ROW = 64 + PAD;
+	static constexpr int CS = ROW * (F4 + (DB == 4 ? 1 : 0));
 };
 
 __device__ __forceinline__ int lane_id() {
@@ -192,7 +198,7 @@ __device__ __forceinline__ float fma_mix_hi(unsigned h2, float x, float acc) {
 // so that every multiply-add is a v_pk_fma_f32 on register pairs that are already adjacent: the
 // converted weight pair, the activation pair from ds_read_b128, the accumulator pair.
 // xp points at this lane's first float4 of the chunk in the swizzled LDS image; float4 #i of the
-// lane is at xp[i * 64].
+// lane is at xp[i * ROW] (ROW = Fmt<DB>::ROW slots).
 template <int DB>
 __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 	// (fp16 / fp8: a second, call-local accumulator pair halves the length of the dependent v_pk_fma chain
@@ -201,7 +207,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		f32x2 acc_b = {0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
-			f32x4 x = xp[i * 64];
+			f32x4 x = xp[i * Fmt<DB>::ROW];
 			unsigned w0 = v[2 * i], w1 = v[2 * i + 1];
 			f32x2 a = {half_bits_to_float((unsigned short)(w0 & 0xffff)), half_bits_to_float((unsigned short)(w0 >> 16))};
 			f32x2 b = {half_bits_to_float((unsigned short)(w1 & 0xffff)), half_bits_to_float((unsigned short)(w1 >> 16))};
@@ -213,7 +219,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		f32x2 acc_b = {0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			f32x4 x = xp[i * 64];
+			f32x4 x = xp[i * Fmt<DB>::ROW];
 			acc = __builtin_elementwise_fma(bf8x2_lo(v[i]), x.lo, acc);
 			acc_b = __builtin_elementwise_fma(bf8x2_hi(v[i]), x.hi, acc_b);
 		}
@@ -231,12 +237,12 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		f32x4 xv[4][2];
 		unsigned m[4][5];
 		float t[4], S[4];
-		const f32x4 xsum = xp[8 * 64];
+		const f32x4 xsum = xp[8 * Fmt<4>::ROW];
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const unsigned w = v[j];
-			xv[j][0] = xp[(2 * j) * 64];
-			xv[j][1] = xp[(2 * j + 1) * 64];
+			xv[j][0] = xp[(2 * j) * Fmt<4>::ROW];
+			xv[j][1] = xp[(2 * j + 1) * Fmt<4>::ROW];
 			S[j] = bf8_byte0(w);
 			const unsigned r = __builtin_amdgcn_alignbit(w, w, 23); // rotate right by 23
 			m[j][0] = r & 0x000E0007u; // lo: c5 (a = 0)   hi: c0 (a = 1)
@@ -273,14 +279,14 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 
 // Swizzled LDS image of an n-float vector for weight format DB.  Logical float4 p (columns
 // 4p..4p+3) belongs to chunk p / (16G), lane (p % 16G) / F4, sub-index i = p % F4 and is stored at
-// float4 slot chunk*CS + i*64 + lane: a wave reading "its float4 #i" hits 64 consecutive slots.
+// float4 slot chunk*CS + i*ROW + lane (Fmt<DB>: ROW = 64 + PAD): a wave reading "its float4 #i" hits 64 consecutive slots.
 // gf4 only: the image holds x_k * 2^-a(k % 8), a = {1,4,7,1,4,0,3,6} (dot16<4> multiplies by codes that
-// sit 2^a too high), and slot chunk*CS + 8*64 + lane holds the four UNSCALED 8-column sums of the lane.
+// sit 2^a too high), and slot chunk*CS + 8*ROW + lane holds the four UNSCALED 8-column sums of the lane.
 template <int DB>
 __device__ __forceinline__ int swz4(int p) {
 	constexpr int G = Fmt<DB>::G, F4 = Fmt<DB>::F4;
 	int chunk = p / (16 * G), r = p % (16 * G);
-	return chunk * Fmt<DB>::CS + (r % F4) * 64 + r / F4;
+	return chunk * Fmt<DB>::CS + (r % F4) * Fmt<DB>::ROW + r / F4;
 }
 
 // logical float4 count of the image of n floats (whole chunks; the tail is zero-filled) ...
@@ -307,7 +313,7 @@ __device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
 	xs4[swz4<4>(p)] = t;
 	if (!odd) {
 		const int chunk = p / 512, r = p % 512; // 512 logical float4 per gf4 chunk; lane r / 8, word (r % 8) / 2
-		((float*)&xs4[chunk * Fmt<4>::CS + 512 + r / 8])[(r % 8) >> 1] = s;
+		((float*)&xs4[chunk * Fmt<4>::CS + 8 * Fmt<4>::ROW + r / 8])[(r % 8) >> 1] = s;
 	}
 }
 

@@ -63,8 +63,8 @@ if [ -x oracle/_ref/run_hip ]; then
 fi
 fi
 if want 5; then
-echo "== 5. counters of the gf4 kernels (Llama-3-8B shape, 8 layers; three separate passes)" | tee -a $OUT/summary.txt
-bash tools/pmc_kernel.sh ${TAG}_pmc_gf4 llama-3-8b gf4 8 > $OUT/pmc_gf4.log 2>&1
+echo "== 5. counters of the gf4 kernels (Llama-3-8B shape, full depth; three separate passes)" | tee -a $OUT/summary.txt
+bash tools/pmc_kernel.sh ${TAG}_pmc_gf4 llama-3-8b gf4 > $OUT/pmc_gf4.log 2>&1
 cp gpurun_out/${TAG}_pmc_gf4/summary.txt $OUT/pmc_gf4_tables.txt 2>/dev/null; tail -12 $OUT/pmc_gf4_tables.txt | cut -c1-400 >> $OUT/summary.txt
 fi
 cat $OUT/summary.txt
