@@ -375,17 +375,48 @@ __device__ __forceinline__ void stage_load(StageRegs<V, NORM>& sr, const float* 
 }
 
 template <int DB, int BLOCK, int V, bool NORM>
-__device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
-                                             int n, float eps, bool ln, float* dump) {
+// Returns the factor the caller's epilogue still has to apply to every dot product with the image: 1, except for RMSNorm
+// (normw, !ln, no dump), where the image holds x * normw and the factor is rsqrt(mean(x^2) + eps) -- a scalar commutes with the
+// matvec, so the image does not wait for the block-wide sum of squares (two barriers and an LDS round trip on the path to the first
+// multiply-add); the sum rides on the image's own barrier instead.
+__device__ __forceinline__ float stage_finish(const StageRegs<V, NORM>& sr, float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
+                                              int n, float eps, bool ln, float* dump) {
 	constexpr int MAXV = V;
+	constexpr int NWAVES = BLOCK / 64;
 	const int tid = threadIdx.x;
 	const int n4 = n >> 2;
 	const int slots = xs_logical<DB>(n);
 	const float4* src4 = (const float4*)src;
 	const float4(&v)[MAXV] = sr.v;
 
+	const bool deferred = normw && !ln && !dump;
 	float mean = 0.f, scale = 1.f;
-	if (normw) {
+	if (deferred) {
+		float ss = 0.f;
+		auto put = [&](int p, float4 t, float4 gw) {
+			ss += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+			t.x *= gw.x, t.y *= gw.y, t.z *= gw.z, t.w *= gw.w;
+			if constexpr (DB == 4) {
+				stage_store_gf4(xs4, p, t);
+			} else {
+				xs4[swz4<DB>(p)] = t;
+			}
+		};
+#pragma unroll
+		for (int i = 0; i < MAXV; ++i) {
+			int p = tid + i * BLOCK;
+			if (p < n4) {
+				put(p, v[i], sr.g[NORM ? i : 0]);
+			}
+		}
+		for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
+			put(p, src4[p], ((const float4*)normw)[p]);
+		}
+		ss = wave_sum(ss);
+		if (lane_id() == 0) {
+			red[tid >> 6] = ss;
+		}
+	} else if (normw) {
 		if (ln) {
 			float s = 0.f;
 #pragma unroll
@@ -434,15 +465,17 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float
 			xs4[swz4<DB>(p)] = t;
 		}
 	};
+	if (!deferred) {
 #pragma unroll
-	for (int i = 0; i < MAXV; ++i) {
-		int p = tid + i * BLOCK;
-		if (p < n4) {
-			emit(p, v[i], sr.g[NORM ? i : 0]);
+		for (int i = 0; i < MAXV; ++i) {
+			int p = tid + i * BLOCK;
+			if (p < n4) {
+				emit(p, v[i], sr.g[NORM ? i : 0]);
+			}
 		}
-	}
-	for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
-		emit(p, src4[p], normw ? ((const float4*)normw)[p] : make_float4(0.f, 0.f, 0.f, 0.f));
+		for (int p = tid + MAXV * BLOCK; p < n4; p += BLOCK) {
+			emit(p, src4[p], normw ? ((const float4*)normw)[p] : make_float4(0.f, 0.f, 0.f, 0.f));
+		}
 	}
 	// zero the tail of the last chunk so masked-off lanes multiply 0 * 0
 	for (int p = n4 + tid; p < slots; p += BLOCK) {
@@ -453,6 +486,15 @@ __device__ __forceinline__ void stage_finish(const StageRegs<V, NORM>& sr, float
 		}
 	}
 	__syncthreads();
+	if (deferred) {
+		float ss = 0.f;
+#pragma unroll
+		for (int i = 0; i < NWAVES; ++i) {
+			ss += red[i];
+		}
+		return 1.0f / sqrtf(ss / (float)n + eps);
+	}
+	return 1.0f;
 }
 
 // ---------------------------------------------------------------- the row engine --------------
@@ -870,7 +912,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 	};
 	StageRegs<V, true> sr;
 	auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
-	auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump); };
+	float nscale = 1.f; // what the norm leaves to the epilogue (stage_finish)
+	auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump); };
 	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
 	// aux = (cos, sin) of each row pair's RoPE angle, fetched before the task's last multiply-add
 	auto aux_of = [&](int t, float(&aux)[NR]) {
@@ -890,7 +933,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 #pragma unroll
 		for (int r = 0; r < NR; r += 2) {
 			int j = t * NR + r; // even row of a pair
-			float v0 = acc[r], v1 = acc[r + 1];
+			float v0 = acc[r] * nscale, v1 = acc[r + 1] * nscale;
 			if (a.bqkv) {
 				v0 += a.bqkv[j];
 				v1 += a.bqkv[j + 1];
@@ -1723,12 +1766,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		}
 	};
 	auto no_aux = [&](int, float(&)[NR]) {};
+	float nscale = 1.f; // what the norm leaves to the epilogue (stage_finish)
 	auto epi = [&](int t, float(&acc)[NR], float(&)[NR]) {
 		if (lane == RED_LANE) {
 			int k = t / per_expert, j = (t % per_expert) * JP;
 #pragma unroll
 			for (int p = 0; p < JP; ++p) {
-				float u = acc[2 * p], g = acc[2 * p + 1];
+				float u = acc[2 * p] * nscale, g = acc[2 * p + 1] * nscale;
 				a.he[(size_t)k * hidden + j + p] = (a.gelu ? act_gelu(u) : act_silu(u)) * g; // src/infer.c:440-450
 			}
 		}
@@ -1737,7 +1781,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	StageRegs<V, true> sr;
 	if constexpr (!MOE) {
 		auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
-		auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
+		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
 		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
@@ -1770,7 +1814,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		int e, k;
 		gw[j] = *gate_src(min(j, total - 1), e, k);
 	}
-	stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr);
+	nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr);
 	{
 		f32x2 acc2 = {0.f, 0.f};
 		auto gate_step = [&](u32x4 w, int j) { // multiply-add load j; a row's last chunk reduces and files the logit
@@ -1783,7 +1827,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 			}
 			acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
 			if (k == chunks - 1) {
-				const float logit = wave_sum63(acc2[0] + acc2[1]);
+				const float logit = wave_sum63(acc2[0] + acc2[1]) * nscale;
 				if (lane == RED_LANE && e < n_experts) {
 					gate[e] = logit;
 				}
@@ -1944,14 +1988,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const floa
 	};
 	StageRegs<V, true> sr;
 	auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
-	auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
+	float nscale = 1.f; // what the norm leaves to the epilogue (stage_finish)
+	auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, eps, ln != 0, nullptr); };
 	auto no_aux = [&](int, float(&)[NR]) {};
 	auto epi = [&](int t, float(&acc)[NR], float(&)[NR]) {
 		if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
 				if (t * NR + r < vocab) {
-					logits[t * NR + r] = acc[r];
+					logits[t * NR + r] = acc[r] * nscale;
 				}
 			}
 		}
