@@ -85,7 +85,7 @@ int g_qkv_half = 0;    // k_qkv tiles half as deep: 0 = when a wave's share of t
 int g_out_one = 0;     // k_attn_out one row per task: 0 = by the same rule (rows_balance_one), 1 = always, 2 = never
 int g_down_one = 0;    // k_ffn_down one row per task: 0 = when row pairs would leave a full grid's last round markedly emptier (rows_balance_one), 1 = always, 2 = never
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
-int g_attn_mfma = 0;   // 1: split attention on the matrix cores where the head size is 128 (k_attn_mfma; measured no faster than k_attn_gqa: profiles/r03_long_context.txt)
+int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the matrix cores over the transposed value cache where the head size is 128 (k_attn_vt); 0: k_attn_gqa
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -203,6 +203,7 @@ struct Ctx {
 	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
 	TokState* ts = nullptr;
 	void *kc = nullptr, *vc = nullptr;
+	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, behind vc in ONE allocation
 	size_t kv_layer_bytes = 0;
 	int attn_chunk = 1 << 30; // cached positions per attention split of the step being enqueued (launch_attn_lpr)
 	float* logits_h = nullptr; // pinned host
@@ -327,6 +328,7 @@ void launch_qkv(Ctx* c, int l) {
 	a.q = c->q;
 	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
 	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+	a.vt = c->vt ? (char*)c->vt + (size_t)l * c->kv_layer_bytes : nullptr;
 	a.xb_dump = p->norm_par ? c->xb : nullptr;
 	a.ts = c->ts;
 	a.rope_cs = c->rope_cs;
@@ -347,6 +349,11 @@ void launch_qkv(Ctx* c, int l) {
 			});
 		});
 	});
+}
+
+// split attention on the matrix cores over the transposed value cache (k_attn_vt): prepare_hip keeps one for head size 128 and windows of whole 64-position blocks
+inline bool attn_uses_vt(const Ctx* c) {
+	return g_attn_vt && c->vt;
 }
 
 void launch_attn_merge(Ctx* c, int n_split) {
@@ -387,13 +394,14 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
 	// a split of at most two rounds (4 waves x 64 / LPR positions x 4 tiles each) asks for all its rows at once; the split length
 	// of THIS step (Ctx::attn_chunk, set by run_step from kv_len; part of the graph key through attn_two)
-	if (g_attn_mfma && c->head_dim == 128) { // the matrix-core form: a wave per 32-key tile, all qh query heads at once
+	if (attn_uses_vt(c)) { // the matrix-core form over the transposed value cache: a wave per tile of keys, all qh query heads at once
+		const void* vt = (const char*)c->vt + (size_t)l * c->kv_layer_bytes;
 		if (qh == 4) {
-			hipLaunchKernelGGL((k_attn_mfma<KVB, 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+			hipLaunchKernelGGL((k_attn_vt<KVB, 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 		} else if (qh == 2) {
-			hipLaunchKernelGGL((k_attn_mfma<KVB, 2>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+			hipLaunchKernelGGL((k_attn_vt<KVB, 2>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 		} else {
-			hipLaunchKernelGGL((k_attn_mfma<KVB, 1>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
+			hipLaunchKernelGGL((k_attn_vt<KVB, 1>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 		}
 		launch_attn_merge(c, n_split);
 		return;
@@ -574,15 +582,17 @@ void launch_sample(Ctx* c) {
 	hipLaunchKernelGGL(k_sample_minp, dim3(1), dim3(1024), 0, g_stream, c->logits_d, c->vocab, c->next_tok, c->trace, c->trace_count, c->sample_st);
 }
 
-int attn_splits(int kv_len) {
+int attn_splits(const Ctx* c, int kv_len) {
 	if (kv_len <= g_split_min) {
 		return 1;
 	}
 	// 32 splits x 8 kv heads cover the chip once; past that, longer splits (more rounds per workgroup, loaded one
-	// ahead) measured better than more workgroups: 8k context, 32 x 256 positions 12.8 us vs 64 x 128 14.4-16.6 us
-	int n = (kv_len + g_split_t - 1) / g_split_t;
+	// ahead) measured better than more workgroups: 8k context, 32 x 256 positions 12.8 us vs 64 x 128 14.4-16.6 us.
+	// k_attn_vt over an e5m2 cache walks 4 waves x 64 positions per round: splits twice as long.
+	const int t = (attn_uses_vt(c) && c->kvbits == 8) ? 2 * g_split_t : g_split_t;
+	int n = (kv_len + t - 1) / t;
 	if (n > 32) {
-		int n2 = (kv_len + 2 * g_split_t - 1) / (2 * g_split_t);
+		int n2 = (kv_len + 2 * t - 1) / (2 * t);
 		n = n2 > 32 ? n2 : 32;
 	}
 	return n > MAX_SPLIT ? MAX_SPLIT : n;
@@ -743,7 +753,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	CALM_REQUIRE(pos >= 0, "negative position");
 
 	sp.sink = kv_sink > 0;
-	sp.n_split = attn_splits(kv_len);
+	sp.n_split = attn_splits(c, kv_len);
 	c->attn_chunk = (kv_len + sp.n_split - 1) / sp.n_split;
 	const int attn_two = c->attn_chunk <= 2 * 4 * (64 / c->lpr) * 4; // the split kernel's two-round form (launch_attn_lpr): a different graph
 	sp.chained = tok_src != nullptr;
@@ -1035,6 +1045,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		a.w0 = w->wq[l], a.w1 = w->wk[l], a.w2 = w->wv[l], a.bqkv = w->bqkv[l];
 		a.out = c->pf_q;
 		a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes, a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
+		a.vt = c->vt ? (char*)c->vt + (size_t)l * c->kv_layer_bytes : nullptr;
 		gemm(a, EpiQkv(), cols);
 		// causal attention of every token of the chunk over the cache (its own row included)
 		launch_pf_attn<KVB>(c, l, nb, pos0);
@@ -1152,8 +1163,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_min;
 	} else if (!strcmp(key, "attn_waves")) {
 		slot = &g_attn_waves;
-	} else if (!strcmp(key, "attn_mfma")) {
-		slot = &g_attn_mfma;
+	} else if (!strcmp(key, "attn_vt")) {
+		slot = &g_attn_vt;
 	} else if (!strcmp(key, "down_u")) {
 		slot = &g_down_u;
 	} else if (!strcmp(key, "down_u4")) {
@@ -1267,7 +1278,7 @@ extern "C" void init_hip(void) {
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
-	g_attn_mfma = env_int("CALM_HIP_ATTN_MFMA", g_attn_mfma);
+	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
@@ -1384,10 +1395,15 @@ void prepare_ctx(struct Transformer* t) {
 
 	// KV cache, private layout [layer][kv_head][seq_len][head_dim]; zero like calloc (src/infer.c:162-163)
 	c->kv_layer_bytes = (size_t)c->kv_dim * c->seq_len * (c->kvbits / 8);
-	c->kc = dev_alloc(c->kv_layer_bytes * c->n_layers);
-	c->vc = dev_alloc(c->kv_layer_bytes * c->n_layers);
-	HIP_CHECK(hipMemset(c->kc, 0, c->kv_layer_bytes * c->n_layers));
-	HIP_CHECK(hipMemset(c->vc, 0, c->kv_layer_bytes * c->n_layers));
+	// head size 128: the value cache a second time behind the first, transposed ([layer][kv_head][head_dim][seq_len]) -- the operand
+	// layout of the matrix-core split attention (kernels.hip.h k_attn_vt); both are written by the same epilogues
+	const size_t kv_bytes = c->kv_layer_bytes * c->n_layers;
+	const bool vt = attn_has_vt(c->head_dim) && c->seq_len % 64 == 0; // (whole 64-position blocks: attn_vt_offset)
+	c->kc = dev_alloc(kv_bytes);
+	c->vc = dev_alloc(kv_bytes * (vt ? 2 : 1));
+	c->vt = vt ? (char*)c->vc + kv_bytes : nullptr;
+	HIP_CHECK(hipMemset(c->kc, 0, kv_bytes));
+	HIP_CHECK(hipMemset(c->vc, 0, kv_bytes * (vt ? 2 : 1)));
 
 	// RoPE frequencies with the host libm -- the very expression of src/infer.c:226 -- so that
 	// pos * freq is bit-identical to the CPU path's; cos/sin of one position step for the sink keys
@@ -1941,7 +1957,7 @@ extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, ui
 	if (bytes_per_launch) {
 		*bytes_per_launch = stage_bytes(c, stage, kv_len);
 	}
-	int n_split = attn_splits(kv_len);
+	int n_split = attn_splits(c, kv_len);
 	c->attn_chunk = (kv_len + n_split - 1) / n_split;
 	auto one = [&](int l) {
 #define ST(db, kvb)                                  \

@@ -51,6 +51,20 @@ struct TokState {
 	int pad[3];
 };
 
+// head size for which prepare_hip keeps the transposed value cache (behind the [position][dim] one, same size)
+__host__ __device__ constexpr bool attn_has_vt(int head_dim) {
+	return head_dim == 128;
+}
+// Its layout: [kv head][block of VT_BLOCK_BYTES / ebytes positions][dim][position in the block] -- transposed within blocks of 32
+// (binary16) / 64 (e5m2) positions, so that the V^T operand rows of one tile of keys (64 bytes of every dim) are ONE contiguous 8 KiB
+// and its wave-loads are as coalesced as those of the K rows.  Element offset of (row = kv head * head_dim + dim, position):
+constexpr int VT_BLOCK_BYTES = 64;
+__host__ __device__ inline size_t attn_vt_offset(int row, int pos, int head_dim, int seq_len, int ebytes) {
+	const int pb = VT_BLOCK_BYTES / ebytes; // positions per block
+	const int kvh = row / head_dim, d = row % head_dim;
+	return (((size_t)kvh * (seq_len / pb) + pos / pb) * head_dim + d) * pb + pos % pb;
+}
+
 // weights per 16-byte lane-load and float4s of activation it pairs with
 template <int DB>
 struct Fmt {
@@ -867,6 +881,7 @@ struct QkvArgs {
 	const float* bqkv;
 	float* q;
 	void *kc, *vc; // this layer's K / V cache: [kv_head][seq_len][head_dim]
+	void* vt;      // this layer's transposed V cache [kv_head][head_dim][seq_len] (k_attn_vt), or nullptr
 	float* xb_dump;
 	const TokState* ts;
 	const float2* rope_cs;
@@ -956,10 +971,23 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 					cache = a.vc;
 				}
 				size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + kv_pos) * a.head_dim + (jl % a.head_dim);
+				const bool tr = cache == a.vc && a.vt;
+				const size_t offt = tr ? attn_vt_offset(jl, kv_pos, a.head_dim, a.seq_len, KVB / 8) : 0; // the same element in the transposed cache: row (kv head, dim) = jl
+				constexpr int next_d = VT_BLOCK_BYTES / (KVB / 8);                                          // ... and the next dim of the same position
 				if constexpr (KVB == 16) {
-					*(__half2*)((__half*)cache + off) = __floats2half2_rn(v0, v1); // RNE, as (half)x: src/infer.c:378-381
+					const __half2 h = __floats2half2_rn(v0, v1); // RNE, as (half)x: src/infer.c:378-381
+					*(__half2*)((__half*)cache + off) = h;
+					if (tr) {
+						((__half*)a.vt)[offt] = __low2half(h);
+						((__half*)a.vt)[offt + next_d] = __high2half(h);
+					}
 				} else {
-					*(unsigned short*)((unsigned char*)cache + off) = e5m2x2_sat(v0, v1);
+					const unsigned short b2 = e5m2x2_sat(v0, v1);
+					*(unsigned short*)((unsigned char*)cache + off) = b2;
+					if (tr) {
+						((unsigned char*)a.vt)[offt] = (unsigned char)(b2 & 0xff);
+						((unsigned char*)a.vt)[offt + next_d] = (unsigned char)(b2 >> 8);
+					}
 				}
 			}
 		}
@@ -1416,23 +1444,31 @@ __global__ __launch_bounds__(ATTN_GQA_BLOCK) void k_attn_gqa(const TokState* ts,
 	}
 }
 
-// ---- the same split attention on the matrix cores (head size 128) -------------------------------------------------------
+// ---- the same split attention on the matrix cores (head size 128), V read TRANSPOSED ------------------------------------
 // k_attn_gqa is bound by its lane arithmetic from a few thousand positions on (65.6 MB of an fp8 cache at 32k in 24 us: 2.7 TB/s,
-// every score a 16-lane DPP reduction).  Here a WAVE owns a tile of 32 keys and all QH query heads of the kv head at once:
+// every score a 16-lane DPP reduction).  Here a WAVE owns a tile of keys and all QH query heads of the kv head at once:
 //   S^T[key][query] = K[key][:] . q[query][:]      v_mfma_f32_16x16x32_f16: A = K rows (binary16 as cached; e5m2 widened, exact),
 //                                                  B = q as hi + lo binary16 (the fp32 query to 22 significant bits; columns
 //                                                  beyond QH are zero), two 16-key row blocks x four k-steps of 32 dims
 //   online softmax down the columns: a lane holds 8 keys of ONE query (C layout: column = lane & 15, rows 4 (lane >> 4) + e), so
 //   maximum and sum are in-lane reductions plus two exchanges (lane ^ 16, lane ^ 32)
-//   O^T[d][query] += V^T[d][key] . P[key][query]   A = V transposed through the wave's LDS image, B = P as hi + lo binary16 taken
-//   from S^T's accumulator registers as they are: slot e of k-block kb is key 16 (e >> 2) + 4 kb + (e & 3), and the V^T image is
-//   written in that key order
-// Every product is exact in fp32, accumulation is fp32; the result agrees with k_attn_gqa to fp32 rounding (same tolerance in the
-// tests).  The four waves of a workgroup take different tiles of the split (wave-private LDS images: no barrier in the loop; a
-// wave's LDS operations execute in order), rows are fetched coalesced (16 lanes per row) one tile ahead, and the wave states
-// are folded through LDS at the end exactly as in k_attn_gqa (same partial format, same k_attn_merge).
-// LDS per wave: K [32 keys][16 chunks of 8 halfs], chunk index XOR (key & 15); V^T [128 d][4 chunks of 8 keys], chunk index
-// XOR ((d >> 2) & 3): both make the ds_read_b128 operand fetches conflict-free for the hardware's 16-lane groups.
+//   O^T[d][query] += V^T[d][key] . P[key][query]   A = V^T, B = P as hi + lo binary16 taken from S^T's accumulator registers as they are
+// Both A operands want 8 consecutive elements of the K dimension per lane: for S that is a piece of a cached K row, for PV it is 8
+// consecutive POSITIONS of one head dimension -- a piece of a row of the TRANSPOSED value cache, which this backend keeps beside
+// the [position][dim] one for head size 128 ([kv head][dim][position], written by the same epilogues: k_qkv, the prompt GEMM).
+// (Round 3 first transposed V through LDS -- 64 two-byte stores per lane and tile -- and ended no faster than the lane arithmetic;
+// with that transposition faked the same kernel ran 8.1 instead of 10.7 us at 4096 positions, 15.1 instead of 23.7 at 32k:
+// profiles/r03_long_context.txt.)  The keys of a tile are ORDERED so that the 8 scores a lane holds (C rows 4 kb + e of both row
+// blocks) are 8 consecutive positions: A row n of block rb is key 8 NT (n >> 2) + 8 j + 4 rb + (n & 3) of the tile, j = the
+// sub-tile.  fp16 cache: tiles of 32 keys (NT = 1); e5m2 cache: tiles of 64 keys = two sub-tiles of 32 (NT = 2), so that a lane's
+// 16-byte piece of a V^T row (16 positions) serves both.  Every product is exact in fp32, accumulation is fp32; the result agrees
+// with k_attn_gqa to fp32 rounding (same tolerance in the tests).  The four waves of a workgroup take different tiles of the split
+// (wave-private LDS images of the RAW cache bytes, 8 KiB each for K and V^T: no barrier in the loop; a wave's LDS operations execute
+// in order), rows are fetched coalesced one tile ahead (K: whole rows; V^T: 64-byte pieces of 16 rows per wave-load), and the wave
+// states are folded through LDS at the end exactly as in k_attn_gqa (same partial format, same k_attn_merge).  The split length is
+// rounded up to whole 64-position blocks (a V^T piece must start on a 16-byte boundary); trailing splits may be empty.
+// LDS per wave: K [TILE keys][CPR 16-byte chunks], chunk index XOR a function of the key that is injective over the 16 keys one
+// operand fetch touches; V^T [128 d][4 chunks], chunk index XOR ((d >> 2) & 3): conflict-free operand fetches.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void att_split2(float a, float b, unsigned& hi, unsigned& lo) { // x = hi + lo, binary16 each (|x| < 65504)
@@ -1443,10 +1479,14 @@ __device__ __forceinline__ void att_split2(float a, float b, unsigned& hi, unsig
 }
 
 template <int KVB, int QH>
-__global__ __launch_bounds__(256) void k_attn_mfma(const TokState* ts, const float* qin, const void* kc, const void* vc, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float* qin, const void* kc, const void* vt, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
 	constexpr int HD = 128, NW = 4;
-	__shared__ u32x4 kst[NW][32 * 16];
-	__shared__ u32x4 vst[NW][HD * 4];
+	constexpr int EB = KVB / 8;
+	constexpr int NT = KVB == 16 ? 1 : 2, TILE = 32 * NT; // keys per tile (8 KiB of K, 8 KiB of V^T either way)
+	constexpr int CPR = HD * EB / 16;                     // 16-byte chunks per K row: 16 / 8
+	constexpr int RPL = 64 / CPR;                         // K rows per wave-load: 4 / 8
+	__shared__ u32x4 kst[NW][512];
+	__shared__ u32x4 vst[NW][512];
 	__shared__ float sm_m[QH][NW], sm_l[QH][NW];
 	__shared__ float sm_o[QH][NW][HD];
 
@@ -1458,28 +1498,33 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const TokState* ts, const flo
 	const int h0 = kvh * kv_mul + qg * QH;
 	const int n = lane & 15, kb = lane >> 4; // MFMA column (query) / row (key, d) index, k-block = C row group
 	const int kv_len = ts->kv_len;
-	const int chunk = (kv_len + n_split - 1) / n_split;
+	const int chunk = ((kv_len + n_split - 1) / n_split + 63) & ~63;
 	const int t0 = split * chunk;
 	const int t1 = min(kv_len, t0 + chunk);
 
-	// staging: every lane fetches 16 bytes of a cached row -- 8 binary16 elements (16 lanes per row, 4 rows per wave-load, 8 loads
-	// per 32-key tile) or 16 e5m2 elements (8 lanes per row, 8 rows per wave-load, 4 loads per tile).  (8-byte loads of an e5m2
-	// row kept the split kernels at 2.6 TB/s: a CU's memory path counts wave-loads in flight, not bytes.)
-	constexpr int EB = KVB / 8;
-	constexpr int NLD = KVB == 16 ? 8 : 4; // wave-loads per tile and matrix
-	constexpr int RPL = 32 / NLD;          // rows per wave-load
-	constexpr int LPRW = 64 / RPL;         // lanes per row
-	const int c = lane % LPRW, rr = lane / LPRW;
+	// the key's swizzle: its place (0..15) among the 16 keys of one operand fetch -- key = 8 NT a + 8 j + 4 rb + b -> 4 a + b; an e5m2
+	// row is 128 bytes, so rows of even and odd b already differ in their bank phase and 2 a + (b >> 1) is enough
+	auto kswz = [](int key) { return KVB == 16 ? (((key >> 3) << 2) | (key & 3)) : (((key >> 4) << 1) | ((key >> 1) & 1)); };
+	const int c = lane % CPR, rr = lane / CPR; // K fetch: chunk of the row, row of the wave-load
+	const int vc4 = lane & 3, vr = lane >> 2;  // V^T fetch: 16-byte piece of the 64 bytes, d row of the wave-load
 	const unsigned char* kbase = (const unsigned char*)kc + (size_t)kvh * seq_len * HD * EB + c * 16;
-	const unsigned char* vbase = (const unsigned char*)vc + (size_t)kvh * seq_len * HD * EB + c * 16;
+	const unsigned char* vbase = (const unsigned char*)vt + (size_t)kvh * seq_len * HD * EB + vr * VT_BLOCK_BYTES + vc4 * 16; // (block 0 of the kv head, dim vr)
 	const size_t rstride = (size_t)HD * EB;
-	u32x4 kreg[NLD], vreg[NLD];
-	auto fetch = [&](int tb) { // rows tb .. tb + 31, clamped into the live range (masked at use)
+	u32x4 kreg[8], vreg[8];
+	auto fetch = [&](int tb) { // K rows tb .. tb + TILE - 1, clamped into the live range (masked at use); V^T positions tb .. tb + TILE - 1 of every d
 #pragma unroll
-		for (int i = 0; i < NLD; ++i) {
+		for (int i = 0; i < 8; ++i) {
 			const int row = min(tb + RPL * i + rr, kv_len - 1);
 			kreg[i] = *(const u32x4*)(kbase + (size_t)row * rstride);
-			vreg[i] = *(const u32x4*)(vbase + (size_t)row * rstride);
+			vreg[i] = *(const u32x4*)(vbase + (size_t)(tb / TILE) * (HD * VT_BLOCK_BYTES) + i * (16 * VT_BLOCK_BYTES)); // a tile = one block: 8 KiB in a row
+		}
+	};
+	auto stage = [&]() {
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const int key = RPL * i + rr, d = 16 * i + vr;
+			kst[wave][key * CPR + (c ^ kswz(key))] = kreg[i];
+			vst[wave][d * 4 + (vc4 ^ ((d >> 2) & 3))] = vreg[i];
 		}
 	};
 	// e5m2 -> binary16: the byte becomes the upper byte (exact); two cached dwords -> four
@@ -1487,38 +1532,21 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const TokState* ts, const flo
 		return (u32x4){__builtin_amdgcn_perm(w0, w0, 0x050c040cu), __builtin_amdgcn_perm(w0, w0, 0x070c060cu), __builtin_amdgcn_perm(w1, w1, 0x050c040cu),
 		               __builtin_amdgcn_perm(w1, w1, 0x070c060cu)};
 	};
-	auto stage = [&]() {
-		unsigned short* vt = (unsigned short*)vst[wave];
-#pragma unroll
-		for (int i = 0; i < NLD; ++i) {
-			const int key = RPL * i + rr; // within the tile
-			const int pos = ((key >> 2) & 3) * 8 + (key >> 4) * 4 + (key & 3); // the key's place in the MFMA's k order
-			constexpr int NCH = KVB == 16 ? 1 : 2; // 8-element chunks this lane holds of the row
-#pragma unroll
-			for (int hc = 0; hc < NCH; ++hc) {
-				const int ch = NCH * c + hc; // chunk of 8 elements: d = 8 ch .. 8 ch + 7
-				const u32x4 k16 = KVB == 16 ? kreg[i] : widen(kreg[i][2 * hc], kreg[i][2 * hc + 1]);
-				const u32x4 v16 = KVB == 16 ? vreg[i] : widen(vreg[i][2 * hc], vreg[i][2 * hc + 1]);
-				kst[wave][key * 16 + (ch ^ (key & 15))] = k16;
-#pragma unroll
-				for (int e = 0; e < 8; ++e) {
-					const int d = 8 * ch + e;
-					const unsigned w = v16[e >> 1];
-					vt[d * 32 + ((((pos >> 3) ^ ((d >> 2) & 3)) << 3) | (pos & 7))] = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffff));
-				}
-			}
-		}
-	};
-	const int tb0 = t0 + wave * 32; // this wave's tiles: tb0, tb0 + 128, ...
-	if (tb0 < t1) {                 // wave-uniform
+	// the 16-byte chunk `chunk` of row `row` (cpr chunks per row, chunk swizzle `swz`) of an image: 8 binary16 = one MFMA operand, or
+	// 16 e5m2 = two (low / high 8 bytes, widened)
+	auto chunk16 = [](const u32x4* img, int row, int cpr, int chunk, int swz) -> u32x4 { return img[row * cpr + (chunk ^ swz)]; };
+	const int tb0 = t0 + wave * TILE; // this wave's tiles: tb0, tb0 + NW * TILE, ...
+	if (tb0 < t1) {                   // wave-uniform
 		fetch(tb0);
 	}
 
-	// the queries as B operands: column n = head h0 + n, d = 32 t + 8 kb + e
+	// the queries as B operands: column n = head h0 + n; k-step t, k-block kb, element e is head dimension 32 t + 8 kb + e for a binary16
+	// cache and 64 (t >> 1) + 16 kb + 8 (t & 1) + e for an e5m2 one (a lane's 16-byte chunk of a K row then holds its operands of two
+	// k-steps; the order of the summation over the head dimension is free as long as K and q agree)
 	u32x4 qh[4], ql[4];
 #pragma unroll
 	for (int t = 0; t < 4; ++t) {
-		const float* qsrc = qin + (size_t)(h0 + (n < QH ? n : 0)) * HD + 32 * t + 8 * kb;
+		const float* qsrc = qin + (size_t)(h0 + (n < QH ? n : 0)) * HD + (KVB == 16 ? 32 * t + 8 * kb : 64 * (t >> 1) + 16 * kb + 8 * (t & 1));
 		const float4 q0 = *(const float4*)qsrc, q1 = *(const float4*)(qsrc + 4);
 		unsigned hi, lo;
 		att_split2(q0.x, q0.y, hi, lo), qh[t][0] = hi, ql[t][0] = lo;
@@ -1537,66 +1565,90 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const TokState* ts, const flo
 	}
 	float m = -INFINITY, l = 0.f;
 
-	for (int tb = tb0; tb < t1; tb += 32 * NW) {
-		stage(); // (this tile's rows have landed: the loads were issued a tile ago)
-		if (tb + 32 * NW < t1) { // wave-uniform
-			fetch(tb + 32 * NW);
+	for (int tb = tb0; tb < t1; tb += TILE * NW) {
+		stage(); // (this tile's bytes have landed: the loads were issued a tile ago)
+		if (tb + TILE * NW < t1) { // wave-uniform
+			fetch(tb + TILE * NW);
 		}
-		f32x4 s[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-		for (int t = 0; t < 4; ++t) {
+		for (int j = 0; j < NT; ++j) {
+			if (tb + 8 * j >= t1 && NT > 1) { // wave-uniform: the sub-tile's first key lies past the split
+				break;
+			}
+			f32x4 s[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
 			for (int rb = 0; rb < 2; ++rb) {
-				const f16x8 kop = __builtin_bit_cast(f16x8, kst[wave][(16 * rb + n) * 16 + ((4 * t + kb) ^ n)]);
-				s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, qh[t]), s[rb], 0, 0, 0);
-				s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, ql[t]), s[rb], 0, 0, 0);
+				const int key = 8 * NT * (n >> 2) + 8 * j + 4 * rb + (n & 3); // A row n of this block
+				auto kstep = [&](int t, u32x4 k16) {
+					const f16x8 kop = __builtin_bit_cast(f16x8, k16);
+					s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, qh[t]), s[rb], 0, 0, 0);
+					s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, ql[t]), s[rb], 0, 0, 0);
+				};
+				if constexpr (KVB == 16) {
+#pragma unroll
+					for (int t = 0; t < 4; ++t) {
+						kstep(t, chunk16(kst[wave], key, CPR, 4 * t + kb, kswz(key)));
+					}
+				} else {
+#pragma unroll
+					for (int u = 0; u < 2; ++u) {
+						const u32x4 w = chunk16(kst[wave], key, CPR, 4 * u + kb, kswz(key));
+						kstep(2 * u, widen(w[0], w[1]));
+						kstep(2 * u + 1, widen(w[2], w[3]));
+					}
+				}
 			}
-		}
-		// scores of this lane's query against keys tb + 16 rb + 4 kb + e   (src/infer.c:244-248)
-		float mt = -INFINITY;
+			// scores of this lane's query against keys tb + 8 NT kb + 8 j + 4 rb + e   (src/infer.c:244-248)
+			float mt = -INFINITY;
+			const bool ragged = tb + TILE > t1; // wave-uniform: only the split's last tile has keys to mask
 #pragma unroll
-		for (int rb = 0; rb < 2; ++rb) {
+			for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				const int key = tb + 16 * rb + 4 * kb + e;
-				s[rb][e] = key < t1 ? s[rb][e] * inv_sqrt_hd : -INFINITY;
-				mt = fmaxf(mt, s[rb][e]);
+				for (int e = 0; e < 4; ++e) {
+					const int key = tb + 8 * NT * kb + 8 * j + 4 * rb + e;
+					s[rb][e] = (!ragged || key < t1) ? s[rb][e] * inv_sqrt_hd : -INFINITY;
+					mt = fmaxf(mt, s[rb][e]);
+				}
 			}
-		}
-		mt = fmaxf(mt, __shfl_xor(mt, 16));
-		mt = fmaxf(mt, __shfl_xor(mt, 32));
-		const float mn = fmaxf(m, mt); // finite: the tile's first key is inside the split
-		const float cs = (m == -INFINITY) ? 0.f : __expf(m - mn);
-		float ls = 0.f;
+			mt = fmaxf(mt, __shfl_xor(mt, 16));
+			mt = fmaxf(mt, __shfl_xor(mt, 32));
+			const float mn = fmaxf(m, mt); // finite: the sub-tile's first key (kb = 0) is inside the split
+			const float cs = (m == -INFINITY) ? 0.f : __expf(m - mn);
+			const bool moved = __any(mn != m); // wave-uniform: some query's running maximum changed (rare once a few tiles are in)
+			float ls = 0.f;
 #pragma unroll
-		for (int rb = 0; rb < 2; ++rb) {
+			for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				s[rb][e] = __expf(s[rb][e] - mn); // masked: exp(-inf) = 0
-				ls += s[rb][e];
+				for (int e = 0; e < 4; ++e) {
+					s[rb][e] = __expf(s[rb][e] - mn); // masked: exp(-inf) = 0
+					ls += s[rb][e];
+				}
 			}
-		}
-		ls += __shfl_xor(ls, 16);
-		ls += __shfl_xor(ls, 32);
-		l = l * cs + ls;
-		m = mn;
+			ls += __shfl_xor(ls, 16);
+			ls += __shfl_xor(ls, 32);
+			l = l * cs + ls;
+			m = mn;
+			if (moved) {
 #pragma unroll
-		for (int db = 0; db < 8; ++db) {
-			o[db] *= cs;
-		}
-		u32x4 ph, pl; // P as the B operand: slot e = 4 rb + e'
+				for (int db = 0; db < 8; ++db) {
+					o[db] *= cs;
+				}
+			}
+			u32x4 ph, pl; // P as the B operand: slot 4 rb + e of k-block kb = position 8 NT kb + 8 j + 4 rb + e of the tile
 #pragma unroll
-		for (int rb = 0; rb < 2; ++rb) {
-			unsigned hi, lo;
-			att_split2(s[rb][0], s[rb][1], hi, lo), ph[2 * rb] = hi, pl[2 * rb] = lo;
-			att_split2(s[rb][2], s[rb][3], hi, lo), ph[2 * rb + 1] = hi, pl[2 * rb + 1] = lo;
-		}
+			for (int rb = 0; rb < 2; ++rb) {
+				unsigned hi, lo;
+				att_split2(s[rb][0], s[rb][1], hi, lo), ph[2 * rb] = hi, pl[2 * rb] = lo;
+				att_split2(s[rb][2], s[rb][3], hi, lo), ph[2 * rb + 1] = hi, pl[2 * rb + 1] = lo;
+			}
 #pragma unroll
-		for (int db = 0; db < 8; ++db) {
-			const int d = 16 * db + n;
-			const f16x8 vop = __builtin_bit_cast(f16x8, vst[wave][d * 4 + (kb ^ ((d >> 2) & 3))]);
-			o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, ph), o[db], 0, 0, 0);
-			o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, pl), o[db], 0, 0, 0);
+			for (int db = 0; db < 8; ++db) {
+				const int d = 16 * db + n;
+				const u32x4 vw = chunk16(vst[wave], d, 4, kb, (d >> 2) & 3); // positions 8 NT kb .. of the tile: this sub-tile's 8 are element group j
+				const f16x8 vop = __builtin_bit_cast(f16x8, KVB == 16 ? vw : widen(vw[2 * (j & (NT - 1))], vw[2 * (j & (NT - 1)) + 1]));
+				o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, ph), o[db], 0, 0, 0);
+				o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, pl), o[db], 0, 0, 0);
+			}
 		}
 	}
 
@@ -1615,7 +1667,7 @@ __global__ __launch_bounds__(256) void k_attn_mfma(const TokState* ts, const flo
 		}
 	}
 	__syncthreads();
-	// one thread per (query head, output dim) folds the NW wave partials (see k_attn)
+	// one thread per (query head, output dim) folds the NW wave partials (see k_attn); a split without positions files (-inf, 0, 0)
 	for (int idx = threadIdx.x; idx < QH * HD; idx += 256) {
 		const int q = idx / HD, d = idx % HD;
 		float M = sm_m[q][0];

@@ -726,6 +726,7 @@ struct PfGemmArgs {
 	const float* bqkv;
 	const float2* rope;  // [token][head_dim / 2]
 	void *kc, *vc;       // this layer's caches, [kv_head][seq_len][head_dim]
+	void* vt;            // the transposed V cache [kv_head][head_dim][seq_len] (kernels.hip.h k_attn_vt), or nullptr
 	int q_dim, kv_dim, head_dim, seq_len, kv_pos0;
 	float clip;
 	int gelu;
@@ -822,11 +823,23 @@ __device__ __forceinline__ void pf_epi4(const PfGemmArgs& a, const int token, co
 				cache = a.vc;
 			}
 			const size_t off = ((size_t)(jl / a.head_dim) * a.seq_len + a.kv_pos0 + token) * a.head_dim + (jl % a.head_dim);
+			const bool tr = cache == a.vc && a.vt;
+			const size_t offt = tr ? attn_vt_offset(jl, a.kv_pos0 + token, a.head_dim, a.seq_len, KVB / 8) : 0; // the same elements in the transposed cache: dims jl .. jl + 3
+			constexpr int nd = VT_BLOCK_BYTES / (KVB / 8);                                                             // (the next dim of the same position)
 			if constexpr (KVB == 16) { // src/infer.c:378-381
 				const __half2 lo = __floats2half2_rn(r[0], r[1]), hi = __floats2half2_rn(r[2], r[3]);
 				*(u32x2*)((__half*)cache + off) = (u32x2){__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+				if (tr) {
+					__half* t = (__half*)a.vt + offt;
+					t[0] = __low2half(lo), t[nd] = __high2half(lo), t[2 * nd] = __low2half(hi), t[3 * nd] = __high2half(hi);
+				}
 			} else {
-				*(unsigned*)((unsigned char*)cache + off) = (unsigned)e5m2x2_sat(r[0], r[1]) | ((unsigned)e5m2x2_sat(r[2], r[3]) << 16);
+				const unsigned w = (unsigned)e5m2x2_sat(r[0], r[1]) | ((unsigned)e5m2x2_sat(r[2], r[3]) << 16);
+				*(unsigned*)((unsigned char*)cache + off) = w;
+				if (tr) {
+					unsigned char* t = (unsigned char*)a.vt + offt;
+					t[0] = (unsigned char)w, t[nd] = (unsigned char)(w >> 8), t[2 * nd] = (unsigned char)(w >> 16), t[3 * nd] = (unsigned char)(w >> 24);
+				}
 			}
 		}
 	}

@@ -98,6 +98,15 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	c.kv_layer_bytes = kk.size() * 2;
 	c.kc = upload_hip(kk.data(), kk.size() * 2);
 	c.vc = upload_hip(vv.data(), vv.size() * 2);
+	if (attn_has_vt(head_dim) && seq_len % 64 == 0) { // the transposed copy k_attn_vt reads (kernels.hip.h attn_vt_offset)
+		std::vector<uint16_t> tt((size_t)seq_len * kv_dim);
+		for (int t = 0; t < seq_len; ++t) {
+			for (int hd = 0; hd < kv_dim; ++hd) {
+				tt[attn_vt_offset(hd, t, head_dim, seq_len, 2)] = vcache[(size_t)t * kv_dim + hd];
+			}
+		}
+		c.vt = upload_hip(tt.data(), tt.size() * 2);
+	}
 	c.q = (float*)upload_hip((void*)q, q_dim * sizeof(float));
 	c.att = (float*)dev_alloc(q_dim * sizeof(float));
 	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 2) * sizeof(float));
@@ -113,6 +122,9 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, c.att, q_dim * sizeof(float));
 	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts);
+	if (c.vt) {
+		free_hip(c.vt);
+	}
 }
 
 extern "C" int calm_hip_test_argmax(const float* logits, int n) {
@@ -278,6 +290,21 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 	}
 	HIP_CHECK(hipDeviceSynchronize());
 	HIP_CHECK(hipMemcpy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+	if (which && attn_has_vt(g.head_dim) && g.seq_len % 64 == 0) {
+		// the transposed value cache sits behind the [position][dim] one in the same allocation (prepare_hip): [layer][kv_head][head_dim][seq_len]
+		for (int hd = 0; hd < g.kv_dim; ++hd) {
+			for (int p = 0; p < g.seq_len; ++p) {
+				const uint16_t v = host[(size_t)p * g.kv_dim + hd];
+				const size_t dst = attn_vt_offset(hd, p, g.head_dim, g.seq_len, g.ebytes);
+				if (g.ebytes == 2) {
+					memcpy(tmp.data() + dst * 2, &v, 2);
+				} else {
+					tmp[dst] = (unsigned char)(v >> 8);
+				}
+			}
+		}
+		HIP_CHECK(hipMemcpy((char*)t->state.value_cache + (size_t)(t->config.n_layers + layer) * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+	}
 }
 
 extern "C" void calm_hip_read_moe(struct Transformer* t, int layer, int* experts, float* weights) {

@@ -120,6 +120,25 @@ def test_attention_matches_oracle(hiplib, n_heads, n_kv, head_dim, kv_len, n_spl
     assert rel_err(out, ref) < KERNEL_TOL
 
 
+@pytest.mark.parametrize("n_heads,n_kv", [(32, 8), (8, 8), (6, 1), (2, 1)])
+@pytest.mark.parametrize("kv_len,n_split", [(385, 4), (1000, 8), (2049, 32), (4096, 32), (130, 3), (64, 2)])
+def test_split_attention_over_the_transposed_value_cache(hiplib, n_heads, n_kv, kv_len, n_split):
+    """head size 128 and a window of whole 64-position blocks: the split kernel is k_attn_vt (matrix cores, V read from the transposed
+    copy of the cache; 4 / 2 / 1 query heads per workgroup) -- same answer as the reference's three loops; splits are rounded up to
+    64-position blocks, so some of the trailing ones are empty"""
+    rng = np.random.default_rng(n_heads * 1000 + kv_len)
+    head_dim = 128
+    seq_len = (kv_len + 63) // 64 * 64 + 64
+    kv_dim = n_kv * head_dim
+    q = rng.standard_normal(n_heads * head_dim).astype(np.float32)
+    k = (rng.standard_normal((seq_len, kv_dim)) * 0.7).astype(np.float16)
+    v = rng.standard_normal((seq_len, kv_dim)).astype(np.float16)
+    out = np.empty(n_heads * head_dim, dtype=np.float32)
+    hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
+    ref = oracle.attention(q, k, v, n_heads, n_kv, head_dim, kv_len)
+    assert rel_err(out, ref) < KERNEL_TOL
+
+
 def test_attention_softmax_is_stable_for_huge_scores(hiplib):
     """scores of +-1e4: the reference subtracts the max (src/infer.c:252-257); so must we"""
     rng = np.random.default_rng(3)
