@@ -47,7 +47,8 @@ void* upload_hip(void* host, size_t size);
 void* alloc_hip(size_t size);
 
 /* replaces prepare_cuda (src/run.c:23,580; src/infer.cu:73-131): allocates activations, the KV
- * cache (state.kvbits must already be 8 or 16) and the host-visible logits buffer, and snapshots
+ * cache (state.kvbits must already be 8 or 16; for head size 128 the VALUE cache is kept twice, the second copy transposed for the
+ * matrix-core attention of long contexts -- state.value_cache points at an allocation twice the reference's size) and the host-visible logits buffer, and snapshots
  * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits, and -- an extension, the reference's
  * GPU backend leaves it unset -- state.exp: device memory holding the routing of the last decode step, [n_layers][CALM_MAX_EXPERTS]
  * float weights in rank order followed by as many int expert ids (dense models: weight 1, expert 0).
@@ -161,6 +162,9 @@ const char* calm_hip_device_name(void);
  *   "bpc"     cap on resident 256-thread workgroups per CU when sizing grids (default 0: each kernel's own -- 2, the gf4 classifier 4)
  *   "split_t" cached positions per attention KV split (default 128)
  *   "split_min" contexts up to this many positions are not split (default 384)
+ *   "attn_vt" 1 = split attention on the matrix cores over the transposed value cache (default; head size 128), 0 = lane arithmetic
+ *   "qkv_mode" / "out_one" / "down_one" / "down_u" / "down_u4": tile-shape overrides of single kernels (0 = the launchers' rules by
+ *             matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
  * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.
  * Changing "bpc"/"split_t" only affects graphs captured afterwards. */
 int calm_hip_configure(const char* key, int value);
