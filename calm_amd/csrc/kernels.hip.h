@@ -1645,7 +1645,17 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 			for (int db = 0; db < 8; ++db) {
 				const int d = 16 * db + n;
 				const u32x4 vw = chunk16(vst[wave], d, 4, kb, (d >> 2) & 3); // positions 8 NT kb .. of the tile: this sub-tile's 8 are element group j
-				const f16x8 vop = __builtin_bit_cast(f16x8, KVB == 16 ? vw : widen(vw[2 * (j & (NT - 1))], vw[2 * (j & (NT - 1)) + 1]));
+				u32x4 v16 = KVB == 16 ? vw : widen(vw[2 * (j & (NT - 1))], vw[2 * (j & (NT - 1)) + 1]);
+				if (ragged) {
+					// positions past the split carry P = 0, but what the cache holds there may be anything (a slot of an earlier, longer
+					// sequence; 0 x inf = NaN): clear them -- only in a split's last tile
+					const int live = t1 - (tb + 8 * NT * kb + 8 * j); // this lane's positions 0 .. live - 1 are inside the split
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						v16[i] = 2 * i + 1 < live ? v16[i] : (2 * i < live ? (v16[i] & 0xffffu) : 0u);
+					}
+				}
+				const f16x8 vop = __builtin_bit_cast(f16x8, v16);
 				o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, ph), o[db], 0, 0, 0);
 				o[db] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vop, __builtin_bit_cast(f16x8, pl), o[db], 0, 0, 0);
 			}

@@ -137,6 +137,12 @@ def test_split_attention_over_the_transposed_value_cache(hiplib, n_heads, n_kv, 
     hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
     ref = oracle.attention(q, k, v, n_heads, n_kv, head_dim, kv_len)
     assert rel_err(out, ref) < KERNEL_TOL
+    # what the cache holds beyond the live range (slots of an earlier, longer sequence) must not matter -- not even infinities
+    k[kv_len:] = np.float16(np.nan)
+    v[kv_len:] = np.float16(np.inf)
+    out2 = np.empty_like(out)
+    hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out2), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
+    assert np.array_equal(out, out2)
 
 
 def test_attention_softmax_is_stable_for_huge_scores(hiplib):
