@@ -932,13 +932,23 @@ void launch_pf_attn_mfma(Ctx* c, int l, int nb, int pos0) {
 	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
 	const int hg = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
 	const dim3 grid(c->n_kv_heads, (nb + 32 * (4 / hg) - 1) / (32 * (4 / hg)));
-	if (hg == 4) {
-		hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 4>), grid, dim3(256), 0, g_stream, a);
-	} else if (hg == 2) {
-		hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 2>), grid, dim3(256), 0, g_stream, a);
-	} else {
-		hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 1>), grid, dim3(256), 0, g_stream, a);
+	auto go = [&](auto VT) { // VT: V read from the transposed cache (head size 128; a.vc is that cache)
+		constexpr bool T = decltype(VT)::value;
+		if (hg == 4) {
+			hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 4, T>), grid, dim3(256), 0, g_stream, a);
+		} else if (hg == 2) {
+			hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 2, T>), grid, dim3(256), 0, g_stream, a);
+		} else {
+			hipLaunchKernelGGL((k_pf_attn_mfma<KVB, HD, 1, T>), grid, dim3(256), 0, g_stream, a);
+		}
+	};
+	if constexpr (HD == 128) {
+		if (c->vt && g_attn_vt) {
+			a.vc = (char*)c->vt + (size_t)l * c->kv_layer_bytes;
+			return go(std::true_type());
+		}
 	}
+	go(std::false_type());
 }
 
 template <int KVB>

@@ -491,9 +491,14 @@ __global__ __launch_bounds__(PF_ATTN_BLOCK) void k_pf_attn(AttnArgs a) {
 // LDS images (per 32-key tile, ring of 3): K [key][HD] with the 16-byte chunk index XOR-swizzled by the key, V^T [d][32 keys]
 // (64 B rows) with the 8-key chunk index XOR-swizzled by (d >> 3) & 3 -- both make the ds_read_b128 operand fetches conflict
 // free for the hardware's 16-lane groups.
+// VT (head size 128, where the backend keeps the value cache a second time, transposed in blocks -- kernels.hip.h attn_vt_offset):
+// a.vc is that transposed cache, the V^T image is a plain copy of it (one 16-byte store per lane and pass instead of eight 2-byte
+// ones), and the K rows take the permutation instead: A row r of the S^T product is key (r with bits 2 and 3 exchanged) of the tile,
+// so that the 8 scores a lane contributes to k-step u are the 8 consecutive keys 16 u + 8 (lane >> 5) .. + 7.
 // grid = (n_kv_heads, ceil(nb / (32 * TW))), 256 threads;  HG = heads per round (4, 2 or 1, dividing kv_mul), TW = 4 / HG
-template <int KVB, int HD, int HG>
+template <int KVB, int HD, int HG, bool VT>
 __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
+	static_assert(!VT || HD == 128, "the transposed value cache exists for head size 128");
 	constexpr int TW = 4 / HG;       // token tiles per workgroup
 	constexpr int NT = HD / 16;      // MFMA k-steps of a q . k dot product
 	constexpr int ND = HD / 32;      // 32-row tiles of O^T
@@ -523,16 +528,23 @@ __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
 	constexpr int NP = 32 / RPP;   // passes per tile (HD 128: 2, HD 64: 1)
 	const int srow = threadIdx.x / CK, sck = threadIdx.x % CK;
 	u32x4 kreg[NP], vreg[NP];
+	const int vd = threadIdx.x >> 2, vpc = threadIdx.x & 3; // VT: this lane's head dimension within a pass of 64, its quarter of the tile's 32 keys
 	auto fetch = [&](int kt) {
 #pragma unroll
 		for (int p = 0; p < NP; ++p) {
 			const int row = min(kt * 32 + p * RPP + srow, kv_all - 1);
 			if constexpr (KVB == 16) {
 				kreg[p] = *(const u32x4*)(kbase + ((size_t)row * HD + sck * 8) * 2);
-				vreg[p] = *(const u32x4*)(vbase + ((size_t)row * HD + sck * 8) * 2);
+				if constexpr (VT) { // a tile of 32 keys is one block of the transposed cache: [dim][32 keys], 64 bytes per dim
+					vreg[p] = *(const u32x4*)(vbase + ((size_t)kt * HD + p * 64 + vd) * VT_BLOCK_BYTES + vpc * 16);
+				} else {
+					vreg[p] = *(const u32x4*)(vbase + ((size_t)row * HD + sck * 8) * 2);
+				}
 			} else { // e5m2 -> binary16: the byte becomes the upper byte
 				const u32x2 kw = *(const u32x2*)(kbase + (size_t)row * HD + sck * 8);
-				const u32x2 vw = *(const u32x2*)(vbase + (size_t)row * HD + sck * 8);
+				// VT: half a block of 64 keys, 32 bytes per dim, 8 keys per lane
+				const u32x2 vw = VT ? *(const u32x2*)(vbase + ((size_t)(kt >> 1) * HD + p * 64 + vd) * VT_BLOCK_BYTES + (kt & 1) * 32 + vpc * 8)
+				                    : *(const u32x2*)(vbase + (size_t)row * HD + sck * 8);
 				kreg[p] = (u32x4){__builtin_amdgcn_perm(kw[0], kw[0], 0x050c040cu), __builtin_amdgcn_perm(kw[0], kw[0], 0x070c060cu),
 				                  __builtin_amdgcn_perm(kw[1], kw[1], 0x050c040cu), __builtin_amdgcn_perm(kw[1], kw[1], 0x070c060cu)};
 				vreg[p] = (u32x4){__builtin_amdgcn_perm(vw[0], vw[0], 0x050c040cu), __builtin_amdgcn_perm(vw[0], vw[0], 0x070c060cu),
@@ -541,11 +553,26 @@ __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
 		}
 	};
 	auto kswz = [](int key) { return HD == 128 ? (key & 15) : ((key >> 1) & 7); };
-	auto stage = [&](int slot) {
+	auto stage = [&](int slot, int kt) {
 #pragma unroll
 		for (int p = 0; p < NP; ++p) {
 			const int key = p * RPP + srow; // within the tile
 			kst[slot][key * CK + (sck ^ kswz(key))] = kreg[p];
+			if constexpr (VT) {
+				// 8 consecutive keys (8 vpc .. + 7 of the tile) of head dimension d, as cached; keys past the rows anybody here attends to
+				// carry P = 0 but may hold anything (a slot of an earlier, longer sequence; 0 x inf = NaN): cleared in the last tile
+				const int d = p * 64 + vd;
+				u32x4 v16 = vreg[p];
+				const int live = kv_all - (kt * 32 + 8 * vpc);
+				if (live < 8) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						v16[i] = 2 * i + 1 < live ? v16[i] : (2 * i < live ? (v16[i] & 0xffffu) : 0u);
+					}
+				}
+				vst[slot][d * 4 + (vpc ^ ((d >> 3) & 3))] = v16;
+				continue;
+			}
 			// V transposed: this lane holds d = 8 sck .. + 7 of `key`; position of the key in the MFMA's order, 8-key chunk swizzled
 			const int pi = (key & 16) + 8 * ((key >> 2) & 1) + (key & 3) + 4 * ((key >> 3) & 1);
 			unsigned short* vt = (unsigned short*)vst[slot];
@@ -559,11 +586,12 @@ __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
 	};
 
 	fetch(0);
-	stage(0);
+	stage(0, 0);
 	if (ntiles > 1) {
 		fetch(1);
 	}
 	__syncthreads();
+	const int jk = VT ? ((j & ~12) | ((j & 8) >> 1) | ((j & 4) << 1)) : j; // the key (within a tile) this lane's A row of S^T holds
 
 	for (int r = 0; r < a.kv_mul / HG; ++r) {
 		const int h = kvh * a.kv_mul + r * HG + hr;
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
 			const int slot = kt % 3;
 			// stage tile kt + 1 (fetched an iteration ago), fetch tile kt + 2
 			if (kt + 1 < ntiles) {
-				stage((kt + 1) % 3);
+				stage((kt + 1) % 3, kt + 1);
 			}
 			if (kt + 2 < ntiles) {
 				fetch(kt + 2);
@@ -608,15 +636,16 @@ __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
 				}
 #pragma unroll
 				for (int t = 0; t < NT; ++t) {
-					const f16x8 kop = __builtin_bit_cast(f16x8, kst[slot][j * CK + ((2 * t + hh) ^ kswz(j))]);
+					const f16x8 kop = __builtin_bit_cast(f16x8, kst[slot][jk * CK + ((2 * t + hh) ^ kswz(jk))]);
 					sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kop, __builtin_bit_cast(f16x8, qh[t]), sacc, 0, 0, 0);
 					sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kop, __builtin_bit_cast(f16x8, ql[t]), sacc, 0, 0, 0);
 				}
 				// scores of this lane's query against keys kt * 32 + (i & 3) + 8 (i >> 2) + 4 hh   (src/infer.c:244-248)
+				// (VT: C row r = that expression holds key r with bits 2 and 3 exchanged: (i & 3) + 4 ((i >> 2) & 1) + 16 (i >> 3) + 8 hh)
 				float mt = -INFINITY;
 #pragma unroll
 				for (int i = 0; i < 16; ++i) {
-					const int key = kt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+					const int key = kt * 32 + (VT ? (i & 3) + 4 * ((i >> 2) & 1) + 16 * (i >> 3) + 8 * hh : (i & 3) + 8 * (i >> 2) + 4 * hh);
 					sacc[i] = key <= qpos ? sacc[i] * inv_sqrt_hd : -INFINITY;
 					mt = fmaxf(mt, sacc[i]);
 				}
@@ -681,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void k_pf_attn_mfma(AttnArgs a) {
 		// a further round of heads walks the same tiles again: restart the ring
 		if (r + 1 < a.kv_mul / HG) {
 			fetch(0);
-			stage(0);
+			stage(0, 0);
 			if (ntiles > 1) {
 				fetch(1);
 			}

@@ -672,7 +672,10 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
     calls (201, 3, 33 and 96 tokens: partial tiles on both sides, a nearly empty query tile), then one decode step against the oracle;
     and the same prompt through the lane-arithmetic kernel (calm_hip_configure("pf_attn_mfma", 0)): cache rows equal"""
     dim = 256
-    spec = cf.tiny_spec("pfa", max_seq_len=400, dim=dim, hidden_dim=512, n_heads=n_heads, n_kv_heads=n_kv_heads, head_dim=head_dim, vocab_size=300, n_layers=2)
+    # (head size 128 with a window of whole 64-position blocks: V is read from the transposed cache -- the other window length keeps the
+    # LDS-transposing form of the same kernel under test)
+    seq_len = 448 if (head_dim == 128 and n_heads != 6) else 400
+    spec = cf.tiny_spec("pfa", max_seq_len=seq_len, dim=dim, hidden_dim=512, n_heads=n_heads, n_kv_heads=n_kv_heads, head_dim=head_dim, vocab_size=300, n_layers=2)
     tensors, md = cf.synth_model(spec, "fp8", seed=31)
     model = HostModel(tensors, md)
     rng = np.random.default_rng(6)

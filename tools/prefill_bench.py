@@ -22,6 +22,9 @@ N = int(sys.argv[4]) if len(sys.argv) > 4 else 512
 spec = cf.SPECS[name]
 model = HostModel(cf.stub_tensors(spec, dtype, L), cf.dataclasses.replace(spec, n_layers=L).metadata(dtype))
 be = HipBackend(model, stream=cf.synth_stream_big(spec, dtype, 1, L))
+for kv_ in os.environ.get("KNOBS", "").split():  # e.g. KNOBS="attn_vt=0"
+    key, val = kv_.split("=")
+    assert be.lib.calm_hip_configure(key.encode(), int(val)) >= 0, key
 rng = np.random.default_rng(0)
 toks = [int(t) for t in rng.integers(0, spec.vocab_size, size=N)]
 
