@@ -1,0 +1,237 @@
+// exp_skinny.hip -- EXPERIMENT (not product): the decode matvec for T = 4 / 8 tokens at once on the matrix cores.
+//
+// Question: chunks of 3-16 prompt tokens cost a flat ~160 us per layer through the prompt GEMMs, a decode step 50.
+// Can a row engine that streams every weight ONCE at the decode kernels' rate multiply it with T tokens' activations?
+//
+// Form measured here: fp8 (e5m2) weights, row-major [M][K]; a wave-load covers 256 bytes of each of FOUR rows (lane 4 b + n holds
+// bytes [16 b, 16 b + 16) of row n's 256-byte chunk) -- the operand layout of v_mfma_f32_4x4x4_16b_f16: sixteen independent 4 x 4 x 4
+// products per wave, block b = lane / 4, B column n = lane % 4 = the weight row, A row i = lane % 4 = the TOKEN, K = 4 weights per
+// instruction.  The weights are widened e5m2 -> binary16 (exact, two byte permutes per four weights); the activations sit in LDS as
+// binary16 hi + lo parts (fp32 to 22 bits; every product exact, fp32 accumulation): two MFMAs per K-step of 4, the four tokens'
+// sums of a row accumulate in the lane's four D registers across the whole row, and one cross-lane sum per row group at the end.
+// Per wave-load (1 KiB = 1024 weights): 8 byte permutes + 8 MFMAs (T = 4) or 16 (T = 8) + 4 / 8 ds_read_b128.
+//
+// k_skinny<T>: out[t][m] = sum_k W[m][k] x[t][k], M rows, K columns; grid = 512 workgroups x 4 waves, row groups of 4 rows dealt
+// round-robin, two tiles of U = 4 chunks in flight per wave like the product's engine.  Checked against a float64 dot product on the
+// host for a sample of outputs; timed back to back over `layers` different matrices (beyond the Infinity Cache).
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#define HIP_CHECK(x)                                                                       \
+	do {                                                                                   \
+		hipError_t e_ = (x);                                                               \
+		if (e_ != hipSuccess) {                                                            \
+			fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_));     \
+			abort();                                                                       \
+		}                                                                                  \
+	} while (0)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr16;
+
+// LDS image of the activations: per 256-column chunk c, K-step s (0..3: columns 4 s .. 4 s + 3 of every block's 16), block b (0..15),
+// token i: 16 bytes = 4 binary16 hi | 4 binary16 lo  ->  float4 slot ((c * 4 + s) * 16 + b) * T + i.  A wave's read of one step
+// (lanes 4 b + i, i < 4) is 64 consecutive slots for T = 4.
+template <int T>
+__global__ __launch_bounds__(256) void k_skinny(float* __restrict__ out, const unsigned char* __restrict__ w, const float* __restrict__ x, int M, int K) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	u32x4* img = (u32x4*)smem;
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int b = lane >> 2, n = lane & 3;
+	const int nchunks = K / 256;
+	const int ngroups = M / 4;
+	const int first = blockIdx.x * 4 + wave, stride = gridDim.x * 4;
+	constexpr int U = 4; // chunks per tile
+	// the first two tiles of the wave's first row group go out before the image is built (as in the product)
+	u32x4 tile[2][U];
+	auto load = [&](int ph, int grp, int c0) {
+		const unsigned char* row = w + (size_t)(min(grp, ngroups - 1) * 4 + n) * K;
+#pragma unroll
+		for (int u = 0; u < U; ++u) {
+			const int c = min(c0 + u, nchunks - 1);
+			tile[ph][u] = __builtin_nontemporal_load((gptr16)(row + (size_t)c * 256) + b);
+		}
+	};
+	int grp = first, c0 = 0;
+	int grp1 = grp, c1 = U;
+	if (c1 >= nchunks) {
+		c1 = 0, grp1 += stride;
+	}
+	load(0, grp, c0);
+	load(1, grp1, c1);
+	// stage: thread handles (token t, 4 columns k..k+3): hi / lo binary16
+	for (int idx = threadIdx.x; idx < T * K / 4; idx += 256) {
+		const int t = idx / (K / 4), k = (idx % (K / 4)) * 4;
+		const float4 v = *(const float4*)(x + (size_t)t * K + k);
+		const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+		const float2 f0 = __half22float2(h0), f1 = __half22float2(h1);
+		const __half2 l0 = __floats2half2_rn(v.x - f0.x, v.y - f0.y), l1 = __floats2half2_rn(v.z - f1.x, v.w - f1.y);
+		const int c = k >> 8, kk = k & 255, bb = kk >> 4, s = (kk & 15) >> 2;
+		img[((c * 4 + s) * 16 + bb) * T + t] = (u32x4){__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1), __builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1)};
+	}
+	__syncthreads();
+	constexpr int TS = T / 4; // token sets of four
+	f32x4 acc[TS];
+#pragma unroll
+	for (int q = 0; q < TS; ++q) {
+		acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+	}
+	while (grp < ngroups) {
+#pragma unroll
+		for (int ph = 0; ph < 2; ++ph) {
+			// consume tile[ph] = (grp, c0 .. c0 + U - 1)
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (c0 + u < nchunks) {
+					const u32x4 wv = tile[ph][u];
+#pragma unroll
+					for (int s = 0; s < 4; ++s) {
+						// four e5m2 weights -> binary16 (the byte becomes the upper byte)
+						const u32x2 bw = {__builtin_amdgcn_perm(wv[s], wv[s], 0x050c040cu), __builtin_amdgcn_perm(wv[s], wv[s], 0x070c060cu)};
+						const f16x4 bop = __builtin_bit_cast(f16x4, bw);
+#pragma unroll
+						for (int q = 0; q < TS; ++q) {
+							const u32x4 a = img[(((c0 + u) * 4 + s) * 16 + b) * T + 4 * q + n]; // lane's token = 4 q + (lane & 3)
+							const u32x2 ah = {a[0], a[1]}, al = {a[2], a[3]};
+							acc[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, ah), bop, acc[q], 0, 0, 0);
+							acc[q] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, al), bop, acc[q], 0, 0, 0);
+						}
+					}
+				}
+			}
+			const bool last = c0 + U >= nchunks;
+			const int g_done = grp;
+			// advance: (grp, c0) <- (grp1, c1); issue the tile two steps ahead into this buffer
+			int g2 = grp1, c2 = c1 + U;
+			if (c2 >= nchunks) {
+				c2 = 0, g2 += stride;
+			}
+			load(ph, g2, c2);
+			if (last) {
+				// D register i of lane 4 b + n = token (4 q + i), row n, partial over block b's columns: sum over the 16 blocks
+#pragma unroll
+				for (int q = 0; q < TS; ++q) {
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						float v = acc[q][i];
+						v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)); // row_shr:4
+						v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)); // row_shr:8
+						v += __shfl_xor(v, 16);
+						v += __shfl_xor(v, 32);
+						if (lane >= 60 && g_done < ngroups) {
+							out[(size_t)(4 * q + i) * M + g_done * 4 + n] = v;
+						}
+					}
+					acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+				}
+			}
+			grp = grp1, c0 = c1;
+			grp1 = g2, c1 = c2;
+			if (grp >= ngroups) {
+				break;
+			}
+		}
+	}
+}
+
+static float e5m2_to_float(unsigned char v) {
+	unsigned short h = (unsigned short)v << 8;
+	unsigned sign = h >> 15, ex = (h >> 10) & 31, man = h & 1023;
+	float f;
+	if (ex == 0) {
+		f = (float)man * (1.0f / 16777216.0f);
+	} else {
+		unsigned bits = ((ex + 112) << 23) | (man << 13);
+		memcpy(&f, &bits, 4);
+	}
+	return sign ? -f : f;
+}
+
+// returns us per launch; *err = max |out - ref| / max |ref| over sampled outputs
+extern "C" double exp_skinny(int T, int M, int K, int layers, int iters, double* err) {
+	const size_t wbytes = (size_t)M * K;
+	std::vector<unsigned char> hw(wbytes);
+	uint64_t st = 88172645463325252ull;
+	for (size_t i = 0; i < wbytes; ++i) {
+		st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+		unsigned char v = (unsigned char)(st >> 32);
+		if ((v & 0x7c) == 0x7c) {
+			v &= 0xbf; // no inf / nan
+		}
+		if ((v & 0x7c) > 0x40) {
+			v = (v & 0x83) | 0x3c; // keep |w| around 1
+		}
+		hw[i] = v;
+	}
+	std::vector<float> hx((size_t)T * K);
+	for (size_t i = 0; i < hx.size(); ++i) {
+		st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+		hx[i] = (float)((double)(st >> 11) / 9007199254740992.0 - 0.5) * 4.0f;
+	}
+	unsigned char* dw;
+	float *dx, *dout;
+	HIP_CHECK(hipMalloc(&dw, wbytes * layers + 65536));
+	for (int l = 0; l < layers; ++l) {
+		HIP_CHECK(hipMemcpy(dw + (size_t)l * wbytes, hw.data(), wbytes, hipMemcpyHostToDevice));
+	}
+	HIP_CHECK(hipMalloc(&dx, hx.size() * 4 + 65536));
+	HIP_CHECK(hipMemcpy(dx, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+	HIP_CHECK(hipMalloc(&dout, (size_t)T * M * 4));
+	HIP_CHECK(hipMemset(dout, 0, (size_t)T * M * 4));
+	const size_t lds = (size_t)T * K * 4;
+	HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_skinny<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+	auto launch = [&](int l) {
+		if (T == 4) {
+			hipLaunchKernelGGL(k_skinny<4>, dim3(512), dim3(256), lds, 0, dout, dw + (size_t)l * wbytes, dx, M, K);
+		} else {
+			hipLaunchKernelGGL(k_skinny<8>, dim3(256), dim3(256), lds, 0, dout, dw + (size_t)l * wbytes, dx, M, K);
+		}
+	};
+	launch(0);
+	HIP_CHECK(hipDeviceSynchronize());
+	std::vector<float> ho((size_t)T * M);
+	HIP_CHECK(hipMemcpy(ho.data(), dout, ho.size() * 4, hipMemcpyDeviceToHost));
+	double worst = 0, scale = 0;
+	for (int sidx = 0; sidx < 512; ++sidx) {
+		const int t = sidx % T, m = (int)(((uint64_t)sidx * 2654435761u) % (uint64_t)M);
+		double ref = 0;
+		for (int k = 0; k < K; ++k) {
+			ref += (double)e5m2_to_float(hw[(size_t)m * K + k]) * (double)hx[(size_t)t * K + k];
+		}
+		const double d = fabs((double)ho[(size_t)t * M + m] - ref);
+		worst = d > worst ? d : worst;
+		scale = fabs(ref) > scale ? fabs(ref) : scale;
+	}
+	*err = worst / (scale > 0 ? scale : 1);
+	hipEvent_t e0, e1;
+	HIP_CHECK(hipEventCreate(&e0));
+	HIP_CHECK(hipEventCreate(&e1));
+	for (int l = 0; l < layers; ++l) {
+		launch(l);
+	}
+	HIP_CHECK(hipEventRecord(e0, 0));
+	for (int it = 0; it < iters; ++it) {
+		for (int l = 0; l < layers; ++l) {
+			launch(l);
+		}
+	}
+	HIP_CHECK(hipEventRecord(e1, 0));
+	HIP_CHECK(hipEventSynchronize(e1));
+	float ms = 0;
+	HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+	HIP_CHECK(hipFree(dw));
+	HIP_CHECK(hipFree(dx));
+	HIP_CHECK(hipFree(dout));
+	return (double)ms * 1e3 / ((double)iters * layers);
+}
