@@ -87,6 +87,7 @@ int g_down_one = 0;    // k_ffn_down one row per task: 0 = when row pairs would 
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the matrix cores over the transposed value cache where the head size is 128 (k_attn_vt); 0: k_attn_gqa
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
+int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
@@ -994,6 +995,31 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	auto gemm = [&](PfGemmArgs a, auto EPI, int ncols) {
 		constexpr int epi = decltype(EPI)::value;
 		constexpr int kvb = epi == PF_EPI_QKV ? KVB : 16; // only the QKV epilogue touches the cache
+		// Chunks of 3 or 4 tokens (dense GEMMs): every weight streamed once at the decode kernels' rate with the tokens' activations behind
+		// the stream (prefill.hip.h k_pf_skinny) -- where the image (4 x columns x 4 bytes) fits the LDS, a residual GEMM in column ranges.
+		// Measured per layer on the 8-layer Mistral-7B fp8 shape (tools/smallchunk_bench.py; wall clock, eager launches included): 3 / 4
+		// tokens 138 / 143 us against 184 / 180 through the GEMM forms; an eight-token variant of the same kernel lost (189-215 against 172).
+		if constexpr (epi == PF_EPI_QKV || epi == PF_EPI_RESID || epi == PF_EPI_FFN_UP) {
+			constexpr int CC = 16 * Fmt<DB>::G; // columns per chunk
+			constexpr int T = 4;
+			const int fit = (int)((150 * 1024) / (T * 4)) / CC * CC; // columns whose image fits
+			if (g_pf_skinny && nb <= T && !a.col_expert && a.K % CC == 0 && a.M % 4 == 0 && (epi == PF_EPI_RESID || a.K <= fit)) {
+				const int ranges = (a.K + fit - 1) / fit;
+				const int per = ((a.K / CC + ranges - 1) / ranges) * CC;
+				for (int k0 = 0; k0 < a.K; k0 += per) {
+					const int kn = a.K - k0 < per ? a.K - k0 : per;
+					const size_t lds = (size_t)T * kn * 4;
+					const int ngroups = a.M / 4;
+					const int per_cu = lds <= 72 * 1024 ? 2 : 1;
+					int blocks = (ngroups + 3) / 4;
+					blocks = blocks > g_ncu * per_cu ? g_ncu * per_cu : blocks;
+					auto kern = k_pf_skinny<DB, kvb, epi, T>;
+					allow_lds(kern, lds);
+					hipLaunchKernelGGL(kern, dim3(blocks), block, lds, g_stream, a, k0, kn);
+				}
+				return;
+			}
+		}
 		const int nx = (a.M + PfWide<epi>::UNITS - 1) / PfWide<epi>::UNITS;
 		const int tiles = 8 * ((nx + 7) / 8) * ncols, nsteps = pf_steps(a.K);
 		// Which form (profiles/r02_prefill_gemm.txt: Mistral-7B and TinyLlama shapes at 64-1024 tokens): the wide form from 5/8 of
@@ -1193,6 +1219,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_pf_wide;
 	} else if (!strcmp(key, "pf_attn_mfma")) {
 		slot = &g_pf_attn_mfma;
+	} else if (!strcmp(key, "pf_skinny")) {
+		slot = &g_pf_skinny;
 	} else if (!strcmp(key, "stage")) {
 		CALM_REQUIRE(value < (int)g_devs.size(), "calm_hip_configure(\"stage\"): no such stage");
 		int old_stage = g_alloc_stage;
@@ -1294,6 +1322,7 @@ extern "C" void init_hip(void) {
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
+	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
 		printf("# HIP: %s (%s), %d CUs, %.1f GiB, device %d\n", prop.name, prop.gcnArchName, g_ncu, (double)prop.totalGlobalMem / (1024.0 * 1024 * 1024), dev);
 	}

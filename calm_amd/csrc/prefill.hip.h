@@ -39,6 +39,7 @@ namespace calm {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PF_NT = 1024; // tokens per chunk: up to sixteen 64-token workgroup columns (the wide GEMM form fills the chip from ~512)
 
@@ -940,6 +941,192 @@ __device__ __forceinline__ void pf_epilogue_rows(const PfGemmArgs& a, const f32x
 					const float v[4] = {t.x, t.y, t.z, t.w};
 					pf_epi4<KVB, EPI>(a, token, ub, v);
 				}
+			}
+		}
+	}
+}
+
+// ---- chunks of 3 or 4 tokens: every weight streamed ONCE, at the decode kernels' rate ----------------------------------------------
+// The GEMM forms below cost a flat ~160 us per layer for a handful of tokens (every weight streamed once at 1.4 TB/s), four serial
+// decode steps 200.  k_pf_skinny is the decode row engine's stream with T tokens' activations behind it
+// (tools/exp_skinny.hip, profiles/r03_multi_token_probe.txt: four tokens in 1.55-2.3 x one token's launch):
+//   * a wave-load covers 256 bytes of each of FOUR weight rows (lane 4 b + n: bytes [16 b, 16 b + 16) of row n's chunk) -- the operand
+//     layout of v_mfma_f32_4x4x4_16b_f16: sixteen independent 4 x 4 x 4 products per wave, block b = lane / 4, B column n = lane % 4 =
+//     the weight ROW, A row i = lane % 4 = the TOKEN, K = 4 weights per instruction;
+//   * the weights as binary16 (pf_operand: exact in all three formats), the activations from the same fragment-major hi + lo
+//     matrices the GEMMs read (pf_unit), re-laid in LDS per (chunk, K-step, block, token): 16 bytes = 4 hi | 4 lo halves; two MFMAs
+//     per K-step, fp32 accumulation in the lane's four D registers (one per token) across the whole row;
+//   * one cross-lane sum per group of four rows, then the GEMMs' own epilogues (pf_epi4 / the gated activation + pf_store4) per token.
+// T = 4 tokens in the product (tokens >= nb are zero and dropped; the T = 8 instantiation measured slower than the GEMM forms and is
+// not launched); [k0, k0 + kn) = the columns this launch covers -- whole chunks; a residual
+// GEMM whose image does not fit the LDS runs as several launches over column ranges, each adding its part (pf_epi4 accumulates).
+// grid: like the decode kernels', groups of four units dealt round-robin over the waves; LDS = T * kn * 4 bytes.
+template <int DB, int KVB, int EPI, int T>
+__global__ __launch_bounds__(256) void k_pf_skinny(PfGemmArgs a, int k0, int kn) {
+	static_assert(EPI == PF_EPI_QKV || EPI == PF_EPI_RESID || EPI == PF_EPI_FFN_UP, "dense GEMMs of a layer");
+	constexpr int G = Fmt<DB>::G;   // weights per 16-byte lane-load
+	constexpr int SPL = G / 4;      // MFMA K-steps (4 weights) per lane-load
+	constexpr int CC = 16 * G;      // columns per chunk: one wave-load of each of the four rows
+	constexpr int NA = EPI == PF_EPI_FFN_UP ? 2 : 1; // weight streams: FFN-up multiplies w1 and w3 with the same activations
+	constexpr int TS = T / 4;       // token sets of four
+	constexpr int U = 4 / NA;       // chunks per tile: four wave-loads, two tiles in flight per wave
+	extern __shared__ __attribute__((aligned(16))) unsigned char pf_sk_smem[];
+	u32x4* img = (u32x4*)pf_sk_smem;
+	const int lane = lane_id(), wave = wave_id();
+	const int b = lane >> 2, n = lane & 3;
+	const int nchunks = kn / CC;
+	const int ngroups = a.M / 4;
+	const int stride = gridDim.x * 4;
+	const size_t row_bytes = (size_t)a.K * DB / 8;
+	const size_t col_off = (size_t)k0 * DB / 8;
+
+	// row n of group g in stream s
+	auto row_of = [&](int g, int s) -> const unsigned char* {
+		const int u = min(g, ngroups - 1) * 4 + n;
+		if constexpr (EPI == PF_EPI_QKV) {
+			const bool is_q = u < a.q_dim, is_k = u < a.q_dim + a.kv_dim;
+			const unsigned char* base = (const unsigned char*)(is_q ? a.w0 : (is_k ? a.w1 : a.w2));
+			return base + (size_t)(u - (is_q ? 0 : (is_k ? a.q_dim : a.q_dim + a.kv_dim))) * row_bytes + col_off;
+		} else {
+			return (const unsigned char*)(s == 0 ? a.w0 : a.w1) + (size_t)u * row_bytes + col_off;
+		}
+	};
+	u32x4 tile[2][NA][U];
+	auto load = [&](int ph, int g, int c0) {
+#pragma unroll
+		for (int s = 0; s < NA; ++s) {
+			const unsigned char* row = row_of(g, s);
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				const int c = min(c0 + u, nchunks - 1);
+				tile[ph][s][u] = __builtin_nontemporal_load((gptr16)(row + (size_t)c * 256) + b);
+			}
+		}
+	};
+	int grp = blockIdx.x * 4 + wave, c0 = 0;
+	int grp1 = grp, c1 = U;
+	if (c1 >= nchunks) {
+		c1 = 0, grp1 += stride;
+	}
+	load(0, grp, c0);
+	load(1, grp1, c1);
+
+	// the image: per (token t, 8 columns) one hi and one lo unit of the fragment-major matrix -> two slots (K-steps 2 j, 2 j + 1)
+	{
+		const int nsteps = pf_steps(a.K);
+		const u32x4* xin = (const u32x4*)a.xin;
+		for (int idx = threadIdx.x; idx < T * (kn / 8); idx += 256) {
+			const int t = idx / (kn / 8), kk = (idx % (kn / 8)) * 8;
+			u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+			if (t < a.nb) {
+				const int un = pf_unit(t, k0 + kk, nsteps);
+				hi = xin[un], lo = xin[un + 64];
+			}
+			const int c = kk / CC, col = kk % CC, bb = col / G, s0 = (col % G) / 4;
+			u32x4* slot = img + ((c * SPL + s0) * 16 + bb) * T + t;
+			slot[0] = (u32x4){hi[0], hi[1], lo[0], lo[1]};
+			slot[16 * T] = (u32x4){hi[2], hi[3], lo[2], lo[3]};
+		}
+	}
+	__syncthreads();
+
+	f32x4 acc[NA][TS];
+#pragma unroll
+	for (int s = 0; s < NA; ++s) {
+#pragma unroll
+		for (int q = 0; q < TS; ++q) {
+			acc[s][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+		}
+	}
+	while (grp < ngroups) {
+#pragma unroll
+		for (int ph = 0; ph < 2; ++ph) {
+#pragma unroll
+			for (int u = 0; u < U; ++u) {
+				if (c0 + u < nchunks) { // wave-uniform
+#pragma unroll
+					for (int j = 0; j < G / 8; ++j) {
+						f16x8 wop[NA];
+#pragma unroll
+						for (int s = 0; s < NA; ++s) {
+							wop[s] = pf_operand<DB>(tile[ph][s][u], j);
+						}
+#pragma unroll
+						for (int h = 0; h < 2; ++h) { // K-step 2 j + h: weights 4 h .. 4 h + 3 of the operand
+#pragma unroll
+							for (int q = 0; q < TS; ++q) {
+								const u32x4 av = img[(((c0 + u) * SPL + 2 * j + h) * 16 + b) * T + 4 * q + n]; // this lane's A row = token 4 q + n
+								const u32x2 ah = {av[0], av[1]}, al = {av[2], av[3]};
+#pragma unroll
+								for (int s = 0; s < NA; ++s) {
+									const u32x4 w4 = __builtin_bit_cast(u32x4, wop[s]);
+									const u32x2 bw = {w4[2 * h], w4[2 * h + 1]};
+									acc[s][q] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, ah), __builtin_bit_cast(f16x4, bw), acc[s][q], 0, 0, 0);
+									acc[s][q] = __builtin_amdgcn_mfma_f32_4x4x4f16(__builtin_bit_cast(f16x4, al), __builtin_bit_cast(f16x4, bw), acc[s][q], 0, 0, 0);
+								}
+							}
+						}
+					}
+				}
+			}
+			const bool last = c0 + U >= nchunks;
+			const int g_done = grp;
+			int g2 = grp1, c2 = c1 + U;
+			if (c2 >= nchunks) {
+				c2 = 0, g2 += stride;
+			}
+			load(ph, g2, c2);
+			if (last) {
+				// D register i of lane 4 b + n = token 4 q + i, row n, summed over block b's columns: add the sixteen blocks (lanes 60 + n hold the sums)
+				float sum[NA][T];
+#pragma unroll
+				for (int s = 0; s < NA; ++s) {
+#pragma unroll
+					for (int q = 0; q < TS; ++q) {
+#pragma unroll
+						for (int i = 0; i < 4; ++i) {
+							float v = acc[s][q][i];
+							v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xf, 0xf, true)); // row_shr:4
+							v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x118, 0xf, 0xf, true)); // row_shr:8
+							v += __shfl_xor(v, 16);
+							v += __shfl_xor(v, 32);
+							sum[s][4 * q + i] = v;
+						}
+						acc[s][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+					}
+				}
+				const int ub = g_done * 4;
+#pragma unroll
+				for (int t = 0; t < T; ++t) {
+					if (t < a.nb) { // uniform
+						float r[NA][4];
+#pragma unroll
+						for (int s = 0; s < NA; ++s) {
+#pragma unroll
+							for (int e = 0; e < 4; ++e) {
+								r[s][e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sum[s][t]), 60 + e));
+							}
+						}
+						if (lane == 0) {
+							if constexpr (EPI == PF_EPI_FFN_UP) {
+								float hv[4];
+#pragma unroll
+								for (int e = 0; e < 4; ++e) {
+									hv[e] = (a.gelu ? act_gelu(r[0][e]) : act_silu(r[0][e])) * r[NA - 1][e]; // src/infer.c:440-450
+								}
+								pf_store4(a.out, t, ub, pf_steps(a.M), hv);
+							} else {
+								const float v4[4] = {r[0][0], r[0][1], r[0][2], r[0][3]};
+								pf_epi4<KVB, EPI>(a, t, ub, v4);
+							}
+						}
+					}
+				}
+			}
+			grp = grp1, c0 = c1;
+			grp1 = g2, c1 = c2;
+			if (grp >= ngroups) {
+				break;
 			}
 		}
 	}

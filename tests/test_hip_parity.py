@@ -664,6 +664,52 @@ def test_prefill_in_two_calls_and_odd_chunks(hiplib):
         o.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp8", "fp16", "gf4"])
+@pytest.mark.parametrize("kvbits", [16, 8])
+def test_prefill_chunks_of_three_or_four_tokens_stream_the_weights_once(hiplib, dtype, kvbits):
+    """chunks of 3 or 4 tokens go through k_pf_skinny (one weight stream, four tokens' activations behind it; the FFN-down in column
+    ranges where its image does not fit the LDS), larger ones through the GEMM forms: a 60-token prompt fed 3, 4, 5, 6, 7, 8, 8, 4, 3,
+    7, 5 tokens at a time, then a decode step against the oracle (same cache format); the same prompt with the knob off: cache rows agree"""
+    spec = cf.tiny_spec("sk", max_seq_len=128, dim=1024, hidden_dim=12288, n_heads=8, n_kv_heads=2, head_dim=128, vocab_size=400, n_layers=2)
+    tensors, md = cf.synth_model(spec, dtype, seed=77)
+    model = HostModel(tensors, md)
+    rng = np.random.default_rng(8)
+    sizes = [3, 4, 5, 6, 7, 8, 8, 4, 3, 7, 5]
+    toks = [int(t) for t in rng.integers(0, 400, size=sum(sizes) + 1)]
+    o = oracle.OracleBackend(model, kvbits=kvbits)
+    b = HipBackend(model, kvbits=kvbits)
+    g = HipBackend(model, kvbits=kvbits)
+    try:
+        for pos, tok in enumerate(toks[:-1]):
+            o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        lo = o.forward(toks[-1], len(toks) - 1, 0).copy()
+        assert hiplib.calm_hip_configure(b"pf_skinny", -1) == 1
+        pos = 0
+        for n in sizes:
+            b.prefill(toks[pos : pos + n], pos)
+            pos += n
+        lb = b.forward(toks[-1], pos, 0).copy()
+        assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
+        hiplib.calm_hip_configure(b"pf_skinny", 0)
+        try:
+            pos = 0
+            for n in sizes:
+                g.prefill(toks[pos : pos + n], pos)
+                pos += n
+        finally:
+            hiplib.calm_hip_configure(b"pf_skinny", 1)
+        lg = g.forward(toks[-1], pos, 0).copy()
+        assert rel_err(lg, lo) < LOGIT_TOL, rel_err(lg, lo)
+        if kvbits == 16:
+            assert rel_err(lb, lg) < 2e-5, rel_err(lb, lg)
+        for ks, kg in zip(_kv_floats(hiplib, b, kvbits), _kv_floats(hiplib, g, kvbits)):
+            assert np.abs(ks - kg).max() <= (2e-3 if kvbits == 16 else 0.26) * max(np.abs(kg).max(), 1e-6)
+    finally:
+        b.close()
+        g.close()
+        o.close()
+
+
 @pytest.mark.parametrize("kvbits", [16, 8])
 @pytest.mark.parametrize("head_dim,n_heads,n_kv_heads", [(64, 4, 4), (64, 4, 2), (64, 8, 2), (64, 12, 2), (64, 16, 2), (128, 4, 1), (128, 6, 2), (128, 2, 2)])
 def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_heads, kvbits):
