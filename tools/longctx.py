@@ -13,12 +13,16 @@ from calm_amd.host import STAGES, HipBackend, HostModel, generate, load_lib
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 spec = cf.SPECS["mistral-7b"]
 lib = load_lib()
+for kv_ in os.environ.get("KNOBS", "").split():  # e.g. KNOBS="split_min=100000"
+    key, val = kv_.split("=")
+    assert lib.calm_hip_configure(key.encode(), int(val)) >= 0, key
+POS = [int(x) for x in os.environ["POS"].split(",")] if os.environ.get("POS") else None
 for kvbits, ctx in ((16, 4096), (8, 32768)) if not os.environ.get("KV16_32K") else ((16, 32768),):
     md = cf.dataclasses.replace(spec, n_layers=L, max_seq_len=ctx).metadata("fp8")
     model = HostModel(cf.stub_tensors(spec, "fp8", L), md, context=ctx)
     be = HipBackend(model, kvbits=kvbits, stream=cf.synth_stream_big(spec, "fp8", 1, L))
     generate(be, model, [17], 16, kvbits=kvbits)
-    for pos in ([256, 4000] if ctx == 4096 else [256, 4000, 8000, 16000, 32000]):
+    for pos in (POS if POS else ([256, 4000] if ctx == 4096 else [256, 4000, 8000, 16000, 32000])):
         for split_t in [int(x) for x in os.environ.get("SPLITS", "0").split(",")]:  # 0 = the backend's default
             old = lib.calm_hip_configure(b"split_t", split_t) if split_t else None
             generate(be, model, [17], 8, pos_offset=pos, kvbits=kvbits)
