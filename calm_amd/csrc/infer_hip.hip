@@ -45,7 +45,7 @@ using namespace calm;
 
 namespace {
 
-constexpr int LDS_EXTRA = 1024; // reduction scratch + MoE routing scratch behind the activation image
+constexpr int LDS_EXTRA = 2048; // reduction scratch + MoE routing scratch (k_ffn_up) / the waves' gate partials (k_attn_out) behind the activation image
 constexpr int MAX_SPLIT = ATTN_MAX_SPLIT; // (k_attn_merge holds one partial per split in registers)
 
 hipStream_t g_stream; // the CURRENT device's decode stream (multi-device: switched by use_dev)
@@ -86,7 +86,12 @@ int g_out_one = 0;     // k_attn_out one row per task: 0 = by the same rule (row
 int g_down_one = 0;    // k_ffn_down one row per task: 0 = when row pairs would leave a full grid's last round markedly emptier (rows_balance_one), 1 = always, 2 = never
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the matrix cores over the transposed value cache where the head size is 128 (k_attn_vt); 0: k_attn_gqa
+int g_attn_fuse = 1;   // ... and merges the splits itself: the last workgroup of a head group to arrive folds the partials (no k_attn_merge launch); 0: two launches
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
+int g_moe_route = 1;   // mixture-of-experts models: the router's logits from partial sums k_attn_out's epilogue leaves (k_ffn_up MOE == 2); 0: every
+                       // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
+int g_down_seg = 1;    // mixture-of-experts models: k_ffn_down streams the active experts' rows as one segmented task stream, their hidden vectors
+                       // side by side in LDS (as many per pass as fit); 0: one pass (prologue, drained pipeline) per expert
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -203,10 +208,15 @@ struct Ctx {
 	int *moe_e = nullptr, *next_tok = nullptr, *trace = nullptr, *trace_count = nullptr;
 	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
 	TokState* ts = nullptr;
+	unsigned* attn_count = nullptr; // k_attn_vt's arrival counters (one per kv head and query-head group; zero between launches)
 	void *kc = nullptr, *vc = nullptr;
-	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, behind vc in ONE allocation
+	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, its own allocation (prepare_ctx)
 	size_t kv_layer_bytes = 0;
 	int attn_chunk = 1 << 30; // cached positions per attention split of the step being enqueued (launch_attn_lpr)
+	// mixture-of-experts routing ahead of k_ffn_up (kernels.hip.h k_attn_out GATE): per layer a [dim][gate_ep] fp32 table
+	// moegate[e][j] * ffn_norm[j] (+ gate_ep column sums), and the [gate_ep + 2][GATE_COLS] partial sums of the last k_attn_out
+	float *gate_mt = nullptr, *gate_part = nullptr;
+	int gate_ep = 0;
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
 	// batched prompt ingestion (allocated on first use): token-major [PF_NT][...] activations of one chunk
@@ -257,8 +267,11 @@ Ctx* ctx_of(struct Transformer* t) {
 // in the last round (rounds * waves / ntasks) and too few waves to keep HBM busy (a wave holds 16 KiB
 // in flight; 4 waves per CU measured latency-bound: gf4 FFN-up ran at 2.6 TB/s on a "perfectly
 // balanced" b = 1 grid) -- so the waste is weighted by (1 + 1/(2b)).
-int pick_blocks(int ntasks, int wpb, int kernel_bpc = 0) {
-	const int bpc = g_bpc > 0 ? g_bpc : (kernel_bpc > 0 ? kernel_bpc : 2);
+int pick_blocks(int ntasks, int wpb, int kernel_bpc = 0, int max_bpc = 0) {
+	int bpc = g_bpc > 0 ? g_bpc : (kernel_bpc > 0 ? kernel_bpc : 2);
+	if (max_bpc > 0 && bpc > max_bpc) {
+		bpc = max_bpc;
+	}
 	int need = (ntasks + wpb - 1) / wpb;
 	if (need <= g_ncu * bpc) {
 		return need > 0 ? need : 1;
@@ -279,13 +292,7 @@ int pick_blocks(int ntasks, int wpb, int kernel_bpc = 0) {
 
 // the matvec kernels with a dim-sized vector: WG_WAVES waves per workgroup (kernels.hip.h); 512-thread workgroups sit one per CU
 int pick_blocks_wg(int ntasks, int kernel_bpc = 0) {
-	const int cap = g_bpc;
-	if (WG_THREADS >= 512) {
-		g_bpc = 1;
-	}
-	const int n = pick_blocks(ntasks, WG_WAVES, kernel_bpc);
-	g_bpc = cap;
-	return n;
+	return pick_blocks(ntasks, WG_WAVES, kernel_bpc, WG_THREADS >= 512 ? 1 : 0);
 }
 
 template <int DB>
@@ -360,15 +367,26 @@ inline bool attn_uses_vt(const Ctx* c) {
 	return g_attn_vt && c->vt;
 }
 
-void launch_attn_merge(Ctx* c, int n_split) {
+void launch_attn_merge(Ctx* c, int n_split, int stride) {
 	const dim3 mblock((c->head_dim + 63) / 64 * 64);
 	if (n_split <= 16) {
-		hipLaunchKernelGGL(k_attn_merge<16>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+		hipLaunchKernelGGL(k_attn_merge<16>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split, stride);
 	} else if (n_split <= 32) {
-		hipLaunchKernelGGL(k_attn_merge<32>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+		hipLaunchKernelGGL(k_attn_merge<32>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split, stride);
 	} else {
-		hipLaunchKernelGGL(k_attn_merge<64>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split);
+		hipLaunchKernelGGL(k_attn_merge<64>, dim3(c->n_heads), mblock, 0, g_stream, c->partial, c->att, c->head_dim, n_split, stride);
 	}
+}
+
+// query heads of one kv head that share a workgroup of k_attn_vt: all of them up to 8 (the MFMA tile has 16 columns), else the
+// largest divisor of kv_mul up to 8
+inline int attn_vt_heads(int kv_mul) {
+	for (int q = kv_mul < 8 ? kv_mul : 8; q > 1; --q) {
+		if (kv_mul % q == 0) {
+			return q;
+		}
+	}
+	return 1;
 }
 
 template <int KVB, int LPR>
@@ -382,6 +400,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
 	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
+	a.count = nullptr;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
 		if (g_attn_waves == 4) {
@@ -393,23 +412,27 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 		}
 		return;
 	}
-	// long context: K/V rows loaded once per kv head for up to 4 query heads, kv range split, then merged
+	// long context: K/V rows loaded once per kv head for several query heads, kv range split, then merged
+	a.count = c->attn_count;
+	if (attn_uses_vt(c)) { // the matrix-core form over the transposed value cache: a wave per tile of keys, all qh query heads at once
+		const int qh = attn_vt_heads(c->kv_mul);
+		const dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(256);
+		const void* vt = (const char*)c->vt + (size_t)l * c->kv_layer_bytes;
+		by_bool(qh > 4, [&](auto WIDE) {
+			by_bool(g_attn_fuse != 0, [&](auto FUSE) {
+				hipLaunchKernelGGL((k_attn_vt<KVB, decltype(WIDE)::value ? 8 : 4, decltype(FUSE)::value>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len,
+				                   a.n_split, qh, a);
+			});
+		});
+		if (!g_attn_fuse) {
+			launch_attn_merge(c, n_split, ATTN_VT_PSTRIDE);
+		}
+		return;
+	}
 	const int qh = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
 	dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(ATTN_GQA_BLOCK);
 	// a split of at most two rounds (4 waves x 64 / LPR positions x 4 tiles each) asks for all its rows at once; the split length
 	// of THIS step (Ctx::attn_chunk, set by run_step from kv_len; part of the graph key through attn_two)
-	if (attn_uses_vt(c)) { // the matrix-core form over the transposed value cache: a wave per tile of keys, all qh query heads at once
-		const void* vt = (const char*)c->vt + (size_t)l * c->kv_layer_bytes;
-		if (qh == 4) {
-			hipLaunchKernelGGL((k_attn_vt<KVB, 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
-		} else if (qh == 2) {
-			hipLaunchKernelGGL((k_attn_vt<KVB, 2>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
-		} else {
-			hipLaunchKernelGGL((k_attn_vt<KVB, 1>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
-		}
-		launch_attn_merge(c, n_split);
-		return;
-	}
 	const int step = (ATTN_GQA_BLOCK / 64) * (64 / LPR) * 4;
 	const bool two = c->attn_chunk <= 2 * step;
 	by_bool(two, [&](auto TWO) {
@@ -422,7 +445,7 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 			hipLaunchKernelGGL((k_attn_gqa<KVB, LPR, 1, T>), grid, block, 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a.n_split, a);
 		}
 	});
-	launch_attn_merge(c, n_split);
+	launch_attn_merge(c, n_split, c->head_dim + 2);
 }
 
 template <int KVB>
@@ -457,17 +480,38 @@ inline bool rows_balance_one(int rows, int nr, int waves, int knob) {
 	return nr > 1 && eff(1) > eff(nr) + 0.1;
 }
 
+// k_attn_out's grid and row grouping (k_ffn_up's MOE == 2 form folds one partial column per workgroup of it)
+template <int DB>
+int attn_out_grid(const Ctx* c, bool* one_out = nullptr) {
+	const bool one = rows_balance_one(c->dim, KShape<DB, KS_ATTN_OUT>::NR, g_ncu * 2 * WG_WAVES, g_out_one);
+	if (one_out) {
+		*one_out = one;
+	}
+	return pick_blocks_wg(c->dim / (one ? 1 : KShape<DB, KS_ATTN_OUT>::NR), KShape<DB, KS_ATTN_OUT>::BPC);
+}
+
+// the router's logits travel from k_attn_out's epilogue to k_ffn_up (knob "moe_route"): a mixture-of-experts model whose FFN
+// normalises the residual k_attn_out completes (not a parallel-residual one, which feeds the FFN the attention norm's output)
+template <int DB>
+bool moe_route_ahead(const Ctx* c) {
+	return g_moe_route && c->gate_mt && attn_out_grid<DB>(c) <= GATE_COLS;
+}
+
 template <int DB>
 void launch_attn_out(Ctx* c, int l) {
-	const bool one = rows_balance_one(c->dim, KShape<DB, KS_ATTN_OUT>::NR, g_ncu * 2 * WG_WAVES, g_out_one);
-	int ntasks = c->dim / (one ? 1 : KShape<DB, KS_ATTN_OUT>::NR);
-	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_ATTN_OUT>::BPC)), block(WG_THREADS);
+	bool one = false;
+	dim3 grid(attn_out_grid<DB>(c, &one)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->q_dim);
 	const void* wo = c->t->weights.wo[l];
+	const bool gate = moe_route_ahead<DB>(c);
+	const float* mt = gate ? c->gate_mt + (size_t)l * ((size_t)c->dim + 1) * c->gate_ep : nullptr;
 	by_bool(stage_v4(c->q_dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->q_dim), [&](auto FULL) {
 			by_bool(one, [&](auto ONE) {
-				hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(ONE)::value>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim);
+				by_bool(gate, [&](auto GATE) {
+					hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(ONE)::value, decltype(GATE)::value>), grid, block, lds, g_stream, c->x,
+					                   c->att, wo, c->dim, c->q_dim, mt, c->gate_part, c->gate_ep);
+				});
 			});
 		});
 	});
@@ -490,12 +534,26 @@ void launch_ffn_up(Ctx* c, int l) {
 	int ntasks = nact * (c->hidden / (KShape<DB, KS_FFN_UP>::NR / 2));
 	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_FFN_UP>::BPC)), block(WG_THREADS);
 	size_t lds = lds_bytes<DB>(c->dim);
+	// 0: dense; 1: the gate inside the kernel; 2: from k_attn_out's partials (its grid rides in the upper bits of n_experts)
+	const int moe = c->n_experts > 0 ? (moe_route_ahead<DB>(c) ? 2 : 1) : 0;
+	a.gate_c = nullptr;
+	if (moe == 2) {
+		a.moegate = c->gate_part;
+		a.n_experts = c->n_experts | (attn_out_grid<DB>(c) << 8);
+		a.gate_c = c->gate_mt + (size_t)l * ((size_t)c->dim + 1) * c->gate_ep + (size_t)c->dim * c->gate_ep;
+	}
+	auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, lds, g_stream, a.x, a.norm_w, a.w1, a.w3, a.moegate, a.dim, a.hidden, a.n_experts, a.n_active, a); };
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
-			by_bool(c->n_experts > 0, [&](auto MOE) {
-				hipLaunchKernelGGL((k_ffn_up<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(MOE)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.w1, a.w3,
-					                   a.moegate, a.dim, a.hidden, a.n_experts, a.n_active, a);
-			});
+			constexpr int V = decltype(V4)::value ? 4 : 8;
+			constexpr bool F = decltype(FULL)::value;
+			if (moe == 2) {
+				go(k_ffn_up<DB, V, F, 2>);
+			} else if (moe == 1) {
+				go(k_ffn_up<DB, V, F, 1>);
+			} else {
+				go(k_ffn_up<DB, V, F, 0>);
+			}
 		});
 	});
 }
@@ -525,6 +583,23 @@ int ffn_down_cols(int hidden) {
 	return (per + unit - 1) / unit * unit;
 }
 
+// experts k_ffn_down's segmented form takes per pass (0: the one-pass-per-expert form): as many hidden-vector images as fit the
+// CU's LDS, at most FFN_DOWN_SEGS, balanced over the passes (DBRX's four 43-KB images go as 2 + 2, not 3 + 1)
+template <int DB>
+int ffn_down_segs(const Ctx* c, int kn) {
+	if (!g_down_seg || c->n_active < 2) {
+		return 0;
+	}
+	const size_t seg = (size_t)xs_slots<DB>(kn) * 16;
+	int fit = (int)((160 * 1024 - LDS_EXTRA) / seg);
+	fit = fit > FFN_DOWN_SEGS ? FFN_DOWN_SEGS : fit;
+	if (fit < 2) {
+		return 0;
+	}
+	const int passes = (c->n_active + fit - 1) / fit;
+	return (c->n_active + passes - 1) / passes;
+}
+
 template <int DB>
 void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
@@ -540,26 +615,30 @@ void launch_ffn_down(Ctx* c, int l) {
 		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : (few_rows ? 1 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0));
 		int ntasks = c->dim / (uo == 1 ? 1 : (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
-		size_t lds = lds_bytes<DB>(kn);
+		const int segs = ffn_down_segs<DB>(c, kn);
+		size_t lds = segs ? (size_t)segs * xs_slots<DB>(kn) * 16 + LDS_EXTRA : lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
 			hipLaunchKernelGGL(kern, grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
-			                   c->hidden, c->n_active, k0, kn);
+			                   c->hidden, c->n_active, k0, kn, segs);
 		};
 		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
-			constexpr int V = decltype(V4)::value ? 4 : 8;
-			if (uo == 7) {
-				go(k_ffn_down<DB, BLOCK, V, 7, true>);
-			} else if (uo == 1 && rows_full<DB>(kn)) {
-				go(k_ffn_down<DB, BLOCK, V, 1, true>);
-			} else if (uo == 1) {
-				go(k_ffn_down<DB, BLOCK, V, 1, false>);
-			} else if (uo == 2) {
-				go(k_ffn_down<DB, BLOCK, V, 2, true>);
-			} else if (rows_full<DB>(kn)) {
-				go(k_ffn_down<DB, BLOCK, V, 0, true>);
-			} else {
-				go(k_ffn_down<DB, BLOCK, V, 0, false>);
-			}
+			by_bool(segs > 0, [&](auto SEG) {
+				constexpr int V = decltype(V4)::value ? 4 : 8;
+				constexpr bool S = decltype(SEG)::value;
+				if (uo == 7) {
+					go(k_ffn_down<DB, BLOCK, V, 7, true, S>);
+				} else if (uo == 1 && rows_full<DB>(kn)) {
+					go(k_ffn_down<DB, BLOCK, V, 1, true, S>);
+				} else if (uo == 1) {
+					go(k_ffn_down<DB, BLOCK, V, 1, false, S>);
+				} else if (uo == 2) {
+					go(k_ffn_down<DB, BLOCK, V, 2, true, S>);
+				} else if (rows_full<DB>(kn)) {
+					go(k_ffn_down<DB, BLOCK, V, 0, true, S>);
+				} else {
+					go(k_ffn_down<DB, BLOCK, V, 0, false, S>);
+				}
+			});
 		});
 	}
 }
@@ -705,8 +784,11 @@ void account_step(Ctx* c, const StepPlan& sp, int kv_len) {
 	if (sp.n_split == 1) {
 		add("k_attn", L, stage_bytes(c, CALM_STAGE_ATTN, kv_len));
 	} else {
-		add("k_attn_gqa", L, stage_bytes(c, CALM_STAGE_ATTN, kv_len));
-		add("k_attn_merge", L, (uint64_t)c->n_heads * sp.n_split * (c->head_dim + 2) * sizeof(float));
+		const bool vt = attn_uses_vt(c);
+		add(vt ? "k_attn_vt" : "k_attn_gqa", L, stage_bytes(c, CALM_STAGE_ATTN, kv_len));
+		if (!vt || !g_attn_fuse) {
+			add("k_attn_merge", L, (uint64_t)c->n_heads * sp.n_split * (vt ? ATTN_VT_PSTRIDE : c->head_dim + 2) * sizeof(float));
+		}
 	}
 	add("k_attn_out", L, stage_bytes(c, CALM_STAGE_ATTN_OUT, kv_len));
 	add("k_ffn_up", L, stage_bytes(c, CALM_STAGE_FFN_UP, kv_len));
@@ -915,6 +997,7 @@ void launch_pf_attn_lpr(Ctx* c, int l, int nb, int pos0) {
 	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
 	a.out = c->pf_att;
 	a.partial = nullptr;
+	a.count = nullptr;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
 	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
@@ -931,6 +1014,7 @@ void launch_pf_attn_mfma(Ctx* c, int l, int nb, int pos0) {
 	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
 	a.out = c->pf_att;
 	a.partial = nullptr;
+	a.count = nullptr;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
 	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
@@ -1149,25 +1233,33 @@ template <int DB>
 void set_lds_attrs(Ctx* c) {
 	// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
 	// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
-	by_bool(true, [&](auto) {
-		size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
-		by_bool(true, [&](auto) {
-			auto all = [&](auto V) {
-				constexpr int v = decltype(V)::value;
-				allow_lds(k_ffn_down<DB, 512, v, 7, true>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true>, big), allow_lds(k_ffn_down<DB, 512, v, 1, false>, big);
-				allow_lds(k_ffn_down<DB, 512, v, 0, true>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false>, big);
-			};
-			all(std::integral_constant<int, 4>()), all(std::integral_constant<int, 8>());
-		});
+	{
+		// k_ffn_down: the hidden-sized image, or several side by side (ffn_down_segs) -- the attribute is the kernel's ceiling
+		const int kn = ffn_down_cols<DB>(c->hidden);
+		const int segs = ffn_down_segs<DB>(c, kn);
+		const size_t one = lds_bytes<DB>(kn), big = segs ? (size_t)segs * xs_slots<DB>(kn) * 16 + LDS_EXTRA : one;
+		auto all = [&](auto V, auto S) {
+			constexpr int v = decltype(V)::value;
+			constexpr bool sg = decltype(S)::value;
+			const size_t b = sg ? big : one;
+			allow_lds(k_ffn_down<DB, 512, v, 7, true, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 2, true, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 1, true, sg>, b);
+			allow_lds(k_ffn_down<DB, 512, v, 1, false, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 0, true, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 0, false, sg>, b);
+		};
+		all(std::integral_constant<int, 4>(), std::false_type()), all(std::integral_constant<int, 8>(), std::false_type());
+		if (c->n_active >= 2) {
+			all(std::integral_constant<int, 4>(), std::true_type()), all(std::integral_constant<int, 8>(), std::true_type());
+		}
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
 		if (d > 48 * 1024) {
 			allow_lds(k_qkv<DB, 16, 8, true, false>, d), allow_lds(k_qkv<DB, 16, 8, false, false>, d), allow_lds(k_qkv<DB, 8, 8, true, false>, d), allow_lds(k_qkv<DB, 8, 8, false, false>, d);
 			allow_lds(k_qkv<DB, 16, 8, true, true>, d), allow_lds(k_qkv<DB, 16, 8, false, true>, d), allow_lds(k_qkv<DB, 8, 8, true, true>, d), allow_lds(k_qkv<DB, 8, 8, false, true>, d);
-			allow_lds(k_attn_out<DB, 8, true, false>, d), allow_lds(k_attn_out<DB, 8, false, false>, d), allow_lds(k_attn_out<DB, 8, true, true>, d), allow_lds(k_attn_out<DB, 8, false, true>, d);
-			allow_lds(k_ffn_up<DB, 8, true, true>, d), allow_lds(k_ffn_up<DB, 8, true, false>, d), allow_lds(k_ffn_up<DB, 8, false, true>, d), allow_lds(k_ffn_up<DB, 8, false, false>, d);
+			allow_lds(k_attn_out<DB, 8, true, false, false>, d), allow_lds(k_attn_out<DB, 8, false, false, false>, d), allow_lds(k_attn_out<DB, 8, true, true, false>, d), allow_lds(k_attn_out<DB, 8, false, true, false>, d);
+			allow_lds(k_attn_out<DB, 8, true, false, true>, d), allow_lds(k_attn_out<DB, 8, false, false, true>, d), allow_lds(k_attn_out<DB, 8, true, true, true>, d), allow_lds(k_attn_out<DB, 8, false, true, true>, d);
+			allow_lds(k_ffn_up<DB, 8, true, 0>, d), allow_lds(k_ffn_up<DB, 8, false, 0>, d), allow_lds(k_ffn_up<DB, 8, true, 1>, d), allow_lds(k_ffn_up<DB, 8, false, 1>, d);
+			allow_lds(k_ffn_up<DB, 8, true, 2>, d), allow_lds(k_ffn_up<DB, 8, false, 2>, d);
 			allow_lds(k_output<DB, 8, true>, d), allow_lds(k_output<DB, 8, false>, d);
 		}
-	});
+	}
 }
 
 } // namespace
@@ -1204,6 +1296,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_attn_waves;
 	} else if (!strcmp(key, "attn_vt")) {
 		slot = &g_attn_vt;
+	} else if (!strcmp(key, "attn_fuse")) {
+		slot = &g_attn_fuse;
 	} else if (!strcmp(key, "down_u")) {
 		slot = &g_down_u;
 	} else if (!strcmp(key, "down_u4")) {
@@ -1214,6 +1308,10 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_down_one;
 	} else if (!strcmp(key, "out_one")) {
 		slot = &g_out_one;
+	} else if (!strcmp(key, "moe_route")) {
+		slot = &g_moe_route;
+	} else if (!strcmp(key, "down_seg")) {
+		slot = &g_down_seg;
 
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
@@ -1320,6 +1418,9 @@ extern "C" void init_hip(void) {
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
+	g_attn_fuse = env_int("CALM_HIP_ATTN_FUSE", g_attn_fuse);
+	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
+	g_down_seg = env_int("CALM_HIP_DOWN_SEG", g_down_seg);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
@@ -1419,7 +1520,9 @@ void prepare_ctx(struct Transformer* t) {
 	c->q = (float*)dev_alloc(c->q_dim * sizeof(float));
 	c->att = (float*)dev_alloc(c->q_dim * sizeof(float));
 	c->he = (float*)dev_alloc((size_t)nact * c->hidden * sizeof(float));
-	c->partial = (float*)dev_alloc((size_t)c->n_heads * MAX_SPLIT * (c->head_dim + 2) * sizeof(float));
+	c->partial = (float*)dev_alloc((size_t)c->n_heads * MAX_SPLIT * (c->head_dim + 4) * sizeof(float));
+	c->attn_count = (unsigned*)dev_alloc((size_t)c->n_heads * sizeof(unsigned));
+	HIP_CHECK(hipMemset(c->attn_count, 0, (size_t)c->n_heads * sizeof(unsigned)));
 	c->logits_d = (float*)dev_alloc((size_t)c->vocab * sizeof(float));
 	// routing of the last step: [layer][rank] weights, then [layer][rank] expert ids, one allocation (shown to the host as state.exp)
 	c->moe_w = (float*)dev_alloc((size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int)));
@@ -1440,12 +1543,53 @@ void prepare_ctx(struct Transformer* t) {
 	// head size 128: the value cache a second time behind the first, transposed ([layer][kv_head][head_dim][seq_len]) -- the operand
 	// layout of the matrix-core split attention (kernels.hip.h k_attn_vt); both are written by the same epilogues
 	const size_t kv_bytes = c->kv_layer_bytes * c->n_layers;
-	const bool vt = attn_has_vt(c->head_dim) && c->seq_len % 64 == 0; // (whole 64-position blocks: attn_vt_offset)
+	// ... only where it can be used: the knob "attn_vt" on at prepare time (CALM_HIP_ATTN_VT=0 or calm_hip_configure before
+	// prepare_hip saves the memory: + 50 % of the KV cache), whole 64-position blocks (attn_vt_offset), and a window longer than
+	// the contexts the unsplit kernel serves.  It is a separate allocation: if it does not fit, the backend runs without it
+	// (k_attn_gqa; the epilogues skip the transposed stores when Ctx::vt is null).
+	const bool vt = g_attn_vt && attn_has_vt(c->head_dim) && c->seq_len % 64 == 0 && c->seq_len > g_split_min;
 	c->kc = dev_alloc(kv_bytes);
-	c->vc = dev_alloc(kv_bytes * (vt ? 2 : 1));
-	c->vt = vt ? (char*)c->vc + kv_bytes : nullptr;
+	c->vc = dev_alloc(kv_bytes);
 	HIP_CHECK(hipMemset(c->kc, 0, kv_bytes));
-	HIP_CHECK(hipMemset(c->vc, 0, kv_bytes * (vt ? 2 : 1)));
+	HIP_CHECK(hipMemset(c->vc, 0, kv_bytes));
+	if (vt) {
+		if (hipMalloc(&c->vt, kv_bytes + DEV_PAD) == hipSuccess) {
+			HIP_CHECK(hipMemset(c->vt, 0, kv_bytes));
+		} else {
+			(void)hipGetLastError();
+			c->vt = nullptr;
+			fprintf(stderr, "calm_hip: no room for the transposed value cache (%.1f GiB): split attention falls back to k_attn_gqa\n", (double)kv_bytes / (1 << 30));
+		}
+	}
+
+	// mixture of experts: the router's table per layer (kernels.hip.h k_attn_out GATE / k_gate_prep) and the partial-sum buffer.  Not for
+	// parallel-residual models (their FFN reads the attention norm's output, which k_attn_out does not produce).
+	if (c->n_experts > 0 && c->n_experts <= GATE_MAX_E && !p->norm_par) {
+		int ep = 1;
+		while (ep < c->n_experts) {
+			ep *= 2;
+		}
+		c->gate_ep = ep;
+		const size_t per_layer = ((size_t)c->dim + 1) * ep;
+		c->gate_mt = (float*)dev_alloc(per_layer * c->n_layers * sizeof(float));
+		c->gate_part = (float*)dev_alloc((size_t)(GATE_MAX_E + 2) * GATE_COLS * sizeof(float));
+		HIP_CHECK(hipMemsetAsync(c->gate_part, 0, (size_t)(GATE_MAX_E + 2) * GATE_COLS * sizeof(float), g_stream));
+		for (int l = 0; l < c->n_layers; ++l) {
+			float* mt = c->gate_mt + per_layer * l;
+			const dim3 grid(ep + (c->dim + 255) / 256);
+			switch (c->dbits) {
+			case 16:
+				hipLaunchKernelGGL(k_gate_prep<16>, grid, dim3(256), 0, g_stream, mt, w->moegate[l], w->rms_ffn_weight[l], c->dim, c->n_experts, ep);
+				break;
+			case 8:
+				hipLaunchKernelGGL(k_gate_prep<8>, grid, dim3(256), 0, g_stream, mt, w->moegate[l], w->rms_ffn_weight[l], c->dim, c->n_experts, ep);
+				break;
+			default:
+				hipLaunchKernelGGL(k_gate_prep<4>, grid, dim3(256), 0, g_stream, mt, w->moegate[l], w->rms_ffn_weight[l], c->dim, c->n_experts, ep);
+			}
+		}
+		HIP_CHECK(hipGetLastError());
+	}
 
 	// RoPE frequencies with the host libm -- the very expression of src/infer.c:226 -- so that
 	// pos * freq is bit-identical to the CPU path's; cos/sin of one position step for the sink keys
@@ -1699,8 +1843,15 @@ extern "C" void release_hip(struct Transformer* t) {
 	for (hipEvent_t e : c->events) {
 		HIP_CHECK(hipEventDestroy(e));
 	}
+	if (c->vt) {
+		HIP_CHECK(hipFree(c->vt));
+	}
+	if (c->gate_mt) {
+		HIP_CHECK(hipFree(c->gate_mt));
+		HIP_CHECK(hipFree(c->gate_part));
+	}
 	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->sample_st, c->logits_d, c->moe_w,
-	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc};
+	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc, c->attn_count};
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}

@@ -568,11 +568,22 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // register tiles alternate through a 2x-unrolled loop body so all tile indices are compile-time.
 // aux_of(t, aux) may issue small loads the epilogue needs (residual value, RoPE pair); it runs before the
 // task's last multiply-add so that latency hides behind it.  epi(t, acc, aux): sums valid in lane RED_LANE.
-template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
-__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+//
+// SEGS (k_ffn_down of a mixture-of-experts model): a task's "row" is the CONCATENATION of `segs` rows of n columns each -- the
+// same output row of several experts' matrices, each against its own expert's hidden vector -- so that one uninterrupted tile
+// stream covers all of them (a restart per expert drained the pipeline and paid a prologue each time).  rows_of(t, seg, rows)
+// names segment seg's rows; segment seg's image starts seg * (chunks of n) * CS slots into xs4; every segment is walked in whole
+// steps (its last step's surplus chunks clamp into the row, as they do at the end of any row); at the end of EVERY segment the
+// sums are reduced and handed to epi(t, seg, acc, aux), which keeps the running value -- the experts are added in rank order by
+// the same lane, exactly as with one pass per expert.  aux_of runs before segment 0's last multiply-add.
+template <int DB, int NR, int U, bool FULL, bool SEGS, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                               StageFn stage, AuxFn aux_of, EpiFn epi) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
+	const int cpi = (nl + 63) >> 6;           // chunks of one segment's row (and of its image)
+	const int cps = (cpi + U - 1) / U * U;    // ... walked in whole steps
+	const int ksteps = SEGS ? segs * cps : 0; // chunk positions of a task
 	const unsigned char* rows[2][NR];
 	Tile<NR, U> tile[2];
 	f32x2 acc2[NR];
@@ -588,15 +599,20 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	// compiler's vmcnt bookkeeping is exact and every wait is "the tile two issues ago".
 	auto advance = [&](int& t, int& k0, bool& live) { // -> the step after (t, k0)
 		k0 += U;
-		if (k0 * 64 >= nl) {
+		if (SEGS ? k0 >= ksteps : k0 * 64 >= nl) {
 			k0 = 0;
 			t += stride;
 			live = live && t < ntasks;
 		}
 	};
+	auto seg_start = [&](int k0) { return SEGS ? k0 % cps == 0 : k0 == 0; }; // (t, k0) opens a row (SEGS: a segment)
 	auto issue = [&](int ph, int t, int k0, bool live) {
-		if (k0 == 0 || !live) {
-			rows_of(min(t, ntasks - 1), rows[ph]);
+		if (seg_start(k0) || !live) {
+			if constexpr (SEGS) {
+				rows_of(min(t, ntasks - 1), live ? k0 / cps : 0, rows[ph]);
+			} else {
+				rows_of(min(t, ntasks - 1), rows[ph]);
+			}
 		}
 		if (!live) {
 #pragma unroll
@@ -604,7 +620,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 				rows[ph][r] = (const unsigned char*)dummy;
 			}
 		}
-		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? k0 : 0, nl, lane);
+		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? (SEGS ? k0 % cps : k0) : 0, nl, lane);
 	};
 
 #ifdef CALM_TIMELINE
@@ -637,7 +653,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	bool live1 = live;
 	issue(0, t, 0, live);
 	advance(t1, k1, live1);
-	if (k1 != 0) { // same task, next k-offset: same rows
+	if (!seg_start(k1)) { // same task (and segment), next k-offset: same rows
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
 			rows[1][r] = rows[0][r];
@@ -662,11 +678,12 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 #pragma unroll
 		for (int ph = 0; ph < 2; ++ph) {
 			// (t, k0) lives in tile[ph]; (t1, k1) in tile[ph ^ 1]
-			const bool last_k = (k0 + U) * 64 >= nl;
-			if (last_k) {
+			const int seg = SEGS ? k0 / cps : 0, kl = SEGS ? k0 - seg * cps : k0; // segment, chunk offset inside it
+			const bool last_k = SEGS ? kl + U >= cps : (k0 + U) * 64 >= nl;          // the row's (segment's) last step
+			if (last_k && seg == 0) {
 				aux_of(t, aux);
 			}
-			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, xs4, k0, nl, lane);
+			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, SEGS ? xs4 + seg * cpi * Fmt<DB>::CS : xs4, kl, nl, lane);
 #ifdef CALM_TIMELINE
 			if (tl[2] == 0) {
 				asm volatile("" ::"v"(acc2[0][0]));
@@ -676,7 +693,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 			int t2 = t1, k2 = k1;
 			bool live2 = live1;
 			advance(t2, k2, live2);
-			if (k2 != 0 && live2) { // continues the task of step s+1: same rows
+			if (!seg_start(k2) && live2) { // continues the row of step s+1: same rows
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					rows[ph][r] = rows[ph ^ 1][r];
@@ -689,7 +706,11 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
 					acc2[r] = (f32x2){0.f, 0.f};
 				}
-				epi(t, acc, aux);
+				if constexpr (SEGS) {
+					epi(t, seg, acc, aux);
+				} else {
+					epi(t, acc, aux);
+				}
 			}
 			if (!live1) {
 #ifdef CALM_TIMELINE
@@ -709,7 +730,13 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                          StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+	run_rows_impl<DB, NR, U, FULL, false>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+}
+// ... over rows of `segs` segments of n columns each (run_rows_impl: SEGS)
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+__device__ __forceinline__ void run_rows_segs(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
+	run_rows_impl<DB, NR, U, FULL, true>(ntasks, first, stride, n, segs, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
 // Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
@@ -1001,7 +1028,8 @@ struct AttnArgs {
 	const float* q;
 	const void *kc, *vc; // this layer's caches
 	float* out;          // (q_dim) normalised attention output, written when n_split == 1
-	float* partial;      // (n_heads, n_split, head_dim + 2) when n_split > 1: o[head_dim], m, l
+	float* partial;      // (n_heads, n_split, pstride) when n_split > 1: o[head_dim], m, l (k_attn_gqa: pstride = head_dim + 2; k_attn_vt: head_dim + 4)
+	unsigned* count;     // k_attn_vt FUSE: arrival counters, one per (kv head, query-head group); zero between launches
 	const TokState* ts;
 	int head_dim, kv_mul, seq_len, n_split;
 	// batched prompt ingestion (prefill.hip.h: k_pf_attn): token b of the chunk reads q + b * pf_stride, attends to
@@ -1478,24 +1506,42 @@ __device__ __forceinline__ void att_split2(float a, float b, unsigned& hi, unsig
 	lo = __builtin_bit_cast(unsigned, __floats2half2_rn(a - hf.x, b - hf.y));
 }
 
-template <int KVB, int QH>
-__global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float* qin, const void* kc, const void* vt, int head_dim, int kv_mul, int seq_len, int n_split, AttnArgs a) {
+// QHM (4 / 8): columns of the 16-wide MFMA tile a workgroup may use; `qh` <= QHM query heads of one kv head share a workgroup (all
+// kv_mul of them when kv_mul <= 8: DBRX's 6, Yi-34B's 7 -- each K / V tile is then read once per kv head; columns beyond qh are zero).
+// The fp32 query is split into hi + lo binary16 AFTER a per-head power-of-two scaling that brings its largest component to 2^14
+// (exact; undone, together with 1 / sqrt(head size), on the scores): any finite query fits, and small components keep their lo part.
+// FUSE (knob "attn_fuse"): no merge launch.  A workgroup's partial rows are written THROUGH (sc1 stores), drained, and counted in
+// on the (kv head, head group)'s arrival counter; the LAST of the n_split workgroups to arrive reads all partials of its heads past
+// its caches (sc1 loads), folds them in split order -- the result does not depend on who came last -- and writes the attention
+// output.  (The hand-off form of prefill.hip.h's K-range GEMMs; MI355X_MICROARCH.md "handoff-flag".)
+constexpr int ATTN_MAX_SPLIT = 64;
+constexpr int ATTN_VT_PSTRIDE = 128 + 4; // partial row: o[128], m, l, 2 pad -- rows stay 16-byte aligned
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+constexpr int BUF_SC1 = 16; // cache-policy operand of the raw buffer builtins: agent scope (written through / served past the L1)
+
+template <int KVB, int QHM, bool FUSE>
+__global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float* qin, const void* kc, const void* vt, int head_dim, int kv_mul, int seq_len, int n_split, int qh, AttnArgs a) {
 	constexpr int HD = 128, NW = 4;
 	constexpr int EB = KVB / 8;
 	constexpr int NT = KVB == 16 ? 1 : 2, TILE = 32 * NT; // keys per tile (8 KiB of K, 8 KiB of V^T either way)
 	constexpr int CPR = HD * EB / 16;                     // 16-byte chunks per K row: 16 / 8
 	constexpr int RPL = 64 / CPR;                         // K rows per wave-load: 4 / 8
+	constexpr int PS = ATTN_VT_PSTRIDE;
 	__shared__ u32x4 kst[NW][512];
 	__shared__ u32x4 vst[NW][512];
-	__shared__ float sm_m[QH][NW], sm_l[QH][NW];
-	__shared__ float sm_o[QH][NW][HD];
+	__shared__ float sm_m[QHM][NW], sm_l[QHM][NW];
+	__shared__ __attribute__((aligned(16))) float sm_o[QHM][NW][HD + 4]; // (+ 4: the heads' rows start 16 banks apart)
+	__shared__ unsigned arrived;
 
 	const int lane = lane_id(), wave = wave_id();
-	const int qgroups = kv_mul / QH;
+	const int qgroups = kv_mul / qh;
 	const int split = blockIdx.x % n_split;
 	const int qg = (blockIdx.x / n_split) % qgroups;
 	const int kvh = blockIdx.x / (n_split * qgroups);
-	const int h0 = kvh * kv_mul + qg * QH;
+	const int h0 = kvh * kv_mul + qg * qh;
 	const int n = lane & 15, kb = lane >> 4; // MFMA column (query) / row (key, d) index, k-block = C row group
 	const int kv_len = ts->kv_len;
 	const int chunk = ((kv_len + n_split - 1) / n_split + 63) & ~63;
@@ -1543,21 +1589,36 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 	// the queries as B operands: column n = head h0 + n; k-step t, k-block kb, element e is head dimension 32 t + 8 kb + e for a binary16
 	// cache and 64 (t >> 1) + 16 kb + 8 (t & 1) + e for an e5m2 one (a lane's 16-byte chunk of a K row then holds its operands of two
 	// k-steps; the order of the summation over the head dimension is free as long as K and q agree)
-	u32x4 qh[4], ql[4];
+	u32x4 qh_[4], ql_[4];
+	float post; // what a score of this lane's query column is multiplied by: 1 / (sqrt(head size) * the query's scaling)
+	{
+		float4 q0[4], q1[4];
+		float mx = 0.f;
 #pragma unroll
-	for (int t = 0; t < 4; ++t) {
-		const float* qsrc = qin + (size_t)(h0 + (n < QH ? n : 0)) * HD + (KVB == 16 ? 32 * t + 8 * kb : 64 * (t >> 1) + 16 * kb + 8 * (t & 1));
-		const float4 q0 = *(const float4*)qsrc, q1 = *(const float4*)(qsrc + 4);
-		unsigned hi, lo;
-		att_split2(q0.x, q0.y, hi, lo), qh[t][0] = hi, ql[t][0] = lo;
-		att_split2(q0.z, q0.w, hi, lo), qh[t][1] = hi, ql[t][1] = lo;
-		att_split2(q1.x, q1.y, hi, lo), qh[t][2] = hi, ql[t][2] = lo;
-		att_split2(q1.z, q1.w, hi, lo), qh[t][3] = hi, ql[t][3] = lo;
-		if (n >= QH) {
-			qh[t] = (u32x4){0u, 0u, 0u, 0u}, ql[t] = (u32x4){0u, 0u, 0u, 0u};
+		for (int t = 0; t < 4; ++t) {
+			const float* qsrc = qin + (size_t)(h0 + (n < qh ? n : 0)) * HD + (KVB == 16 ? 32 * t + 8 * kb : 64 * (t >> 1) + 16 * kb + 8 * (t & 1));
+			q0[t] = *(const float4*)qsrc, q1[t] = *(const float4*)(qsrc + 4);
+			mx = fmaxf(mx, fmaxf(fmaxf(fabsf(q0[t].x), fabsf(q0[t].y)), fmaxf(fabsf(q0[t].z), fabsf(q0[t].w))));
+			mx = fmaxf(mx, fmaxf(fmaxf(fabsf(q1[t].x), fabsf(q1[t].y)), fmaxf(fabsf(q1[t].z), fabsf(q1[t].w))));
+		}
+		mx = fmaxf(mx, __shfl_xor(mx, 16)); // the head's 128 dims sit in the four lanes n, n + 16, n + 32, n + 48
+		mx = fmaxf(mx, __shfl_xor(mx, 32));
+		int e = (int)((__builtin_bit_cast(unsigned, mx) >> 23) & 0xff); // biased exponent of the largest component (NaN / inf: 255)
+		e = e < 30 ? 30 : (e > 250 ? 250 : e);
+		const float up = __builtin_bit_cast(float, (unsigned)(268 - e) << 23); // 2^(14 - (e - 127)): the largest component lands in [2^14, 2^15)
+		post = __builtin_bit_cast(float, (unsigned)(e - 14) << 23) * (1.0f / sqrtf((float)HD));
+#pragma unroll
+		for (int t = 0; t < 4; ++t) {
+			unsigned hi, lo;
+			att_split2(q0[t].x * up, q0[t].y * up, hi, lo), qh_[t][0] = hi, ql_[t][0] = lo;
+			att_split2(q0[t].z * up, q0[t].w * up, hi, lo), qh_[t][1] = hi, ql_[t][1] = lo;
+			att_split2(q1[t].x * up, q1[t].y * up, hi, lo), qh_[t][2] = hi, ql_[t][2] = lo;
+			att_split2(q1[t].z * up, q1[t].w * up, hi, lo), qh_[t][3] = hi, ql_[t][3] = lo;
+			if (n >= qh) {
+				qh_[t] = (u32x4){0u, 0u, 0u, 0u}, ql_[t] = (u32x4){0u, 0u, 0u, 0u};
+			}
 		}
 	}
-	const float inv_sqrt_hd = 1.0f / sqrtf((float)HD);
 	f32x4 o[8];
 #pragma unroll
 	for (int db = 0; db < 8; ++db) {
@@ -1581,8 +1642,8 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 				const int key = 8 * NT * (n >> 2) + 8 * j + 4 * rb + (n & 3); // A row n of this block
 				auto kstep = [&](int t, u32x4 k16) {
 					const f16x8 kop = __builtin_bit_cast(f16x8, k16);
-					s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, qh[t]), s[rb], 0, 0, 0);
-					s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, ql[t]), s[rb], 0, 0, 0);
+					s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, qh_[t]), s[rb], 0, 0, 0);
+					s[rb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kop, __builtin_bit_cast(f16x8, ql_[t]), s[rb], 0, 0, 0);
 				};
 				if constexpr (KVB == 16) {
 #pragma unroll
@@ -1606,7 +1667,7 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 #pragma unroll
 				for (int e = 0; e < 4; ++e) {
 					const int key = tb + 8 * NT * kb + 8 * j + 4 * rb + e;
-					s[rb][e] = (!ragged || key < t1) ? s[rb][e] * inv_sqrt_hd : -INFINITY;
+					s[rb][e] = (!ragged || key < t1) ? s[rb][e] * post : -INFINITY;
 					mt = fmaxf(mt, s[rb][e]);
 				}
 			}
@@ -1663,40 +1724,103 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 	}
 
 	// wave states -> LDS: O^T[d = 16 db + 4 kb + e][query n]
-	if (n < QH) {
+	if (n < qh) {
 		if (kb == 0) {
 			sm_m[n][wave] = m;
 			sm_l[n][wave] = l;
 		}
 #pragma unroll
 		for (int db = 0; db < 8; ++db) {
-#pragma unroll
-			for (int e = 0; e < 4; ++e) {
-				sm_o[n][wave][16 * db + 4 * kb + e] = o[db][e];
-			}
+			*(f32x4*)&sm_o[n][wave][16 * db + 4 * kb] = o[db];
 		}
 	}
 	__syncthreads();
-	// one thread per (query head, output dim) folds the NW wave partials (see k_attn); a split without positions files (-inf, 0, 0)
-	for (int idx = threadIdx.x; idx < QH * HD; idx += 256) {
-		const int q = idx / HD, d = idx % HD;
+	// one thread per (query head, four output dims) folds the NW wave partials (see k_attn); a split without positions files
+	// (-inf, 0, 0).  Rows of PS floats: o[HD], m, l.
+	const __amdgpu_buffer_rsrc_t prs = buf_rsrc(a.partial);
+	auto prow = [&](int q, int s_) { return (int)((((h0 + q) * n_split + s_) * PS) * sizeof(float)); }; // byte offset of a partial row
+	for (int idx = threadIdx.x; idx < qh * (HD / 4); idx += 256) {
+		const int q = idx / (HD / 4), d = (idx % (HD / 4)) * 4;
 		float M = sm_m[q][0];
 #pragma unroll
 		for (int w = 1; w < NW; ++w) {
 			M = fmaxf(M, sm_m[q][w]);
 		}
-		float L = 0.f, O = 0.f;
+		float L = 0.f;
+		f32x4 O = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
 		for (int w = 0; w < NW; ++w) {
 			const float e = (sm_m[q][w] == -INFINITY) ? 0.f : __expf(sm_m[q][w] - M);
 			L = fmaf(sm_l[q][w], e, L);
-			O = fmaf(sm_o[q][w][d], e, O);
+			O += *(const f32x4*)&sm_o[q][w][d] * e;
 		}
-		float* p = a.partial + ((size_t)(h0 + q) * n_split + split) * (HD + 2);
-		p[d] = O;
+		typedef int i32x4 __attribute__((ext_vector_type(4)));
+		typedef int i32x2 __attribute__((ext_vector_type(2)));
+		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, O), prs, prow(q, split) + d * 4, 0, FUSE ? BUF_SC1 : 0);
 		if (d == 0) {
-			p[HD] = M;
-			p[HD + 1] = L;
+			const f32x2 ml = {M, L};
+			__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, ml), prs, prow(q, split) + HD * 4, 0, FUSE ? BUF_SC1 : 0);
+		}
+	}
+	if constexpr (FUSE) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial rows have left this CU (written through) before the arrival is counted
+		__syncthreads();
+		unsigned* cnt = a.count + kvh * qgroups + qg;
+		if (threadIdx.x == 0) {
+			arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__syncthreads();
+		if (arrived != (unsigned)n_split - 1) {
+			return;
+		}
+		if (threadIdx.x == 0) {
+			__hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+		}
+		// the last workgroup of this head group: every split's partial rows, read past the caches.  Thread (q, four dims) asks for its
+		// piece of up to 32 splits at once, then the (m, l) pairs go through LDS (the K image is free) -- one round trip per 32 splits.
+		float2* sm_ml = (float2*)&kst[0][0]; // [QHM][ATTN_MAX_SPLIT]
+		const int idx = threadIdx.x, q = idx / (HD / 4), d = (idx % (HD / 4)) * 4;
+		const bool mine = idx < qh * (HD / 4); // (QHM = 8: 256 threads; QHM = 4: the first 128)
+		constexpr int NS = 32;
+		f32x4 v[NS];
+		auto load_v = [&](int s0) {
+#pragma unroll
+			for (int i = 0; i < NS; ++i) {
+				const int sc = min(s0 + i, n_split - 1); // (past the last split: re-read it, weight 0)
+				v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, prow(mine ? q : 0, sc) + d * 4, 0, BUF_SC1));
+			}
+		};
+		if (mine) {
+			load_v(0);
+		}
+		for (int i = threadIdx.x; i < qh * n_split; i += 256) {
+			const int qq = i / n_split, ss = i % n_split;
+			const f32x2 ml = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prs, prow(qq, ss) + HD * 4, 0, BUF_SC1));
+			sm_ml[qq * ATTN_MAX_SPLIT + ss] = make_float2(ml[0], ml[1]);
+		}
+		__syncthreads();
+		float M = -INFINITY;
+		for (int s_ = 0; s_ < n_split; ++s_) {
+			M = fmaxf(M, sm_ml[(mine ? q : 0) * ATTN_MAX_SPLIT + s_].x);
+		}
+		float L = 0.f;
+		f32x4 O = {0.f, 0.f, 0.f, 0.f};
+		for (int s0 = 0; s0 < n_split; s0 += NS) {
+			if (s0 > 0 && mine) {
+				load_v(s0);
+			}
+#pragma unroll
+			for (int i = 0; i < NS; ++i) {
+				if (s0 + i < n_split) {
+					const float2 ml = sm_ml[(mine ? q : 0) * ATTN_MAX_SPLIT + s0 + i];
+					const float w = ml.x == -INFINITY ? 0.f : __expf(ml.x - M); // (a split without positions)
+					L = fmaf(ml.y, w, L);
+					O += v[i] * w;
+				}
+			}
+		}
+		if (mine) {
+			*(f32x4*)(a.out + (size_t)(h0 + q) * HD + d) = O / L;
 		}
 	}
 }
@@ -1707,11 +1831,9 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 // exp(m_s - M) are then one exponential per lane and reach the fold through v_readlane.  (First form: wave 0 fetched the (m, l)
 // pairs, a barrier, then eight partial loads at a time: three dependent round trips, 5.1 us per launch for 130 KB --
 // profiles/r03_long_context.txt.)
-constexpr int ATTN_MAX_SPLIT = 64;
 template <int NS>
-__global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float* out, int head_dim, int n_split) {
+__global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float* out, int head_dim, int n_split, int stride) {
 	const int h = blockIdx.x, d = threadIdx.x, lane = lane_id();
-	const int stride = head_dim + 2;
 	const float* p = partial + (size_t)h * n_split * stride;
 	const int dc = d < head_dim ? d : 0;
 	float v[NS];
@@ -1743,8 +1865,17 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 #ifndef CALM_ONE_U
 #define CALM_ONE_U 2
 #endif
-template <int DB, int V, bool FULL, bool ONE>
-__global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim) {
+// GATE (mixture-of-experts models, knob "moe_route"): the router's logits for the FFN that follows are LINEAR in the residual this
+// kernel completes -- logit_e = rsqrt(mean(x^2) + eps) * sum_j moegate[e][j] g[j] x[j] (src/infer.c:183-207 then :422-424) -- so the
+// lane that writes x[j] also adds x[j] * (moegate[e][j] g[j]) for every expert e (lane e of the wave: one coalesced load of row j of
+// the [dim][EP] fp32 table `gate_mt` that prepare_hip derives from moegate and the FFN norm weight, k_gate_prep), x[j]^2 and x[j];
+// the workgroup's sums go to column blockIdx.x of `gate_part` ([EP + 2][GATE_COLS]: EP logit partials, sum of squares, sum).
+// k_ffn_up folds the columns in a fixed order and knows its experts before it has seen the vector (k_ffn_up, MOE == 2): the
+// routing left that kernel's critical path, where it stood between the launch and the first weight byte.
+constexpr int GATE_COLS = 1024; // workgroups of k_attn_out the partial buffer has columns for
+constexpr int GATE_MAX_E = 64;  // experts (one per lane)
+template <int DB, int V, bool FULL, bool ONE, bool GATE>
+__global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim, const float* gate_mt, float* gate_part, int ep) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = ONE ? 1 : KShape<DB, KS_ATTN_OUT>::NR, U = ONE ? CALM_ONE_U * KShape<DB, KS_ATTN_OUT>::U : KShape<DB, KS_ATTN_OUT>::U;
 	float4* xs4 = (float4*)smem;
@@ -1760,14 +1891,31 @@ __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* 
 	StageRegs<V, false> sr;
 	auto pre = [&]() { stage_load<WG_THREADS>(sr, att, nullptr); stage_first_barrier(); };
 	auto stage = [&]() { stage_finish<DB, WG_THREADS>(sr, xs4, red, att, nullptr, q_dim, 0.f, false, nullptr); };
+	float mt[NR];                       // GATE: this lane's expert's table entry of each row of the task
+	float gacc = 0.f, ss = 0.f, sx = 0.f; // GATE: lane e: logit partial of expert e; every lane: sum of squares, sum
+	const int el = GATE ? lane & (ep - 1) : 0;
 	auto aux_of = [&](int t, float(&aux)[NR]) { // the residual values this task adds to
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
 			aux[r] = x[t * NR + r];
+			if constexpr (GATE) {
+				mt[r] = gate_mt[(size_t)(t * NR + r) * ep + el];
+			}
 		}
 	};
 	auto epi = [&](int t, float(&acc)[NR], float(&aux)[NR]) {
-		if (lane == RED_LANE) {
+		if constexpr (GATE) {
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				const float xn = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, aux[r] + acc[r]), RED_LANE));
+				gacc = fmaf(xn, mt[r], gacc);
+				ss = fmaf(xn, xn, ss);
+				sx += xn;
+				if (lane == RED_LANE) {
+					x[t * NR + r] = xn;
+				}
+			}
+		} else if (lane == RED_LANE) {
 #pragma unroll
 			for (int r = 0; r < NR; ++r) {
 				x[t * NR + r] = aux[r] + acc[r];
@@ -1775,6 +1923,57 @@ __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* 
 		}
 	};
 	run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
+	if constexpr (GATE) {
+		// the waves' sums -> LDS -> one column of the partial buffer, waves added in index order
+		constexpr int W = GATE_MAX_E + 2;
+		const int wave = wave_id();
+		if (lane < ep) {
+			red[wave * W + lane] = gacc;
+		}
+		if (lane == 0) {
+			red[wave * W + GATE_MAX_E] = ss;
+			red[wave * W + GATE_MAX_E + 1] = sx;
+		}
+		__syncthreads();
+		const int q = threadIdx.x;
+		if (q < ep + 2) {
+			const int src = q < ep ? q : GATE_MAX_E + (q - ep);
+			float v = red[src];
+#pragma unroll
+			for (int w = 1; w < WG_WAVES; ++w) {
+				v += red[w * W + src];
+			}
+			gate_part[(size_t)q * GATE_COLS + blockIdx.x] = v;
+		}
+	}
+}
+
+// gate_mt of one layer (prepare_hip): mt[j][e] = moegate[e][j] * g[j] for e < n_experts, 0 up to ep (a power of two); behind the
+// table, c[e] = sum_j mt[j][e] -- what a LayerNorm's mean takes off every logit.  grid = ep + ceil(dim / 256) workgroups of 256:
+// the first ep each sum one expert's column in a fixed order, the others fill the table.
+template <int DB>
+__global__ __launch_bounds__(256) void k_gate_prep(float* mt, const void* moegate, const float* g, int dim, int n_experts, int ep) {
+	__shared__ float red[4];
+	const int b = blockIdx.x;
+	if (b < ep) {
+		float s_ = 0.f;
+		if (b < n_experts) {
+			for (int j = threadIdx.x; j < dim; j += 256) {
+				s_ += decode_elem<DB>(moegate, (size_t)b * dim + j) * g[j];
+			}
+		}
+		const float t = block_sum<256>(s_, red);
+		if (threadIdx.x == 0) {
+			mt[(size_t)dim * ep + b] = t;
+		}
+		return;
+	}
+	const int j = (b - ep) * 256 + threadIdx.x;
+	if (j < dim) {
+		for (int e = 0; e < ep; ++e) {
+			mt[(size_t)j * ep + e] = e < n_experts ? decode_elem<DB>(moegate, (size_t)e * dim + j) * g[j] : 0.f;
+		}
+	}
 }
 
 // ---- FFN up: hb = act(w1 . xn) * (w3 . xn), with optional MoE routing --------------------------
@@ -1789,7 +1988,65 @@ struct FfnUpArgs {
 	int dim, hidden, n_experts, n_active;
 	float eps;
 	int ln, gelu;
+	const float* gate_c; // MOE == 2: c[e] behind the layer's gate_mt table (k_gate_prep), what a LayerNorm's mean takes off logit e
 };
+
+// The router (src/infer.c:277-305), by ONE wave, one expert per lane (n_experts <= 64): n_active rounds of a wave-wide arg-max over
+// the logits not yet taken -- larger logit wins, equal logits go to the lower expert index -- then the softmax over the winners
+// only, their exponentials summed in rank order; rank k's expert and weight end up in sel_e[k] / sel_w[k] (and, if out_w, there).
+__device__ __forceinline__ void moe_route(float logit, int n_experts, int n_active, int* sel_e, float* sel_w, float* out_w, int* out_e) {
+	const int lane = lane_id();
+	const bool valid = lane < n_experts;
+	logit = valid ? logit : 0.f;
+	float top = logit; // the largest logit overall: the softmax's reference point
+	{
+		bool ok = valid;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float v2 = __shfl_xor(top, o);
+			const bool ok2 = __shfl_xor((int)ok, o) != 0;
+			if (ok2 && (!ok || v2 > top)) {
+				top = v2;
+				ok = true;
+			}
+		}
+	}
+	bool open = valid; // this lane's expert can still be picked
+	float rank_logit = 0.f;
+	int rank_expert = 0;
+	for (int k = 0; k < n_active; ++k) {
+		float bv = logit;
+		int bi = lane;
+		bool ok = open;
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const float v2 = __shfl_xor(bv, o);
+			const int i2 = __shfl_xor(bi, o);
+			const bool ok2 = __shfl_xor((int)ok, o) != 0;
+			if (ok2 && (!ok || v2 > bv || (v2 == bv && i2 < bi))) {
+				bv = v2, bi = i2, ok = true;
+			}
+		}
+		open = open && lane != bi;
+		if (lane == k) {
+			rank_logit = bv;
+			rank_expert = bi;
+		}
+	}
+	const float ex = lane < n_active ? expf(rank_logit - top) : 0.f;
+	float denom = 0.f;
+	for (int k = 0; k < n_active; ++k) {
+		denom += __shfl(ex, k);
+	}
+	if (lane < n_active) {
+		sel_e[lane] = rank_expert;
+		sel_w[lane] = ex / denom;
+		if (out_w) {
+			out_w[lane] = ex / denom;
+			out_e[lane] = rank_expert;
+		}
+	}
+}
 
 __device__ __forceinline__ float act_silu(float x) {
 	return x / (1.0f + expf(-x)); // src/infer.c:273-275
@@ -1799,7 +2056,9 @@ __device__ __forceinline__ float act_gelu(float x) {
 }
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
-template <int DB, int V, bool FULL, bool MOE>
+// MOE: 0 dense; 1 the gate computed here, by every workgroup, from the vector (below); 2 the gate folded from the partials
+// k_attn_out's epilogue left (`moegate` then points at gate_part, `n_experts` carries n_experts | k_attn_out's grid << 8).
+template <int DB, int V, bool FULL, int MOE>
 __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1807,15 +2066,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	constexpr int JP = NR / 2; // hidden units per task
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
-	float* gate = red + 16;          // n_experts logits
-	float* sel_w = gate + 64;        // n_active
-	int* sel_e = (int*)(sel_w + 64); // n_active
+	float* gate = red + 16;                   // n_experts logits (MOE == 2: + sum of squares, sum)
+	float* sel_w = gate + GATE_MAX_E + 2;     // n_active
+	int* sel_e = (int*)(sel_w + GATE_MAX_E);  // n_active
 	const size_t row_bytes = (size_t)dim * DB / 8;
 	const int lane = lane_id(), wave = wave_id();
 	const int nact = n_active > 0 ? n_active : 1;
 	const int per_expert = hidden / JP;
 	const int ntasks = nact * per_expert;
-	constexpr bool moe = MOE;
+	constexpr bool moe = MOE != 0;
 
 	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
 		int k = t / per_expert, j = (t % per_expert) * JP;
@@ -1841,7 +2100,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	};
 
 	StageRegs<V, true> sr;
-	if constexpr (!MOE) {
+	if constexpr (MOE == 0) {
 		auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
 		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
 		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
@@ -1849,6 +2108,62 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
 		}
+		return;
+	}
+
+	if constexpr (MOE == 2) {
+		// The routing from k_attn_out's partial sums: [ne + 2][GATE_COLS] floats, `cols` live columns (one per workgroup of that
+		// launch).  Quantity q (expert logits, then the sum of squares and the sum) is folded by wave q % WG_WAVES: every lane
+		// adds its float4s' live columns in index order, then the wave's DPP tree -- the same order in every workgroup, so all of
+		// them pick the same experts -- and every load of a wave is in flight at once (one round trip).  The vector's own
+		// loads go out first (the image needs them right after); nothing here waits for the image.
+		const int ne = n_experts & 0xff, cols = n_experts >> 8, nq = ne + 2;
+		const float* part = (const float*)moegate;
+		stage_load<WG_THREADS>(sr, x, norm_w);
+		constexpr int QB = 5, C4 = GATE_COLS / 256; // quantities per wave and batch, float4s per lane and quantity
+		for (int qb = 0; qb < nq; qb += WG_WAVES * QB) {
+			float4 v[QB][C4];
+#pragma unroll
+			for (int j = 0; j < QB; ++j) {
+				const int q = qb + wave + WG_WAVES * j;
+#pragma unroll
+				for (int i = 0; i < C4; ++i) {
+					v[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+					if (q < nq && i * 256 < cols) { // wave-uniform
+						v[j][i] = *((const float4*)(part + (size_t)q * GATE_COLS) + i * 64 + lane);
+					}
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < QB; ++j) {
+				const int q = qb + wave + WG_WAVES * j;
+				if (q < nq) { // wave-uniform
+					float s_ = 0.f;
+#pragma unroll
+					for (int i = 0; i < C4; ++i) {
+						const int c0 = i * 256 + lane * 4;
+						s_ += (c0 < cols ? v[j][i].x : 0.f) + (c0 + 1 < cols ? v[j][i].y : 0.f) + (c0 + 2 < cols ? v[j][i].z : 0.f) + (c0 + 3 < cols ? v[j][i].w : 0.f);
+					}
+					s_ = wave_sum63(s_);
+					if (lane == RED_LANE) {
+						gate[q] = s_;
+					}
+				}
+			}
+		}
+		__syncthreads();
+		if (wave == 0) {
+			const float n = (float)dim;
+			const float mean = a.ln ? gate[ne + 1] / n : 0.f;                       // src/infer.c:183-207
+			const float scale = 1.0f / sqrtf(gate[ne] / n - mean * mean + a.eps);
+			const int le = lane < ne ? lane : 0;
+			const float c = a.ln ? a.gate_c[le] : 0.f;
+			moe_route((gate[le] - mean * c) * scale, ne, n_active, sel_e, sel_w, blockIdx.x == 0 ? a.moe_w : nullptr, a.moe_e);
+		}
+		__syncthreads();
+		auto nothing = [&]() {};
+		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
+		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, nothing, stage, no_aux, epi);
 		return;
 	}
 
@@ -1908,59 +2223,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		}
 		__syncthreads();
 		if (wave == 0) {
-			// Routing, one expert per lane (n_experts <= 64): n_active rounds of a wave-wide arg-max over the logits not yet
-			// taken -- larger logit wins, equal logits go to the lower expert index -- then the softmax over the winners only,
-			// their exponentials summed in rank order (the semantics of src/infer.c:277-305; rank k ends up in lane k).
-			const bool valid = lane < n_experts;
-			const float logit = valid ? gate[valid ? lane : 0] : 0.f;
-			float top = logit; // the largest logit overall: the softmax's reference point
-			{
-				bool ok = valid;
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1) {
-					const float v2 = __shfl_xor(top, o);
-					const bool ok2 = __shfl_xor((int)ok, o) != 0;
-					if (ok2 && (!ok || v2 > top)) {
-						top = v2;
-						ok = true;
-					}
-				}
-			}
-			bool open = valid; // this lane's expert can still be picked
-			float rank_logit = 0.f;
-			int rank_expert = 0;
-			for (int k = 0; k < n_active; ++k) {
-				float bv = logit;
-				int bi = lane;
-				bool ok = open;
-#pragma unroll
-				for (int o = 32; o > 0; o >>= 1) {
-					const float v2 = __shfl_xor(bv, o);
-					const int i2 = __shfl_xor(bi, o);
-					const bool ok2 = __shfl_xor((int)ok, o) != 0;
-					if (ok2 && (!ok || v2 > bv || (v2 == bv && i2 < bi))) {
-						bv = v2, bi = i2, ok = true;
-					}
-				}
-				open = open && lane != bi;
-				if (lane == k) {
-					rank_logit = bv;
-					rank_expert = bi;
-				}
-			}
-			const float ex = lane < n_active ? expf(rank_logit - top) : 0.f;
-			float denom = 0.f;
-			for (int k = 0; k < n_active; ++k) {
-				denom += __shfl(ex, k);
-			}
-			if (lane < n_active) {
-				sel_e[lane] = rank_expert;
-				sel_w[lane] = ex / denom;
-				if (blockIdx.x == 0) {
-					a.moe_w[lane] = ex / denom;
-					a.moe_e[lane] = rank_expert;
-				}
-			}
+			moe_route(gate[lane < n_experts ? lane : 0], n_experts, n_active, sel_e, sel_w, blockIdx.x == 0 ? a.moe_w : nullptr, a.moe_e);
 		}
 		__syncthreads();
 	}
@@ -1982,19 +2245,90 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 // (Tried for mixture-of-experts models: asking for expert k + 1's hidden vector while expert k's rows stream, so that a later expert
 // starts with a barrier and LDS stores only -- Mixtral-8x7B 25.0 us per launch against 23.1 without: the eight extra loads per
 // wave sit in the queue ahead of the next tiles.  Not kept.)
-template <int DB, int BLOCK, int V, int UO, bool FULL>
+// SEG (mixture-of-experts models, knob "down_seg"): the rows of up to FFN_DOWN_SEGS experts at a time are ONE task (run_rows_impl
+// SEGS): all their hidden vectors sit in LDS side by side (Mixtral-8x7B fp8: 2 x 57 KB) and the tile stream never drains between
+// experts -- `seg_cap` = experts per pass (what fits the LDS, balanced over the passes: DBRX's 4 x 43 KB go as 2 + 2).  The
+// epilogue adds expert after expert in rank order through one lane, so the result is bit-identical to the one-pass-per-expert form.
+constexpr int FFN_DOWN_SEGS = 4;
+template <int DB, int BLOCK, int V, int UO, bool FULL, bool SEG>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
-                                                    int n_active, int k0, int kn) {
+                                                    int n_active, int k0, int kn, int seg_cap) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// UO: tiles of 2 rows x UO chunks instead of the format's shape; UO = 1: ONE row x 4 chunks, for matrices of fewer row pairs than
 	// the chip has waves (TinyLlama's 2048 rows: 7.9 -> 6.6 us)
 	constexpr int NR = UO == 1 ? 1 : (UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR), U = UO == 1 ? 4 : (UO ? UO : KShape<DB, KS_FFN_DOWN>::U);
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
-	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	const size_t row_bytes = (size_t)hidden * DB / 8;
 	const int lane = lane_id();
 	const int nact = n_active > 0 ? n_active : 1;
+	if constexpr (SEG) {
+		const int seg_slots = xs_slots<DB>(kn); // float4 slots of one segment's image
+		float* red = (float*)(xs4 + seg_cap * seg_slots);
+		for (int kb = 0; kb < nact; kb += seg_cap) {
+			const int ns = min(seg_cap, nact - kb); // experts of this pass: ranks kb .. kb + ns - 1
+			float wk[FFN_DOWN_SEGS];
+			const unsigned char* wb[FFN_DOWN_SEGS];
+#pragma unroll
+			for (int s_ = 0; s_ < FFN_DOWN_SEGS; ++s_) {
+				const int k = min(kb + s_, nact - 1);
+				wk[s_] = moe_w[k];
+				wb[s_] = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;
+			}
+			auto rows_of = [&](int t, int seg, const unsigned char*(&rows)[NR]) {
+				const unsigned char* base = seg == 0 ? wb[0] : (seg == 1 ? wb[1] : (seg == 2 ? wb[2] : wb[3]));
+#pragma unroll
+				for (int r = 0; r < NR; ++r) {
+					rows[r] = base + (size_t)(t * NR + r) * row_bytes;
+				}
+			};
+			// the first two hidden vectors' loads go out ahead of the first tiles; further ones are staged behind them
+			StageRegs<V, false> sr0, sr1;
+			const float* hk = he + (size_t)kb * hidden + k0;
+			auto pre = [&]() {
+				stage_load<BLOCK>(sr0, hk, nullptr);
+				stage_load<BLOCK>(sr1, hk + (ns > 1 ? hidden : 0), nullptr);
+				stage_first_barrier();
+			};
+			auto stage = [&]() {
+				if (kb > 0) {
+					__syncthreads(); // everyone is done reading the previous pass's images
+				}
+				stage_finish<DB, BLOCK>(sr0, xs4, red, hk, nullptr, kn, 0.f, false, nullptr);
+				if (ns > 1) {
+					stage_finish<DB, BLOCK>(sr1, xs4 + seg_slots, red, hk + hidden, nullptr, kn, 0.f, false, nullptr);
+				}
+				for (int s_ = 2; s_ < ns; ++s_) {
+					StageRegs<V, false> sr;
+					stage_load<BLOCK>(sr, hk + (size_t)s_ * hidden, nullptr);
+					stage_finish<DB, BLOCK>(sr, xs4 + s_ * seg_slots, red, hk + (size_t)s_ * hidden, nullptr, kn, 0.f, false, nullptr);
+				}
+			};
+			auto aux_of = [&](int t, float(&aux)[NR]) { // residual so far
+#pragma unroll
+				for (int r = 0; r < NR; ++r) {
+					aux[r] = x[t * NR + r];
+				}
+			};
+			float carry[NR]; // the task's running value between its segments (lane RED_LANE)
+			auto epi = [&](int t, int seg, float(&acc)[NR], float(&aux)[NR]) {
+				const float w = seg == 0 ? wk[0] : (seg == 1 ? wk[1] : (seg == 2 ? wk[2] : wk[3]));
+#pragma unroll
+				for (int r = 0; r < NR; ++r) {
+					carry[r] = (seg == 0 ? aux[r] : carry[r]) + acc[r] * w;
+				}
+				if (seg == ns - 1 && lane == RED_LANE) {
+#pragma unroll
+					for (int r = 0; r < NR; ++r) {
+						x[t * NR + r] = carry[r];
+					}
+				}
+			};
+			run_rows_segs<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, kn, ns, xs4, he, rows_of, pre, stage, aux_of, epi);
+		}
+		return;
+	}
+	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	for (int k = 0; k < nact; ++k) {
 		const float wk = moe_w[k];
 		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;

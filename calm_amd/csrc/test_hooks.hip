@@ -43,9 +43,9 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 		constexpr int DB = decltype(DBT)::value;
 		by_bool(stage_v4(n, WG_THREADS), [&](auto V4) {
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
-				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, false>;
+				auto k = k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, false, false>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(d / KShape<DB, KS_ATTN_OUT>::NR)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n);
+				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(d / KShape<DB, KS_ATTN_OUT>::NR)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dw, d, n, (const float*)nullptr, (float*)nullptr, 0);
 			});
 		});
 	});
@@ -109,7 +109,9 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	}
 	c.q = (float*)upload_hip((void*)q, q_dim * sizeof(float));
 	c.att = (float*)dev_alloc(q_dim * sizeof(float));
-	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 2) * sizeof(float));
+	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 4) * sizeof(float));
+	c.attn_count = (unsigned*)dev_alloc((size_t)n_heads * sizeof(unsigned));
+	HIP_CHECK(hipMemset(c.attn_count, 0, (size_t)n_heads * sizeof(unsigned)));
 	TokState ts = {};
 	ts.kv_len = kv_len;
 	c.ts = (TokState*)upload_hip(&ts, sizeof(ts));
@@ -121,7 +123,7 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	launch_attn<16>(&c, 0, n_split);
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, c.att, q_dim * sizeof(float));
-	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts);
+	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts), free_hip(c.attn_count);
 	if (c.vt) {
 		free_hip(c.vt);
 	}

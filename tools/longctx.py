@@ -11,7 +11,7 @@ from calm_amd import calmfile as cf
 from calm_amd.host import STAGES, HipBackend, HostModel, generate, load_lib
 
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-spec = cf.SPECS["mistral-7b"]
+spec = cf.SPECS[os.environ.get("MODEL", "mistral-7b")]  # MODEL=dbrx-132b: kv_mul 6 (all six query heads of a kv head share a workgroup)
 lib = load_lib()
 for kv_ in os.environ.get("KNOBS", "").split():  # e.g. KNOBS="split_min=100000"
     key, val = kv_.split("=")
@@ -30,7 +30,7 @@ for kvbits, ctx in ((16, 4096), (8, 32768)) if not os.environ.get("KV16_32K") el
             _, st = generate(be, model, [17], 32, pos_offset=pos + 8, kvbits=kvbits)
             dt = time.perf_counter() - t0
             us, b = be.stage_us(1, 6)
-            kv_mb = 2 * (kvbits // 8) * 1024 * (pos + 40) / 1e6
+            kv_mb = 2 * (kvbits // 8) * spec.n_kv_heads * spec.head_dim * (pos + 40) / 1e6
             tag = f" split_t {split_t:3d}" if split_t else ""
             print(f"kv{kvbits:2d} ctx {ctx:5d} pos ~{pos:5d}{tag}: {dt/32*1e6:8.1f} us/token (L={L}); attention stage {us:7.2f} us for {kv_mb:6.1f} MB/layer = {kv_mb/us*1e3:6.0f} GB/s; "
                   f"full depth ~{32/dt*L/32:7.1f} tok/s", flush=True)
