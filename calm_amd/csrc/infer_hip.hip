@@ -86,12 +86,11 @@ int g_out_one = 0;     // k_attn_out one row per task: 0 = by the same rule (row
 int g_down_one = 0;    // k_ffn_down one row per task: 0 = when row pairs would leave a full grid's last round markedly emptier (rows_balance_one), 1 = always, 2 = never
 int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the matrix cores over the transposed value cache where the head size is 128 (k_attn_vt); 0: k_attn_gqa
-int g_attn_fuse = 1;   // ... and merges the splits itself: the last workgroup of a head group to arrive folds the partials (no k_attn_merge launch); 0: two launches
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_moe_route = 1;   // mixture-of-experts models: the router's logits from partial sums k_attn_out's epilogue leaves (k_ffn_up MOE == 2); 0: every
                        // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
-int g_down_seg = 1;    // mixture-of-experts models: k_ffn_down streams the active experts' rows as one segmented task stream, their hidden vectors
-                       // side by side in LDS (as many per pass as fit); 0: one pass (prologue, drained pipeline) per expert
+int g_down_chain = 1;  // mixture-of-experts models: k_ffn_down walks the active experts as ONE tile stream, the hidden vector in LDS swapped
+                       // in-stream (kernels.hip.h run_rows_impl PH); 0: one pass (prologue, drained pipeline) per expert
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -208,7 +207,6 @@ struct Ctx {
 	int *moe_e = nullptr, *next_tok = nullptr, *trace = nullptr, *trace_count = nullptr;
 	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
 	TokState* ts = nullptr;
-	unsigned* attn_count = nullptr; // k_attn_vt's arrival counters (one per kv head and query-head group; zero between launches)
 	void *kc = nullptr, *vc = nullptr;
 	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, its own allocation (prepare_ctx)
 	size_t kv_layer_bytes = 0;
@@ -400,7 +398,6 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = n_split;
 	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
-	a.count = nullptr;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
 		if (g_attn_waves == 4) {
@@ -413,20 +410,14 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 		return;
 	}
 	// long context: K/V rows loaded once per kv head for several query heads, kv range split, then merged
-	a.count = c->attn_count;
 	if (attn_uses_vt(c)) { // the matrix-core form over the transposed value cache: a wave per tile of keys, all qh query heads at once
 		const int qh = attn_vt_heads(c->kv_mul);
 		const dim3 grid(c->n_kv_heads * (c->kv_mul / qh) * n_split), block(256);
 		const void* vt = (const char*)c->vt + (size_t)l * c->kv_layer_bytes;
 		by_bool(qh > 4, [&](auto WIDE) {
-			by_bool(g_attn_fuse != 0, [&](auto FUSE) {
-				hipLaunchKernelGGL((k_attn_vt<KVB, decltype(WIDE)::value ? 8 : 4, decltype(FUSE)::value>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len,
-				                   a.n_split, qh, a);
-			});
+			hipLaunchKernelGGL((k_attn_vt<KVB, decltype(WIDE)::value ? 8 : 4>), grid, block, 0, g_stream, a.ts, a.q, a.kc, vt, a.head_dim, a.kv_mul, a.seq_len, a.n_split, qh, a);
 		});
-		if (!g_attn_fuse) {
-			launch_attn_merge(c, n_split, ATTN_VT_PSTRIDE);
-		}
+		launch_attn_merge(c, n_split, ATTN_VT_PSTRIDE);
 		return;
 	}
 	const int qh = c->kv_mul % 4 == 0 ? 4 : (c->kv_mul % 2 == 0 ? 2 : 1);
@@ -583,23 +574,6 @@ int ffn_down_cols(int hidden) {
 	return (per + unit - 1) / unit * unit;
 }
 
-// experts k_ffn_down's segmented form takes per pass (0: the one-pass-per-expert form): as many hidden-vector images as fit the
-// CU's LDS, at most FFN_DOWN_SEGS, balanced over the passes (DBRX's four 43-KB images go as 2 + 2, not 3 + 1)
-template <int DB>
-int ffn_down_segs(const Ctx* c, int kn) {
-	if (!g_down_seg || c->n_active < 2) {
-		return 0;
-	}
-	const size_t seg = (size_t)xs_slots<DB>(kn) * 16;
-	int fit = (int)((160 * 1024 - LDS_EXTRA) / seg);
-	fit = fit > FFN_DOWN_SEGS ? FFN_DOWN_SEGS : fit;
-	if (fit < 2) {
-		return 0;
-	}
-	const int passes = (c->n_active + fit - 1) / fit;
-	return (c->n_active + passes - 1) / passes;
-}
-
 template <int DB>
 void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
@@ -615,14 +589,14 @@ void launch_ffn_down(Ctx* c, int l) {
 		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : (few_rows ? 1 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0));
 		int ntasks = c->dim / (uo == 1 ? 1 : (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
-		const int segs = ffn_down_segs<DB>(c, kn);
-		size_t lds = segs ? (size_t)segs * xs_slots<DB>(kn) * 16 + LDS_EXTRA : lds_bytes<DB>(kn);
+		const bool chain = g_down_chain && c->n_active > 1;
+		size_t lds = lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
 			hipLaunchKernelGGL(kern, grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
-			                   c->hidden, c->n_active, k0, kn, segs);
+			                   c->hidden, c->n_active, k0, kn);
 		};
 		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
-			by_bool(segs > 0, [&](auto SEG) {
+			by_bool(chain, [&](auto SEG) {
 				constexpr int V = decltype(V4)::value ? 4 : 8;
 				constexpr bool S = decltype(SEG)::value;
 				if (uo == 7) {
@@ -786,9 +760,7 @@ void account_step(Ctx* c, const StepPlan& sp, int kv_len) {
 	} else {
 		const bool vt = attn_uses_vt(c);
 		add(vt ? "k_attn_vt" : "k_attn_gqa", L, stage_bytes(c, CALM_STAGE_ATTN, kv_len));
-		if (!vt || !g_attn_fuse) {
-			add("k_attn_merge", L, (uint64_t)c->n_heads * sp.n_split * (vt ? ATTN_VT_PSTRIDE : c->head_dim + 2) * sizeof(float));
-		}
+		add("k_attn_merge", L, (uint64_t)c->n_heads * sp.n_split * (vt ? ATTN_VT_PSTRIDE : c->head_dim + 2) * sizeof(float));
 	}
 	add("k_attn_out", L, stage_bytes(c, CALM_STAGE_ATTN_OUT, kv_len));
 	add("k_ffn_up", L, stage_bytes(c, CALM_STAGE_FFN_UP, kv_len));
@@ -997,7 +969,6 @@ void launch_pf_attn_lpr(Ctx* c, int l, int nb, int pos0) {
 	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
 	a.out = c->pf_att;
 	a.partial = nullptr;
-	a.count = nullptr;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
 	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
@@ -1014,7 +985,6 @@ void launch_pf_attn_mfma(Ctx* c, int l, int nb, int pos0) {
 	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
 	a.out = c->pf_att;
 	a.partial = nullptr;
-	a.count = nullptr;
 	a.ts = c->ts;
 	a.head_dim = c->head_dim, a.kv_mul = c->kv_mul, a.seq_len = c->seq_len, a.n_split = 1;
 	a.pf_kv0 = pos0, a.pf_stride = c->q_dim, a.pf_nb = nb;
@@ -1234,19 +1204,17 @@ void set_lds_attrs(Ctx* c) {
 	// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
 	// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
 	{
-		// k_ffn_down: the hidden-sized image, or several side by side (ffn_down_segs) -- the attribute is the kernel's ceiling
-		const int kn = ffn_down_cols<DB>(c->hidden);
-		const int segs = ffn_down_segs<DB>(c, kn);
-		const size_t one = lds_bytes<DB>(kn), big = segs ? (size_t)segs * xs_slots<DB>(kn) * 16 + LDS_EXTRA : one;
+		// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
+		// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
+		const size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
 		auto all = [&](auto V, auto S) {
 			constexpr int v = decltype(V)::value;
-			constexpr bool sg = decltype(S)::value;
-			const size_t b = sg ? big : one;
-			allow_lds(k_ffn_down<DB, 512, v, 7, true, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 2, true, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 1, true, sg>, b);
-			allow_lds(k_ffn_down<DB, 512, v, 1, false, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 0, true, sg>, b), allow_lds(k_ffn_down<DB, 512, v, 0, false, sg>, b);
+			constexpr bool ch = decltype(S)::value;
+			allow_lds(k_ffn_down<DB, 512, v, 7, true, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true, ch>, big);
+			allow_lds(k_ffn_down<DB, 512, v, 1, false, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 0, true, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false, ch>, big);
 		};
 		all(std::integral_constant<int, 4>(), std::false_type()), all(std::integral_constant<int, 8>(), std::false_type());
-		if (c->n_active >= 2) {
+		if (c->n_active > 1) {
 			all(std::integral_constant<int, 4>(), std::true_type()), all(std::integral_constant<int, 8>(), std::true_type());
 		}
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
@@ -1296,8 +1264,7 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_attn_waves;
 	} else if (!strcmp(key, "attn_vt")) {
 		slot = &g_attn_vt;
-	} else if (!strcmp(key, "attn_fuse")) {
-		slot = &g_attn_fuse;
+
 	} else if (!strcmp(key, "down_u")) {
 		slot = &g_down_u;
 	} else if (!strcmp(key, "down_u4")) {
@@ -1310,8 +1277,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_out_one;
 	} else if (!strcmp(key, "moe_route")) {
 		slot = &g_moe_route;
-	} else if (!strcmp(key, "down_seg")) {
-		slot = &g_down_seg;
+	} else if (!strcmp(key, "down_chain")) {
+		slot = &g_down_chain;
 
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
@@ -1418,9 +1385,8 @@ extern "C" void init_hip(void) {
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
-	g_attn_fuse = env_int("CALM_HIP_ATTN_FUSE", g_attn_fuse);
 	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
-	g_down_seg = env_int("CALM_HIP_DOWN_SEG", g_down_seg);
+	g_down_chain = env_int("CALM_HIP_DOWN_CHAIN", g_down_chain);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
@@ -1521,8 +1487,6 @@ void prepare_ctx(struct Transformer* t) {
 	c->att = (float*)dev_alloc(c->q_dim * sizeof(float));
 	c->he = (float*)dev_alloc((size_t)nact * c->hidden * sizeof(float));
 	c->partial = (float*)dev_alloc((size_t)c->n_heads * MAX_SPLIT * (c->head_dim + 4) * sizeof(float));
-	c->attn_count = (unsigned*)dev_alloc((size_t)c->n_heads * sizeof(unsigned));
-	HIP_CHECK(hipMemset(c->attn_count, 0, (size_t)c->n_heads * sizeof(unsigned)));
 	c->logits_d = (float*)dev_alloc((size_t)c->vocab * sizeof(float));
 	// routing of the last step: [layer][rank] weights, then [layer][rank] expert ids, one allocation (shown to the host as state.exp)
 	c->moe_w = (float*)dev_alloc((size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int)));
@@ -1851,7 +1815,7 @@ extern "C" void release_hip(struct Transformer* t) {
 		HIP_CHECK(hipFree(c->gate_part));
 	}
 	void* bufs[] = {c->x,  c->xb,       c->q,     c->att,         c->he,        c->partial, c->sample_st, c->logits_d, c->moe_w,
-	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc, c->attn_count};
+	                c->ts, c->next_tok, c->trace, c->trace_count, c->rope_freq, c->rope_cs, c->rope_cs1, c->kc,     c->vc};
 	for (void* b : bufs) {
 		HIP_CHECK(hipFree(b));
 	}

@@ -569,27 +569,25 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // aux_of(t, aux) may issue small loads the epilogue needs (residual value, RoPE pair); it runs before the
 // task's last multiply-add so that latency hides behind it.  epi(t, acc, aux): sums valid in lane RED_LANE.
 //
-// SEGS (k_ffn_down of a mixture-of-experts model): a task's "row" is the CONCATENATION of `segs` rows of n columns each -- the
-// same output row of several experts' matrices, each against its own expert's hidden vector -- so that one uninterrupted tile
-// stream covers all of them (a restart per expert drained the pipeline and paid a prologue each time).  rows_of(t, seg, rows)
-// names segment seg's rows; segment seg's image starts seg * (chunks of n) * CS slots into xs4; every segment is walked in whole
-// steps (its last step's surplus chunks clamp into the row, as they do at the end of any row); at the end of EVERY segment the
-// sums are reduced and handed to epi(t, seg, acc, aux), which keeps the running value -- the experts are added in rank order by
-// the same lane, exactly as with one pass per expert.  aux_of runs before segment 0's last multiply-add.
-template <int DB, int NR, int U, bool FULL, bool SEGS, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
-__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
+// PH (k_ffn_down of a mixture-of-experts model): the wave walks its tasks `nph` times -- phase p = the p-th active expert: other
+// rows (rows_of(t, p, rows)), another input vector -- as ONE uninterrupted tile stream: the first tiles of phase p + 1 are in flight
+// while phase p's last rows are multiplied out.  The LDS image is switched in-stream: before a wave consumes its first tile of a new
+// phase it calls sw(p), which must barrier, restage the image and barrier again (every wave of the workgroup calls it exactly once
+// per phase; waves without tasks too) -- its loads sit in a branch, but the branch ends with all of them consumed, so the counted
+// waits on the tiles around it stay exact.  (A run_rows per expert drained the pipeline at every expert boundary and paid a whole
+// start-up again: 3.7 / 5.8 us per launch on the Mixtral-8x7B / DBRX shapes; all experts' images side by side in LDS, the other way
+// to keep the stream going, lost to its own longer prologue -- profiles/r04_moe.txt.)  aux_of / epi get the phase too.
+template <int DB, int NR, int U, bool FULL, bool PH, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn, class SwFn>
+__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, int nph, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                              StageFn stage, AuxFn aux_of, EpiFn epi, SwFn sw) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
-	const int cpi = (nl + 63) >> 6;           // chunks of one segment's row (and of its image)
-	const int cps = (cpi + U - 1) / U * U;    // ... walked in whole steps
-	const int ksteps = SEGS ? segs * cps : 0; // chunk positions of a task
 	const unsigned char* rows[2][NR];
 	Tile<NR, U> tile[2];
 	f32x2 acc2[NR];
 	float acc[NR], aux[NR];
 
-	// The stream of tile steps (task t, k-offset k0) is walked with TWO steps always in flight:
+	// The stream of tile steps (phase p, task t, k-offset k0) is walked with TWO steps always in flight:
 	//   prologue : issue step 0 and step 1, then build the LDS image (stage) while they fly;
 	//   step s   : [last step of a task: issue the epilogue's small loads (aux_of)]
 	//              multiply-add tile s  ->  re-issue that register tile with step s+2
@@ -597,19 +595,22 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	// NOTHING issues a load conditionally: past the end of a wave's work the "next step" reads
 	// `dummy` (a small L2-resident buffer with DEV_PAD slack) and the data is dropped, so the
 	// compiler's vmcnt bookkeeping is exact and every wait is "the tile two issues ago".
-	auto advance = [&](int& t, int& k0, bool& live) { // -> the step after (t, k0)
+	auto advance = [&](int& t, int& k0, int& p, bool& live) { // -> the step after (p, t, k0)
 		k0 += U;
-		if (SEGS ? k0 >= ksteps : k0 * 64 >= nl) {
+		if (k0 * 64 >= nl) {
 			k0 = 0;
 			t += stride;
+			if (PH && t >= ntasks && p + 1 < nph) { // the wave's tasks once more, next phase
+				t = first;
+				++p;
+			}
 			live = live && t < ntasks;
 		}
 	};
-	auto seg_start = [&](int k0) { return SEGS ? k0 % cps == 0 : k0 == 0; }; // (t, k0) opens a row (SEGS: a segment)
-	auto issue = [&](int ph, int t, int k0, bool live) {
-		if (seg_start(k0) || !live) {
-			if constexpr (SEGS) {
-				rows_of(min(t, ntasks - 1), live ? k0 / cps : 0, rows[ph]);
+	auto issue = [&](int ph, int t, int k0, int p, bool live) {
+		if (k0 == 0 || !live) {
+			if constexpr (PH) {
+				rows_of(min(t, ntasks - 1), p, rows[ph]);
 			} else {
 				rows_of(min(t, ntasks - 1), rows[ph]);
 			}
@@ -620,7 +621,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 				rows[ph][r] = (const unsigned char*)dummy;
 			}
 		}
-		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? (SEGS ? k0 % cps : k0) : 0, nl, lane);
+		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? k0 : 0, nl, lane);
 	};
 
 #ifdef CALM_TIMELINE
@@ -640,6 +641,11 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		// dummy tile loads below, which would sit in the CU's memory queue ahead of its neighbours' real tiles
 		pre();
 		stage();
+		if constexpr (PH) {
+			for (int p = 1; p < nph; ++p) {
+				sw(p);
+			}
+		}
 #ifdef CALM_TIMELINE
 		tl[1] = wall_clock64();
 		tl_flush();
@@ -647,19 +653,19 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		return;
 	}
 	pre(); // the activation vector's loads go first: they must retire before, not behind, the tiles
-	int t = first, k0 = 0;   // step being consumed
+	int t = first, k0 = 0, p0 = 0; // step being consumed
 	bool live = t < ntasks;
-	int t1 = t, k1 = 0;      // step s+1
+	int t1 = t, k1 = 0, p1 = 0;    // step s+1
 	bool live1 = live;
-	issue(0, t, 0, live);
-	advance(t1, k1, live1);
-	if (!seg_start(k1)) { // same task (and segment), next k-offset: same rows
+	issue(0, t, 0, 0, live);
+	advance(t1, k1, p1, live1);
+	if (k1 != 0) { // same task, next k-offset: same rows
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
 			rows[1][r] = rows[0][r];
 		}
 	}
-	issue(1, t1, k1, live1);
+	issue(1, t1, k1, p1, live1);
 	stage();
 #ifdef CALM_TIMELINE
 	tl[1] = wall_clock64();
@@ -674,40 +680,50 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	for (int r = 0; r < NR; ++r) {
 		acc2[r] = (f32x2){0.f, 0.f};
 	}
+	int pcur = 0; // the phase whose input vector the LDS image holds
 	for (;;) {
 #pragma unroll
 		for (int ph = 0; ph < 2; ++ph) {
-			// (t, k0) lives in tile[ph]; (t1, k1) in tile[ph ^ 1]
-			const int seg = SEGS ? k0 / cps : 0, kl = SEGS ? k0 - seg * cps : k0; // segment, chunk offset inside it
-			const bool last_k = SEGS ? kl + U >= cps : (k0 + U) * 64 >= nl;          // the row's (segment's) last step
-			if (last_k && seg == 0) {
-				aux_of(t, aux);
+			// (p0, t, k0) lives in tile[ph]; (p1, t1, k1) in tile[ph ^ 1]
+			if constexpr (PH) {
+				if (p0 != pcur) { // wave-uniform: this wave's first step of the next phase
+					sw(p0);
+					pcur = p0;
+				}
 			}
-			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, SEGS ? xs4 + seg * cpi * Fmt<DB>::CS : xs4, kl, nl, lane);
+			const bool last_k = (k0 + U) * 64 >= nl;
+			if (last_k) {
+				if constexpr (PH) {
+					aux_of(t, p0, aux);
+				} else {
+					aux_of(t, aux);
+				}
+			}
+			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, xs4, k0, nl, lane);
 #ifdef CALM_TIMELINE
 			if (tl[2] == 0) {
 				asm volatile("" ::"v"(acc2[0][0]));
 				tl[2] = wall_clock64();
 			}
 #endif
-			int t2 = t1, k2 = k1;
+			int t2 = t1, k2 = k1, p2 = p1;
 			bool live2 = live1;
-			advance(t2, k2, live2);
-			if (!seg_start(k2) && live2) { // continues the row of step s+1: same rows
+			advance(t2, k2, p2, live2);
+			if (k2 != 0 && live2) { // continues the task of step s+1: same rows
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					rows[ph][r] = rows[ph ^ 1][r];
 				}
 			}
-			issue(ph, t2, k2, live2);
+			issue(ph, t2, k2, p2, live2);
 			if (last_k) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
 					acc2[r] = (f32x2){0.f, 0.f};
 				}
-				if constexpr (SEGS) {
-					epi(t, seg, acc, aux);
+				if constexpr (PH) {
+					epi(t, p0, acc, aux);
 				} else {
 					epi(t, acc, aux);
 				}
@@ -718,8 +734,8 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 #endif
 				return;
 			}
-			t = t1, k0 = k1;
-			t1 = t2, k1 = k2, live1 = live2;
+			t = t1, k0 = k1, p0 = p1;
+			t1 = t2, k1 = k2, p1 = p2, live1 = live2;
 		}
 	}
 }
@@ -730,13 +746,13 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                          StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL, false>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+	run_rows_impl<DB, NR, U, FULL, false>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi, [](int) {});
 }
-// ... over rows of `segs` segments of n columns each (run_rows_impl: SEGS)
-template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
-__device__ __forceinline__ void run_rows_segs(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL, true>(ntasks, first, stride, n, segs, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+// ... `nph` times over, phase by phase (run_rows_impl: PH)
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn, class SwFn>
+__device__ __forceinline__ void run_rows_phases(int ntasks, int first, int stride, int n, int nph, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                                StageFn stage, AuxFn aux_of, EpiFn epi, SwFn sw) {
+	run_rows_impl<DB, NR, U, FULL, true>(ntasks, first, stride, n, nph, xs4, dummy, rows_of, pre, stage, aux_of, epi, sw);
 }
 
 // Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
@@ -1029,7 +1045,6 @@ struct AttnArgs {
 	const void *kc, *vc; // this layer's caches
 	float* out;          // (q_dim) normalised attention output, written when n_split == 1
 	float* partial;      // (n_heads, n_split, pstride) when n_split > 1: o[head_dim], m, l (k_attn_gqa: pstride = head_dim + 2; k_attn_vt: head_dim + 4)
-	unsigned* count;     // k_attn_vt FUSE: arrival counters, one per (kv head, query-head group); zero between launches
 	const TokState* ts;
 	int head_dim, kv_mul, seq_len, n_split;
 	// batched prompt ingestion (prefill.hip.h: k_pf_attn): token b of the chunk reads q + b * pf_stride, attends to
@@ -1510,19 +1525,15 @@ __device__ __forceinline__ void att_split2(float a, float b, unsigned& hi, unsig
 // kv_mul of them when kv_mul <= 8: DBRX's 6, Yi-34B's 7 -- each K / V tile is then read once per kv head; columns beyond qh are zero).
 // The fp32 query is split into hi + lo binary16 AFTER a per-head power-of-two scaling that brings its largest component to 2^14
 // (exact; undone, together with 1 / sqrt(head size), on the scores): any finite query fits, and small components keep their lo part.
-// FUSE (knob "attn_fuse"): no merge launch.  A workgroup's partial rows are written THROUGH (sc1 stores), drained, and counted in
-// on the (kv head, head group)'s arrival counter; the LAST of the n_split workgroups to arrive reads all partials of its heads past
-// its caches (sc1 loads), folds them in split order -- the result does not depend on who came last -- and writes the attention
-// output.  (The hand-off form of prefill.hip.h's K-range GEMMs; MI355X_MICROARCH.md "handoff-flag".)
+// (Round 4 also built the merge INTO this kernel -- partial rows written through with sc1 stores, drained, an arrival counter per
+// head group, the last of its n_split workgroups folding all partials read past the caches: the guide's hand-off recipe -- and
+// measured it against the two launches: 14.0 against 9.1 us per layer at 4096 positions, 26.9 against 20.4 at 32k
+// (profiles/r04_long_context.txt).  Write-through + drain, the counted arrival and the dependent read of 66 KB of partials are
+// three memory round trips in a row on one workgroup; the merge launch and its boundary are cheaper.  Removed.)
 constexpr int ATTN_MAX_SPLIT = 64;
 constexpr int ATTN_VT_PSTRIDE = 128 + 4; // partial row: o[128], m, l, 2 pad -- rows stay 16-byte aligned
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p) {
-	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
-}
-constexpr int BUF_SC1 = 16; // cache-policy operand of the raw buffer builtins: agent scope (written through / served past the L1)
-
-template <int KVB, int QHM, bool FUSE>
+template <int KVB, int QHM>
 __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float* qin, const void* kc, const void* vt, int head_dim, int kv_mul, int seq_len, int n_split, int qh, AttnArgs a) {
 	constexpr int HD = 128, NW = 4;
 	constexpr int EB = KVB / 8;
@@ -1534,7 +1545,6 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 	__shared__ u32x4 vst[NW][512];
 	__shared__ float sm_m[QHM][NW], sm_l[QHM][NW];
 	__shared__ __attribute__((aligned(16))) float sm_o[QHM][NW][HD + 4]; // (+ 4: the heads' rows start 16 banks apart)
-	__shared__ unsigned arrived;
 
 	const int lane = lane_id(), wave = wave_id();
 	const int qgroups = kv_mul / qh;
@@ -1737,8 +1747,6 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 	__syncthreads();
 	// one thread per (query head, four output dims) folds the NW wave partials (see k_attn); a split without positions files
 	// (-inf, 0, 0).  Rows of PS floats: o[HD], m, l.
-	const __amdgpu_buffer_rsrc_t prs = buf_rsrc(a.partial);
-	auto prow = [&](int q, int s_) { return (int)((((h0 + q) * n_split + s_) * PS) * sizeof(float)); }; // byte offset of a partial row
 	for (int idx = threadIdx.x; idx < qh * (HD / 4); idx += 256) {
 		const int q = idx / (HD / 4), d = (idx % (HD / 4)) * 4;
 		float M = sm_m[q][0];
@@ -1754,73 +1762,10 @@ __global__ __launch_bounds__(256) void k_attn_vt(const TokState* ts, const float
 			L = fmaf(sm_l[q][w], e, L);
 			O += *(const f32x4*)&sm_o[q][w][d] * e;
 		}
-		typedef int i32x4 __attribute__((ext_vector_type(4)));
-		typedef int i32x2 __attribute__((ext_vector_type(2)));
-		__builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, O), prs, prow(q, split) + d * 4, 0, FUSE ? BUF_SC1 : 0);
+		float* p = a.partial + ((size_t)(h0 + q) * n_split + split) * PS;
+		*(f32x4*)(p + d) = O;
 		if (d == 0) {
-			const f32x2 ml = {M, L};
-			__builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, ml), prs, prow(q, split) + HD * 4, 0, FUSE ? BUF_SC1 : 0);
-		}
-	}
-	if constexpr (FUSE) {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the partial rows have left this CU (written through) before the arrival is counted
-		__syncthreads();
-		unsigned* cnt = a.count + kvh * qgroups + qg;
-		if (threadIdx.x == 0) {
-			arrived = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		}
-		__syncthreads();
-		if (arrived != (unsigned)n_split - 1) {
-			return;
-		}
-		if (threadIdx.x == 0) {
-			__hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
-		}
-		// the last workgroup of this head group: every split's partial rows, read past the caches.  Thread (q, four dims) asks for its
-		// piece of up to 32 splits at once, then the (m, l) pairs go through LDS (the K image is free) -- one round trip per 32 splits.
-		float2* sm_ml = (float2*)&kst[0][0]; // [QHM][ATTN_MAX_SPLIT]
-		const int idx = threadIdx.x, q = idx / (HD / 4), d = (idx % (HD / 4)) * 4;
-		const bool mine = idx < qh * (HD / 4); // (QHM = 8: 256 threads; QHM = 4: the first 128)
-		constexpr int NS = 32;
-		f32x4 v[NS];
-		auto load_v = [&](int s0) {
-#pragma unroll
-			for (int i = 0; i < NS; ++i) {
-				const int sc = min(s0 + i, n_split - 1); // (past the last split: re-read it, weight 0)
-				v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, prow(mine ? q : 0, sc) + d * 4, 0, BUF_SC1));
-			}
-		};
-		if (mine) {
-			load_v(0);
-		}
-		for (int i = threadIdx.x; i < qh * n_split; i += 256) {
-			const int qq = i / n_split, ss = i % n_split;
-			const f32x2 ml = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(prs, prow(qq, ss) + HD * 4, 0, BUF_SC1));
-			sm_ml[qq * ATTN_MAX_SPLIT + ss] = make_float2(ml[0], ml[1]);
-		}
-		__syncthreads();
-		float M = -INFINITY;
-		for (int s_ = 0; s_ < n_split; ++s_) {
-			M = fmaxf(M, sm_ml[(mine ? q : 0) * ATTN_MAX_SPLIT + s_].x);
-		}
-		float L = 0.f;
-		f32x4 O = {0.f, 0.f, 0.f, 0.f};
-		for (int s0 = 0; s0 < n_split; s0 += NS) {
-			if (s0 > 0 && mine) {
-				load_v(s0);
-			}
-#pragma unroll
-			for (int i = 0; i < NS; ++i) {
-				if (s0 + i < n_split) {
-					const float2 ml = sm_ml[(mine ? q : 0) * ATTN_MAX_SPLIT + s0 + i];
-					const float w = ml.x == -INFINITY ? 0.f : __expf(ml.x - M); // (a split without positions)
-					L = fmaf(ml.y, w, L);
-					O += v[i] * w;
-				}
-			}
-		}
-		if (mine) {
-			*(f32x4*)(a.out + (size_t)(h0 + q) * HD + d) = O / L;
+			*(f32x2*)(p + HD) = (f32x2){M, L};
 		}
 	}
 }
@@ -1991,59 +1936,44 @@ struct FfnUpArgs {
 	const float* gate_c; // MOE == 2: c[e] behind the layer's gate_mt table (k_gate_prep), what a LayerNorm's mean takes off logit e
 };
 
-// The router (src/infer.c:277-305), by ONE wave, one expert per lane (n_experts <= 64): n_active rounds of a wave-wide arg-max over
-// the logits not yet taken -- larger logit wins, equal logits go to the lower expert index -- then the softmax over the winners
-// only, their exponentials summed in rank order; rank k's expert and weight end up in sel_e[k] / sel_w[k] (and, if out_w, there).
+// The router (src/infer.c:277-305) by one wave, one expert per lane (n_experts <= 64): the experts in the order (larger logit
+// first, equal logits: lower index first), the first n_active of them taken, then the softmax over the winners only, their
+// exponentials summed in rank order; rank k's expert and weight end up in sel_e[k] / sel_w[k] (and, if out_w, there).
+// A lane's rank is the number of experts ahead of it, counted against every other lane's logit through v_readlane (a scalar
+// broadcast: no LDS crossbar round trip -- the first form ran n_active rounds of a wave-wide arg-max over ds_bpermute shuffles,
+// ~50 dependent LDS round trips for Mixtral's 2 of 8, ~90 for DBRX's 4 of 16: 2-5 us at the head of every k_ffn_up launch).
+// Every wave of a workgroup may call it with the same logits (identical stores to sel_e / sel_w; a wave then reads what it wrote).
 __device__ __forceinline__ void moe_route(float logit, int n_experts, int n_active, int* sel_e, float* sel_w, float* out_w, int* out_e) {
 	const int lane = lane_id();
 	const bool valid = lane < n_experts;
 	logit = valid ? logit : 0.f;
-	float top = logit; // the largest logit overall: the softmax's reference point
-	{
-		bool ok = valid;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			const float v2 = __shfl_xor(top, o);
-			const bool ok2 = __shfl_xor((int)ok, o) != 0;
-			if (ok2 && (!ok || v2 > top)) {
-				top = v2;
-				ok = true;
-			}
-		}
+	int rank = 0;
+	for (int j = 0; j < n_experts; ++j) {
+		const float lj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, logit), j));
+		rank += (lj > logit || (lj == logit && j < lane)) ? 1 : 0;
 	}
-	bool open = valid; // this lane's expert can still be picked
-	float rank_logit = 0.f;
-	int rank_expert = 0;
+	float top = 0.f, ex = 0.f;
+	int pick = 0;
 	for (int k = 0; k < n_active; ++k) {
-		float bv = logit;
-		int bi = lane;
-		bool ok = open;
-#pragma unroll
-		for (int o = 32; o > 0; o >>= 1) {
-			const float v2 = __shfl_xor(bv, o);
-			const int i2 = __shfl_xor(bi, o);
-			const bool ok2 = __shfl_xor((int)ok, o) != 0;
-			if (ok2 && (!ok || v2 > bv || (v2 == bv && i2 < bi))) {
-				bv = v2, bi = i2, ok = true;
-			}
-		}
-		open = open && lane != bi;
+		const unsigned long long mask = __ballot(valid && rank == k);
+		const int idx = mask ? (int)__builtin_ctzll(mask) : min(k, n_experts - 1); // (no lane of that rank: logits that do not order -- NaN)
+		const float lk = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, logit), idx));
+		top = k == 0 ? lk : top; // the largest logit overall: the softmax's reference point
 		if (lane == k) {
-			rank_logit = bv;
-			rank_expert = bi;
+			pick = idx;
+			ex = expf(lk - top);
 		}
 	}
-	const float ex = lane < n_active ? expf(rank_logit - top) : 0.f;
 	float denom = 0.f;
 	for (int k = 0; k < n_active; ++k) {
-		denom += __shfl(ex, k);
+		denom += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ex), k));
 	}
 	if (lane < n_active) {
-		sel_e[lane] = rank_expert;
+		sel_e[lane] = pick;
 		sel_w[lane] = ex / denom;
 		if (out_w) {
 			out_w[lane] = ex / denom;
-			out_e[lane] = rank_expert;
+			out_e[lane] = pick;
 		}
 	}
 }
@@ -2152,15 +2082,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 			}
 		}
 		__syncthreads();
-		if (wave == 0) {
+		{
+			// every wave routes for itself (the same logits, the same picks, identical stores): no second barrier before the first tile
 			const float n = (float)dim;
 			const float mean = a.ln ? gate[ne + 1] / n : 0.f;                       // src/infer.c:183-207
 			const float scale = 1.0f / sqrtf(gate[ne] / n - mean * mean + a.eps);
 			const int le = lane < ne ? lane : 0;
 			const float c = a.ln ? a.gate_c[le] : 0.f;
-			moe_route((gate[le] - mean * c) * scale, ne, n_active, sel_e, sel_w, blockIdx.x == 0 ? a.moe_w : nullptr, a.moe_e);
+			moe_route((gate[le] - mean * c) * scale, ne, n_active, sel_e, sel_w, (blockIdx.x == 0 && wave == 0) ? a.moe_w : nullptr, a.moe_e);
 		}
-		__syncthreads();
 		auto nothing = [&]() {};
 		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
 		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, nothing, stage, no_aux, epi);
@@ -2245,90 +2175,62 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 // (Tried for mixture-of-experts models: asking for expert k + 1's hidden vector while expert k's rows stream, so that a later expert
 // starts with a barrier and LDS stores only -- Mixtral-8x7B 25.0 us per launch against 23.1 without: the eight extra loads per
 // wave sit in the queue ahead of the next tiles.  Not kept.)
-// SEG (mixture-of-experts models, knob "down_seg"): the rows of up to FFN_DOWN_SEGS experts at a time are ONE task (run_rows_impl
-// SEGS): all their hidden vectors sit in LDS side by side (Mixtral-8x7B fp8: 2 x 57 KB) and the tile stream never drains between
-// experts -- `seg_cap` = experts per pass (what fits the LDS, balanced over the passes: DBRX's 4 x 43 KB go as 2 + 2).  The
-// epilogue adds expert after expert in rank order through one lane, so the result is bit-identical to the one-pass-per-expert form.
-constexpr int FFN_DOWN_SEGS = 4;
-template <int DB, int BLOCK, int V, int UO, bool FULL, bool SEG>
+// CHAIN (mixture-of-experts models, knob "down_chain"): the active experts' passes are ONE tile stream (run_rows_impl PH) -- expert
+// k + 1's first rows are in flight while expert k's last ones are multiplied out, and the hidden vector in LDS is swapped in-stream
+// (barrier, restage, barrier, with two tiles per wave in flight across it).  Same arithmetic, same order: bit-identical to the
+// one-run_rows-per-expert form below.
+template <int DB, int BLOCK, int V, int UO, bool FULL, bool CHAIN>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
-                                                    int n_active, int k0, int kn, int seg_cap) {
+                                                    int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// UO: tiles of 2 rows x UO chunks instead of the format's shape; UO = 1: ONE row x 4 chunks, for matrices of fewer row pairs than
 	// the chip has waves (TinyLlama's 2048 rows: 7.9 -> 6.6 us)
 	constexpr int NR = UO == 1 ? 1 : (UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR), U = UO == 1 ? 4 : (UO ? UO : KShape<DB, KS_FFN_DOWN>::U);
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
+	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	const size_t row_bytes = (size_t)hidden * DB / 8;
 	const int lane = lane_id();
 	const int nact = n_active > 0 ? n_active : 1;
-	if constexpr (SEG) {
-		const int seg_slots = xs_slots<DB>(kn); // float4 slots of one segment's image
-		float* red = (float*)(xs4 + seg_cap * seg_slots);
-		for (int kb = 0; kb < nact; kb += seg_cap) {
-			const int ns = min(seg_cap, nact - kb); // experts of this pass: ranks kb .. kb + ns - 1
-			float wk[FFN_DOWN_SEGS];
-			const unsigned char* wb[FFN_DOWN_SEGS];
+	if constexpr (CHAIN) {
+		const unsigned char* const wcol = (const unsigned char*)w2 + (size_t)k0 * DB / 8;
+		const size_t expert_bytes = (size_t)dim * row_bytes;
+		auto rows_of = [&](int t, int p, const unsigned char*(&rows)[NR]) {
+			const unsigned char* base = wcol + (size_t)moe_e[p] * expert_bytes;
 #pragma unroll
-			for (int s_ = 0; s_ < FFN_DOWN_SEGS; ++s_) {
-				const int k = min(kb + s_, nact - 1);
-				wk[s_] = moe_w[k];
-				wb[s_] = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;
+			for (int r = 0; r < NR; ++r) {
+				rows[r] = base + (size_t)(t * NR + r) * row_bytes;
 			}
-			auto rows_of = [&](int t, int seg, const unsigned char*(&rows)[NR]) {
-				const unsigned char* base = seg == 0 ? wb[0] : (seg == 1 ? wb[1] : (seg == 2 ? wb[2] : wb[3]));
+		};
+		StageRegs<V, false> sr;
+		auto pre = [&]() { stage_load<BLOCK>(sr, he + k0, nullptr); stage_first_barrier(); };
+		auto stage = [&]() { stage_finish<DB, BLOCK>(sr, xs4, red, he + k0, nullptr, kn, 0.f, false, nullptr); };
+		auto sw = [&](int p) { // expert p's hidden vector replaces expert p - 1's
+			__syncthreads();   // everyone is done reading the previous image
+			const float* hk = he + (size_t)p * hidden + k0;
+			StageRegs<V, false> s2;
+			stage_load<BLOCK>(s2, hk, nullptr);
+			stage_finish<DB, BLOCK>(s2, xs4, red, hk, nullptr, kn, 0.f, false, nullptr);
+		};
+		float wk = 0.f;
+		auto aux_of = [&](int t, int p, float(&aux)[NR]) { // residual so far (the same lane wrote it in the phase before) and this expert's weight
+			wk = moe_w[p];
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				aux[r] = x[t * NR + r];
+			}
+		};
+		auto epi = [&](int t, int, float(&acc)[NR], float(&aux)[NR]) {
+			if (lane == RED_LANE) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
-					rows[r] = base + (size_t)(t * NR + r) * row_bytes;
+					x[t * NR + r] = aux[r] + acc[r] * wk;
 				}
-			};
-			// the first two hidden vectors' loads go out ahead of the first tiles; further ones are staged behind them
-			StageRegs<V, false> sr0, sr1;
-			const float* hk = he + (size_t)kb * hidden + k0;
-			auto pre = [&]() {
-				stage_load<BLOCK>(sr0, hk, nullptr);
-				stage_load<BLOCK>(sr1, hk + (ns > 1 ? hidden : 0), nullptr);
-				stage_first_barrier();
-			};
-			auto stage = [&]() {
-				if (kb > 0) {
-					__syncthreads(); // everyone is done reading the previous pass's images
-				}
-				stage_finish<DB, BLOCK>(sr0, xs4, red, hk, nullptr, kn, 0.f, false, nullptr);
-				if (ns > 1) {
-					stage_finish<DB, BLOCK>(sr1, xs4 + seg_slots, red, hk + hidden, nullptr, kn, 0.f, false, nullptr);
-				}
-				for (int s_ = 2; s_ < ns; ++s_) {
-					StageRegs<V, false> sr;
-					stage_load<BLOCK>(sr, hk + (size_t)s_ * hidden, nullptr);
-					stage_finish<DB, BLOCK>(sr, xs4 + s_ * seg_slots, red, hk + (size_t)s_ * hidden, nullptr, kn, 0.f, false, nullptr);
-				}
-			};
-			auto aux_of = [&](int t, float(&aux)[NR]) { // residual so far
-#pragma unroll
-				for (int r = 0; r < NR; ++r) {
-					aux[r] = x[t * NR + r];
-				}
-			};
-			float carry[NR]; // the task's running value between its segments (lane RED_LANE)
-			auto epi = [&](int t, int seg, float(&acc)[NR], float(&aux)[NR]) {
-				const float w = seg == 0 ? wk[0] : (seg == 1 ? wk[1] : (seg == 2 ? wk[2] : wk[3]));
-#pragma unroll
-				for (int r = 0; r < NR; ++r) {
-					carry[r] = (seg == 0 ? aux[r] : carry[r]) + acc[r] * w;
-				}
-				if (seg == ns - 1 && lane == RED_LANE) {
-#pragma unroll
-					for (int r = 0; r < NR; ++r) {
-						x[t * NR + r] = carry[r];
-					}
-				}
-			};
-			run_rows_segs<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, kn, ns, xs4, he, rows_of, pre, stage, aux_of, epi);
-		}
+			}
+		};
+		run_rows_phases<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, kn, nact, xs4, he, rows_of, pre, stage, aux_of, epi, sw);
 		return;
 	}
-	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	for (int k = 0; k < nact; ++k) {
 		const float wk = moe_w[k];
 		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;

@@ -110,8 +110,6 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	c.q = (float*)upload_hip((void*)q, q_dim * sizeof(float));
 	c.att = (float*)dev_alloc(q_dim * sizeof(float));
 	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 4) * sizeof(float));
-	c.attn_count = (unsigned*)dev_alloc((size_t)n_heads * sizeof(unsigned));
-	HIP_CHECK(hipMemset(c.attn_count, 0, (size_t)n_heads * sizeof(unsigned)));
 	TokState ts = {};
 	ts.kv_len = kv_len;
 	c.ts = (TokState*)upload_hip(&ts, sizeof(ts));
@@ -123,7 +121,7 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	launch_attn<16>(&c, 0, n_split);
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, c.att, q_dim * sizeof(float));
-	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts), free_hip(c.attn_count);
+	free_hip(c.kc), free_hip(c.vc), free_hip(c.q), free_hip(c.att), free_hip(c.partial), free_hip(c.ts);
 	if (c.vt) {
 		free_hip(c.vt);
 	}
@@ -292,8 +290,9 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 	}
 	HIP_CHECK(hipDeviceSynchronize());
 	HIP_CHECK(hipMemcpy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
-	if (which && attn_has_vt(g.head_dim) && g.seq_len % 64 == 0) {
-		// the transposed value cache sits behind the [position][dim] one in the same allocation (prepare_hip): [layer][kv_head][head_dim][seq_len]
+	Ctx* const c = ctx_of(t);
+	if (which && c->vt) {
+		// the transposed value cache (its own allocation, prepare_ctx): [layer][kv_head][block of positions][head_dim][position in block]
 		for (int hd = 0; hd < g.kv_dim; ++hd) {
 			for (int p = 0; p < g.seq_len; ++p) {
 				const uint16_t v = host[(size_t)p * g.kv_dim + hd];
@@ -305,7 +304,7 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 				}
 			}
 		}
-		HIP_CHECK(hipMemcpy((char*)t->state.value_cache + (size_t)(t->config.n_layers + layer) * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy((char*)c->vt + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
 	}
 }
 

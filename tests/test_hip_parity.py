@@ -120,14 +120,12 @@ def test_attention_matches_oracle(hiplib, n_heads, n_kv, head_dim, kv_len, n_spl
     assert rel_err(out, ref) < KERNEL_TOL
 
 
-@pytest.mark.parametrize("fuse", [1, 0])
 @pytest.mark.parametrize("n_heads,n_kv", [(32, 8), (8, 8), (6, 1), (2, 1), (48, 8), (7, 1), (16, 2), (24, 2), (5, 1)])
 @pytest.mark.parametrize("kv_len,n_split", [(385, 4), (1000, 8), (2049, 32), (4096, 32), (130, 3), (64, 2), (4100, 64)])
-def test_split_attention_over_the_transposed_value_cache(hiplib, n_heads, n_kv, kv_len, n_split, fuse):
+def test_split_attention_over_the_transposed_value_cache(hiplib, n_heads, n_kv, kv_len, n_split):
     """head size 128 and a window of whole 64-position blocks: the split kernel is k_attn_vt (matrix cores, V read from the transposed
     copy of the cache; all query heads of a kv head up to 8 per workgroup: DBRX's 6, Yi's 7, 12 as 2 x 6, a prime 5) -- same answer as
-    the reference's three loops; splits are rounded up to 64-position blocks, so some of the trailing ones are empty.  fuse: the last
-    workgroup of a head group to arrive merges the splits itself (no k_attn_merge launch); 0: the two-launch form"""
+    the reference's three loops; splits are rounded up to 64-position blocks, so some of the trailing ones are empty"""
     rng = np.random.default_rng(n_heads * 1000 + kv_len)
     head_dim = 128
     seq_len = (kv_len + 63) // 64 * 64 + 64
@@ -136,20 +134,15 @@ def test_split_attention_over_the_transposed_value_cache(hiplib, n_heads, n_kv, 
     k = (rng.standard_normal((seq_len, kv_dim)) * 0.7).astype(np.float16)
     v = rng.standard_normal((seq_len, kv_dim)).astype(np.float16)
     out = np.empty(n_heads * head_dim, dtype=np.float32)
-    old = hiplib.calm_hip_configure(b"attn_fuse", fuse)
-    try:
-        hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
-        ref = oracle.attention(q, k, v, n_heads, n_kv, head_dim, kv_len)
-        assert rel_err(out, ref) < KERNEL_TOL
-        # what the cache holds beyond the live range (slots of an earlier, longer sequence) must not matter -- not even infinities
-        k[kv_len:] = np.float16(np.nan)
-        v[kv_len:] = np.float16(np.inf)
-        for _ in range(3):  # (and the arrival counters are back at zero after every launch)
-            out2 = np.empty_like(out)
-            hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out2), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
-            assert np.array_equal(out, out2)
-    finally:
-        hiplib.calm_hip_configure(b"attn_fuse", old)
+    hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
+    ref = oracle.attention(q, k, v, n_heads, n_kv, head_dim, kv_len)
+    assert rel_err(out, ref) < KERNEL_TOL
+    # what the cache holds beyond the live range (slots of an earlier, longer sequence) must not matter -- not even infinities
+    k[kv_len:] = np.float16(np.nan)
+    v[kv_len:] = np.float16(np.inf)
+    out2 = np.empty_like(out)
+    hiplib.calm_hip_test_attn(fptr(q), k.ctypes.data, v.ctypes.data, fptr(out2), n_heads, n_kv, head_dim, seq_len, kv_len, n_split)
+    assert np.array_equal(out, out2)
 
 
 @pytest.mark.parametrize("scale", [1e5, 3e-6, 1.0])

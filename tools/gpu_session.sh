@@ -10,7 +10,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 for c in "$@"; do
   echo "== $c" >> $OUT/summary.txt
   t0=$(date +%s)
-  ( eval "timeout ${STEP_TIMEOUT:-600} $c" ) >> $OUT/summary.txt 2>&1
+  timeout ${STEP_TIMEOUT:-600} bash -c "$c" >> $OUT/summary.txt 2>&1
   echo "[exit $? after $(( $(date +%s) - t0 )) s]" >> $OUT/summary.txt
 done
 cat $OUT/summary.txt
