@@ -89,8 +89,6 @@ int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the mat
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_moe_route = 1;   // mixture-of-experts models: the router's logits from partial sums k_attn_out's epilogue leaves (k_ffn_up MOE == 2); 0: every
                        // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
-int g_down_chain = 1;  // mixture-of-experts models: k_ffn_down walks the active experts as ONE tile stream, the hidden vector in LDS swapped
-                       // in-stream (kernels.hip.h run_rows_impl PH); 0: one pass (prologue, drained pipeline) per expert
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -208,7 +206,7 @@ struct Ctx {
 	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
 	TokState* ts = nullptr;
 	void *kc = nullptr, *vc = nullptr;
-	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, its own allocation (prepare_ctx)
+	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, behind vc in ONE allocation (prepare_ctx)
 	size_t kv_layer_bytes = 0;
 	int attn_chunk = 1 << 30; // cached positions per attention split of the step being enqueued (launch_attn_lpr)
 	// mixture-of-experts routing ahead of k_ffn_up (kernels.hip.h k_attn_out GATE): per layer a [dim][gate_ep] fp32 table
@@ -589,30 +587,26 @@ void launch_ffn_down(Ctx* c, int l) {
 		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : (few_rows ? 1 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0));
 		int ntasks = c->dim / (uo == 1 ? 1 : (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
-		const bool chain = g_down_chain && c->n_active > 1;
 		size_t lds = lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
 			hipLaunchKernelGGL(kern, grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
 			                   c->hidden, c->n_active, k0, kn);
 		};
 		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
-			by_bool(chain, [&](auto SEG) {
-				constexpr int V = decltype(V4)::value ? 4 : 8;
-				constexpr bool S = decltype(SEG)::value;
-				if (uo == 7) {
-					go(k_ffn_down<DB, BLOCK, V, 7, true, S>);
-				} else if (uo == 1 && rows_full<DB>(kn)) {
-					go(k_ffn_down<DB, BLOCK, V, 1, true, S>);
-				} else if (uo == 1) {
-					go(k_ffn_down<DB, BLOCK, V, 1, false, S>);
-				} else if (uo == 2) {
-					go(k_ffn_down<DB, BLOCK, V, 2, true, S>);
-				} else if (rows_full<DB>(kn)) {
-					go(k_ffn_down<DB, BLOCK, V, 0, true, S>);
-				} else {
-					go(k_ffn_down<DB, BLOCK, V, 0, false, S>);
-				}
-			});
+			constexpr int V = decltype(V4)::value ? 4 : 8;
+			if (uo == 7) {
+				go(k_ffn_down<DB, BLOCK, V, 7, true>);
+			} else if (uo == 1 && rows_full<DB>(kn)) {
+				go(k_ffn_down<DB, BLOCK, V, 1, true>);
+			} else if (uo == 1) {
+				go(k_ffn_down<DB, BLOCK, V, 1, false>);
+			} else if (uo == 2) {
+				go(k_ffn_down<DB, BLOCK, V, 2, true>);
+			} else if (rows_full<DB>(kn)) {
+				go(k_ffn_down<DB, BLOCK, V, 0, true>);
+			} else {
+				go(k_ffn_down<DB, BLOCK, V, 0, false>);
+			}
 		});
 	}
 }
@@ -1207,16 +1201,12 @@ void set_lds_attrs(Ctx* c) {
 		// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
 		// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
 		const size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
-		auto all = [&](auto V, auto S) {
+		auto all = [&](auto V) {
 			constexpr int v = decltype(V)::value;
-			constexpr bool ch = decltype(S)::value;
-			allow_lds(k_ffn_down<DB, 512, v, 7, true, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true, ch>, big);
-			allow_lds(k_ffn_down<DB, 512, v, 1, false, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 0, true, ch>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false, ch>, big);
+			allow_lds(k_ffn_down<DB, 512, v, 7, true>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true>, big);
+			allow_lds(k_ffn_down<DB, 512, v, 1, false>, big), allow_lds(k_ffn_down<DB, 512, v, 0, true>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false>, big);
 		};
-		all(std::integral_constant<int, 4>(), std::false_type()), all(std::integral_constant<int, 8>(), std::false_type());
-		if (c->n_active > 1) {
-			all(std::integral_constant<int, 4>(), std::true_type()), all(std::integral_constant<int, 8>(), std::true_type());
-		}
+		all(std::integral_constant<int, 4>()), all(std::integral_constant<int, 8>());
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
 		if (d > 48 * 1024) {
 			allow_lds(k_qkv<DB, 16, 8, true, false>, d), allow_lds(k_qkv<DB, 16, 8, false, false>, d), allow_lds(k_qkv<DB, 8, 8, true, false>, d), allow_lds(k_qkv<DB, 8, 8, false, false>, d);
@@ -1277,8 +1267,7 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_out_one;
 	} else if (!strcmp(key, "moe_route")) {
 		slot = &g_moe_route;
-	} else if (!strcmp(key, "down_chain")) {
-		slot = &g_down_chain;
+
 
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
@@ -1386,7 +1375,7 @@ extern "C" void init_hip(void) {
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
-	g_down_chain = env_int("CALM_HIP_DOWN_CHAIN", g_down_chain);
+
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
@@ -1513,18 +1502,19 @@ void prepare_ctx(struct Transformer* t) {
 	// (k_attn_gqa; the epilogues skip the transposed stores when Ctx::vt is null).
 	const bool vt = g_attn_vt && attn_has_vt(c->head_dim) && c->seq_len % 64 == 0 && c->seq_len > g_split_min;
 	c->kc = dev_alloc(kv_bytes);
-	c->vc = dev_alloc(kv_bytes);
-	HIP_CHECK(hipMemset(c->kc, 0, kv_bytes));
-	HIP_CHECK(hipMemset(c->vc, 0, kv_bytes));
-	if (vt) {
-		if (hipMalloc(&c->vt, kv_bytes + DEV_PAD) == hipSuccess) {
-			HIP_CHECK(hipMemset(c->vt, 0, kv_bytes));
-		} else {
+	// (V and V^T in one allocation, V^T behind V: the test hooks find it from state.value_cache and the allocation's size)
+	if (vt && hipMalloc(&c->vc, 2 * kv_bytes + DEV_PAD) == hipSuccess) {
+		c->vt = (char*)c->vc + kv_bytes;
+	} else {
+		if (vt) {
 			(void)hipGetLastError();
-			c->vt = nullptr;
 			fprintf(stderr, "calm_hip: no room for the transposed value cache (%.1f GiB): split attention falls back to k_attn_gqa\n", (double)kv_bytes / (1 << 30));
 		}
+		c->vc = dev_alloc(kv_bytes);
+		c->vt = nullptr;
 	}
+	HIP_CHECK(hipMemset(c->kc, 0, kv_bytes));
+	HIP_CHECK(hipMemset(c->vc, 0, kv_bytes * (c->vt ? 2 : 1)));
 
 	// mixture of experts: the router's table per layer (kernels.hip.h k_attn_out GATE / k_gate_prep) and the partial-sum buffer.  Not for
 	// parallel-residual models (their FFN reads the attention norm's output, which k_attn_out does not produce).
@@ -1806,9 +1796,6 @@ extern "C" void release_hip(struct Transformer* t) {
 	}
 	for (hipEvent_t e : c->events) {
 		HIP_CHECK(hipEventDestroy(e));
-	}
-	if (c->vt) {
-		HIP_CHECK(hipFree(c->vt));
 	}
 	if (c->gate_mt) {
 		HIP_CHECK(hipFree(c->gate_mt));

@@ -568,18 +568,9 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // register tiles alternate through a 2x-unrolled loop body so all tile indices are compile-time.
 // aux_of(t, aux) may issue small loads the epilogue needs (residual value, RoPE pair); it runs before the
 // task's last multiply-add so that latency hides behind it.  epi(t, acc, aux): sums valid in lane RED_LANE.
-//
-// PH (k_ffn_down of a mixture-of-experts model): the wave walks its tasks `nph` times -- phase p = the p-th active expert: other
-// rows (rows_of(t, p, rows)), another input vector -- as ONE uninterrupted tile stream: the first tiles of phase p + 1 are in flight
-// while phase p's last rows are multiplied out.  The LDS image is switched in-stream: before a wave consumes its first tile of a new
-// phase it calls sw(p), which must barrier, restage the image and barrier again (every wave of the workgroup calls it exactly once
-// per phase; waves without tasks too) -- its loads sit in a branch, but the branch ends with all of them consumed, so the counted
-// waits on the tiles around it stay exact.  (A run_rows per expert drained the pipeline at every expert boundary and paid a whole
-// start-up again: 3.7 / 5.8 us per launch on the Mixtral-8x7B / DBRX shapes; all experts' images side by side in LDS, the other way
-// to keep the stream going, lost to its own longer prologue -- profiles/r04_moe.txt.)  aux_of / epi get the phase too.
-template <int DB, int NR, int U, bool FULL, bool PH, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn, class SwFn>
-__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, int nph, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                              StageFn stage, AuxFn aux_of, EpiFn epi, SwFn sw) {
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
 	const unsigned char* rows[2][NR];
@@ -587,7 +578,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	f32x2 acc2[NR];
 	float acc[NR], aux[NR];
 
-	// The stream of tile steps (phase p, task t, k-offset k0) is walked with TWO steps always in flight:
+	// The stream of tile steps (task t, k-offset k0) is walked with TWO steps always in flight:
 	//   prologue : issue step 0 and step 1, then build the LDS image (stage) while they fly;
 	//   step s   : [last step of a task: issue the epilogue's small loads (aux_of)]
 	//              multiply-add tile s  ->  re-issue that register tile with step s+2
@@ -595,25 +586,17 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	// NOTHING issues a load conditionally: past the end of a wave's work the "next step" reads
 	// `dummy` (a small L2-resident buffer with DEV_PAD slack) and the data is dropped, so the
 	// compiler's vmcnt bookkeeping is exact and every wait is "the tile two issues ago".
-	auto advance = [&](int& t, int& k0, int& p, bool& live) { // -> the step after (p, t, k0)
+	auto advance = [&](int& t, int& k0, bool& live) { // -> the step after (t, k0)
 		k0 += U;
 		if (k0 * 64 >= nl) {
 			k0 = 0;
 			t += stride;
-			if (PH && t >= ntasks && p + 1 < nph) { // the wave's tasks once more, next phase
-				t = first;
-				++p;
-			}
 			live = live && t < ntasks;
 		}
 	};
-	auto issue = [&](int ph, int t, int k0, int p, bool live) {
+	auto issue = [&](int ph, int t, int k0, bool live) {
 		if (k0 == 0 || !live) {
-			if constexpr (PH) {
-				rows_of(min(t, ntasks - 1), p, rows[ph]);
-			} else {
-				rows_of(min(t, ntasks - 1), rows[ph]);
-			}
+			rows_of(min(t, ntasks - 1), rows[ph]);
 		}
 		if (!live) {
 #pragma unroll
@@ -641,11 +624,6 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		// dummy tile loads below, which would sit in the CU's memory queue ahead of its neighbours' real tiles
 		pre();
 		stage();
-		if constexpr (PH) {
-			for (int p = 1; p < nph; ++p) {
-				sw(p);
-			}
-		}
 #ifdef CALM_TIMELINE
 		tl[1] = wall_clock64();
 		tl_flush();
@@ -653,19 +631,19 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 		return;
 	}
 	pre(); // the activation vector's loads go first: they must retire before, not behind, the tiles
-	int t = first, k0 = 0, p0 = 0; // step being consumed
+	int t = first, k0 = 0;   // step being consumed
 	bool live = t < ntasks;
-	int t1 = t, k1 = 0, p1 = 0;    // step s+1
+	int t1 = t, k1 = 0;      // step s+1
 	bool live1 = live;
-	issue(0, t, 0, 0, live);
-	advance(t1, k1, p1, live1);
+	issue(0, t, 0, live);
+	advance(t1, k1, live1);
 	if (k1 != 0) { // same task, next k-offset: same rows
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
 			rows[1][r] = rows[0][r];
 		}
 	}
-	issue(1, t1, k1, p1, live1);
+	issue(1, t1, k1, live1);
 	stage();
 #ifdef CALM_TIMELINE
 	tl[1] = wall_clock64();
@@ -680,24 +658,13 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	for (int r = 0; r < NR; ++r) {
 		acc2[r] = (f32x2){0.f, 0.f};
 	}
-	int pcur = 0; // the phase whose input vector the LDS image holds
 	for (;;) {
 #pragma unroll
 		for (int ph = 0; ph < 2; ++ph) {
-			// (p0, t, k0) lives in tile[ph]; (p1, t1, k1) in tile[ph ^ 1]
-			if constexpr (PH) {
-				if (p0 != pcur) { // wave-uniform: this wave's first step of the next phase
-					sw(p0);
-					pcur = p0;
-				}
-			}
+			// (t, k0) lives in tile[ph]; (t1, k1) in tile[ph ^ 1]
 			const bool last_k = (k0 + U) * 64 >= nl;
 			if (last_k) {
-				if constexpr (PH) {
-					aux_of(t, p0, aux);
-				} else {
-					aux_of(t, aux);
-				}
+				aux_of(t, aux);
 			}
 			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, xs4, k0, nl, lane);
 #ifdef CALM_TIMELINE
@@ -706,27 +673,23 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 				tl[2] = wall_clock64();
 			}
 #endif
-			int t2 = t1, k2 = k1, p2 = p1;
+			int t2 = t1, k2 = k1;
 			bool live2 = live1;
-			advance(t2, k2, p2, live2);
+			advance(t2, k2, live2);
 			if (k2 != 0 && live2) { // continues the task of step s+1: same rows
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					rows[ph][r] = rows[ph ^ 1][r];
 				}
 			}
-			issue(ph, t2, k2, p2, live2);
+			issue(ph, t2, k2, live2);
 			if (last_k) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
 					acc2[r] = (f32x2){0.f, 0.f};
 				}
-				if constexpr (PH) {
-					epi(t, p0, acc, aux);
-				} else {
-					epi(t, acc, aux);
-				}
+				epi(t, acc, aux);
 			}
 			if (!live1) {
 #ifdef CALM_TIMELINE
@@ -734,8 +697,8 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 #endif
 				return;
 			}
-			t = t1, k0 = k1, p0 = p1;
-			t1 = t2, k1 = k2, p1 = p2, live1 = live2;
+			t = t1, k0 = k1;
+			t1 = t2, k1 = k2, live1 = live2;
 		}
 	}
 }
@@ -746,13 +709,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                          StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL, false>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi, [](int) {});
-}
-// ... `nph` times over, phase by phase (run_rows_impl: PH)
-template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn, class SwFn>
-__device__ __forceinline__ void run_rows_phases(int ntasks, int first, int stride, int n, int nph, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
-                                                StageFn stage, AuxFn aux_of, EpiFn epi, SwFn sw) {
-	run_rows_impl<DB, NR, U, FULL, true>(ntasks, first, stride, n, nph, xs4, dummy, rows_of, pre, stage, aux_of, epi, sw);
+	run_rows_impl<DB, NR, U, FULL>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
 // Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
@@ -2174,12 +2131,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 // the CU's LDS is covered by several launches over whole-KiB column ranges, each adding its partial products onto x.
 // (Tried for mixture-of-experts models: asking for expert k + 1's hidden vector while expert k's rows stream, so that a later expert
 // starts with a barrier and LDS stores only -- Mixtral-8x7B 25.0 us per launch against 23.1 without: the eight extra loads per
-// wave sit in the queue ahead of the next tiles.  Not kept.)
-// CHAIN (mixture-of-experts models, knob "down_chain"): the active experts' passes are ONE tile stream (run_rows_impl PH) -- expert
-// k + 1's first rows are in flight while expert k's last ones are multiplied out, and the hidden vector in LDS is swapped in-stream
-// (barrier, restage, barrier, with two tiles per wave in flight across it).  Same arithmetic, same order: bit-identical to the
-// one-run_rows-per-expert form below.
-template <int DB, int BLOCK, int V, int UO, bool FULL, bool CHAIN>
+// wave sit in the queue ahead of the next tiles.  Not kept.  Round 4, two more forms of "never drain between experts", both
+// bit-identical to this one and both slower (profiles/r04_moe.txt): all active experts' hidden vectors side by side in LDS with a task's
+// row the concatenation of the experts' rows (Mixtral 22.4 against 21.5 us, DBRX 51 against 49: the longer prologue costs more than
+// the restart it saves), and one tile stream across the expert boundary with the image swapped in-stream behind a barrier (22.2 / 58:
+// the swap's loads go out only after the slowest wave has arrived, where a restart's go out as each wave finishes).)
+template <int DB, int BLOCK, int V, int UO, bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2192,45 +2149,6 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 	const size_t row_bytes = (size_t)hidden * DB / 8;
 	const int lane = lane_id();
 	const int nact = n_active > 0 ? n_active : 1;
-	if constexpr (CHAIN) {
-		const unsigned char* const wcol = (const unsigned char*)w2 + (size_t)k0 * DB / 8;
-		const size_t expert_bytes = (size_t)dim * row_bytes;
-		auto rows_of = [&](int t, int p, const unsigned char*(&rows)[NR]) {
-			const unsigned char* base = wcol + (size_t)moe_e[p] * expert_bytes;
-#pragma unroll
-			for (int r = 0; r < NR; ++r) {
-				rows[r] = base + (size_t)(t * NR + r) * row_bytes;
-			}
-		};
-		StageRegs<V, false> sr;
-		auto pre = [&]() { stage_load<BLOCK>(sr, he + k0, nullptr); stage_first_barrier(); };
-		auto stage = [&]() { stage_finish<DB, BLOCK>(sr, xs4, red, he + k0, nullptr, kn, 0.f, false, nullptr); };
-		auto sw = [&](int p) { // expert p's hidden vector replaces expert p - 1's
-			__syncthreads();   // everyone is done reading the previous image
-			const float* hk = he + (size_t)p * hidden + k0;
-			StageRegs<V, false> s2;
-			stage_load<BLOCK>(s2, hk, nullptr);
-			stage_finish<DB, BLOCK>(s2, xs4, red, hk, nullptr, kn, 0.f, false, nullptr);
-		};
-		float wk = 0.f;
-		auto aux_of = [&](int t, int p, float(&aux)[NR]) { // residual so far (the same lane wrote it in the phase before) and this expert's weight
-			wk = moe_w[p];
-#pragma unroll
-			for (int r = 0; r < NR; ++r) {
-				aux[r] = x[t * NR + r];
-			}
-		};
-		auto epi = [&](int t, int, float(&acc)[NR], float(&aux)[NR]) {
-			if (lane == RED_LANE) {
-#pragma unroll
-				for (int r = 0; r < NR; ++r) {
-					x[t * NR + r] = aux[r] + acc[r] * wk;
-				}
-			}
-		};
-		run_rows_phases<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, kn, nact, xs4, he, rows_of, pre, stage, aux_of, epi, sw);
-		return;
-	}
 	for (int k = 0; k < nact; ++k) {
 		const float wk = moe_w[k];
 		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;

@@ -290,9 +290,14 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 	}
 	HIP_CHECK(hipDeviceSynchronize());
 	HIP_CHECK(hipMemcpy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
-	Ctx* const c = ctx_of(t);
-	if (which && c->vt) {
-		// the transposed value cache (its own allocation, prepare_ctx): [layer][kv_head][block of positions][head_dim][position in block]
+	// the transposed value cache, when the backend keeps one (prepare_ctx: head size 128, knob "attn_vt", a window beyond the unsplit
+	// kernel's contexts), sits behind the [position][dim] one in the same allocation -- seen here from the allocation's size (this
+	// library shares no state with the product library the model was prepared by): [layer][kv_head][block of positions][head_dim][position in block]
+	size_t alloc = 0;
+	void* base = nullptr;
+	HIP_CHECK(hipMemGetAddressRange((hipDeviceptr_t*)&base, &alloc, (hipDeviceptr_t)t->state.value_cache));
+	const size_t kv_bytes = g.layer_bytes * t->config.n_layers;
+	if (which && alloc >= 2 * kv_bytes) {
 		for (int hd = 0; hd < g.kv_dim; ++hd) {
 			for (int p = 0; p < g.seq_len; ++p) {
 				const uint16_t v = host[(size_t)p * g.kv_dim + hd];
@@ -304,7 +309,7 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 				}
 			}
 		}
-		HIP_CHECK(hipMemcpy((char*)c->vt + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+		HIP_CHECK(hipMemcpy((char*)t->state.value_cache + kv_bytes + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
 	}
 }
 
