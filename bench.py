@@ -15,6 +15,9 @@ torch.distributed.run, one rank per GPU, so the printed n_gpus is N either way.
 --gpus N --pipeline: BASELINE config 5 instead -- ONE process, the layers of DBRX-132B fp8 (or --model) split over P = N pipeline
 stages inside the library (CALM_HIP_DEVICES), stage s on GPU s, one token in flight ("scaling": "capacity": the GPUs add
 memory, not throughput).
+A plain `--gpus N` run with N > 1 ALSO measures that: once the replicas are timed and have released their GPUs, rank 0 runs
+`bench.py --gpus N --pipeline --no-cpu` as a child process and embeds its line as "pipeline": {...} (--no-pipeline-leg skips it),
+so the one command the driver issues per N yields both the replica rate and config 5's number.
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -71,6 +74,45 @@ def cpu_baseline(model, n_tokens, first_token, budget_s):
     }, toks, keep
 
 
+def pipeline_leg(args, n_gpus):
+    """BASELINE config 5 as a child process: `bench.py --gpus N --pipeline N --no-cpu` (DBRX-132B fp8 over N in-library stages) in a
+    clean single-process environment; -> the sub-record embedded as "pipeline" in the replica line"""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "CALM_HIP_DEVICE", "OMP_NUM_THREADS")
+           and not k.startswith("TORCHELASTIC")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(n_gpus), "--pipeline", str(n_gpus), "--no-cpu", "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    if args.dry_run:
+        cmd.append("--dry-run")
+    if args.layers:
+        cmd += ["--layers", str(args.layers)]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("CALM_BENCH_PIPELINE_TIMEOUT", "900")))
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout", "command": " ".join(cmd[1:])}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": f"exit {r.returncode}", "stderr_tail": r.stderr[-600:], "command": " ".join(cmd[1:])}
+    d = json.loads(lines[-1])
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "achieved_GBps", "hbm_frac_of_spec", "stage_devices", "handoff_us", "handoffs_timed", "dry_run",
+            "steps_note", "load_seconds")
+    rec = {k: d[k] for k in keep if k in d}
+    rec["config"] = d.get("config")
+    rec["command"] = "bench.py " + " ".join(cmd[2:])
+    rec["wall_seconds"] = round(time.perf_counter() - t0, 1)
+    return rec
+
+
+def steps_note(steps):
+    """BASELINE.json's metric is a 256-token decode: a run with another step count averages over a different range of KV lengths"""
+    if steps == 256:
+        return None
+    return (f"{steps} decode steps from position 0, not the 256 of BASELINE.json's metric: attention averages over KV lengths up to {steps} "
+            f"instead of 256 (short runs read faster); quote a 256-step run against the baseline")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +130,7 @@ def main():
                     "BASELINE config 5's partitioning) instead of running on one GPU; without a value P = --gpus")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: the launch / rendezvous / timing protocol only (gloo), for the CPU tests")
     ap.add_argument("--host-synth", action="store_true", help="without a CPU leg: synthesise the weights on the host and upload them (default: on the device)")
+    ap.add_argument("--no-pipeline-leg", action="store_true", help="--gpus N > 1 without --pipeline: do not run BASELINE config 5 (the N-stage layer pipeline) afterwards")
     args = ap.parse_args()
     if args.pipeline == -1:
         args.pipeline = args.gpus
@@ -141,13 +184,21 @@ def main():
         if dist is not None:
             dist.barrier()
         agg = aggregate_throughput(dist, args.steps, elapsed, device="cpu")
+        if dist is not None:
+            dist.barrier()
         if rank == 0:
             n_gpus = args.pipeline if args.pipeline > 1 else world
-            print(json.dumps({"metric": f"decode tok/s (batch=1, {args.steps} tok)", "value": round(agg["value"], 2), "unit": "tok/s", "n_gpus": n_gpus,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(agg["elapsed"] / args.steps * 1e3, 4),
-                              "higher_is_better": True, "scaling": "capacity" if args.pipeline > 1 else "weak", "vs_baseline": None, "dtype": "f32",
-                              "data": "none (dry run: no device work)", "dry_run": True,
-                              "config": {"workload": f"{args.model} {args.dtype}", "parallelism": f"{args.pipeline}-stage layer pipeline" if args.pipeline > 1 else f"{world} replica(s)"}}), flush=True)
+            line = {"metric": f"decode tok/s (batch=1, {args.steps} tok)", "value": round(agg["value"], 2), "unit": "tok/s", "n_gpus": n_gpus,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(agg["elapsed"] / args.steps * 1e3, 4),
+                    "higher_is_better": True, "scaling": "capacity" if args.pipeline > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+                    "data": "none (dry run: no device work)", "dry_run": True, "steps_note": steps_note(args.steps),
+                    "config": {"workload": f"{args.model} {args.dtype}", "parallelism": f"{args.pipeline}-stage layer pipeline" if args.pipeline > 1 else f"{world} replica(s)"}}
+            if args.pipeline > 1:
+                line["stage_devices"] = list(range(args.pipeline))
+                line["handoff_us"] = None
+            elif world > 1 and not args.no_pipeline_leg:
+                line["pipeline"] = pipeline_leg(args, world)
+            print(json.dumps(line), flush=True)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -161,10 +212,13 @@ def main():
     cpu_skipped = None
     if want_cpu:
         # the CPU leg needs the whole model in host RAM (46.7 GB for Mixtral-8x7B fp8, 131.6 GB for DBRX-132B fp8)
-        import psutil
-
         need = sum(a.nbytes for a in cf.stub_tensors(spec, args.dtype, n_layers).values()) + (6 << 30)
-        have = int(psutil.virtual_memory().available)
+        try:
+            import psutil
+
+            have = int(psutil.virtual_memory().available)
+        except ImportError:  # (not a dependency: fall back to the kernel's own account)
+            have = int(next(ln.split()[1] for ln in open("/proc/meminfo") if ln.startswith("MemAvailable:"))) * 1024
         if have < need:
             cpu_skipped = f"host RAM: the CPU reference needs {need / 2**30:.0f} GiB for this model, {have / 2**30:.0f} GiB available"
             print(f"bench.py: no CPU leg ({cpu_skipped})", file=sys.stderr)
@@ -206,8 +260,9 @@ def main():
     elapsed = agg["elapsed"]
 
     if rank != 0:
-        be.close()
+        be.close()  # (this rank's GPU is free again before rank 0 starts the pipeline leg)
         if dist is not None:
+            barrier()
             dist.destroy_process_group()
         return
 
@@ -318,6 +373,19 @@ def main():
                             f"greedy streams compared over {n_cmp} positions",
                   "max_rel_err": float(f"{worst:.3e}"), "tol": 1e-3, "greedy_identical": first_diff is None, "first_difference_at": first_diff}
 
+    stage_devices, handoff_us, handoffs = None, None, None
+    if args.pipeline > 1:
+        # where the stages really sit, and what one hand-off of the residual stream costs: a few more steps with the library's
+        # profiling on (an event pair around every stage-to-stage copy; perf_hip prints the same)
+        stage_devices = [int(be.lib.calm_hip_configure(b"stage_device", s_)) for s_ in range(be.lib.calm_hip_configure(b"stages", -1))]
+        be.lib.calm_hip_configure(b"prof", 1)
+        tok = first_token
+        for pos in range(8):
+            tok = int(np.argmax(be.forward(tok, pos, 0)))
+        be.lib.calm_hip_configure(b"prof", 0)
+        handoffs = int(be.lib.calm_hip_configure(b"handoffs", -1))
+        handoff_us = round(be.lib.calm_hip_configure(b"handoff_ns", -1) / 1e3, 2) if handoffs else None
+
     out = {
         "metric": f"decode tok/s (batch=1, {args.steps} tok)",
         "value": round(tok_s, 2),
@@ -352,10 +420,19 @@ def main():
         "cpu_baseline_skipped": cpu_skipped,
         "parity": parity,
         "load_seconds": round(load_s, 1),
+        "steps_note": steps_note(args.steps),
     }
+    if args.pipeline > 1:
+        out["stage_devices"] = stage_devices
+        out["handoff_us"] = handoff_us
+        out["handoffs_timed"] = handoffs
     be.close()
     if dist is not None:
+        barrier()  # every rank has released its GPU
         dist.destroy_process_group()
+    if world > 1 and args.pipeline <= 1 and not args.no_pipeline_leg:
+        # BASELINE config 5, which the replica run above is not: DBRX-132B fp8 over N in-library stages
+        out["pipeline"] = pipeline_leg(args, world)
     print(json.dumps(out), flush=True)
 
 

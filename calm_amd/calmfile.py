@@ -303,6 +303,21 @@ SPECS = {
 }
 
 
+# Shapes of further public architectures the reference's converter emits (tools/convert.py:58-125: llama, qwen2, phi3, cohere, olmoe,
+# gemma ...; config.json values of the public checkpoints) -- tests/test_shape_sweep.py runs 1-2 layers of each at full width: the
+# launchers' grid / tile-shape rules were tuned on the five BASELINE shapes above, these are the sixth to thirteenth.
+ARCH_SPECS = {
+    "llama-2-7b": ModelSpec("llama-2-7b", 4096, 11008, 128, 32, 32, 32, 32000, 1e4, max_seq_len=4096),                      # MHA: kv_mul 1
+    "llama-2-13b": ModelSpec("llama-2-13b", 5120, 13824, 128, 40, 40, 40, 32000, 1e4, max_seq_len=4096),                    # 5-KiB fp8 rows
+    "yi-34b": ModelSpec("yi-34b", 7168, 20480, 128, 60, 56, 8, 64000, 5e6, max_seq_len=4096),                               # kv_mul 7
+    "qwen2-7b": ModelSpec("qwen2-7b", 3584, 18944, 128, 28, 28, 4, 152064, 1e6, max_seq_len=32768, norm_eps=1e-6, qkv_bias=True),  # ragged 3.5-KiB rows, bias
+    "phi-3-mini": ModelSpec("phi-3-mini", 3072, 8192, 96, 32, 32, 32, 32064, 1e4, max_seq_len=2048),                        # head size 96
+    "command-r-35b": ModelSpec("command-r-35b", 8192, 22528, 128, 40, 64, 64, 256000, 8e6, max_seq_len=8192, norm_type="layernorm_par", tied=True),
+    "gemma-7b": ModelSpec("gemma-7b", 3072, 24576, 256, 28, 16, 16, 256000, 1e4, max_seq_len=8192, norm_eps=1e-6, act_type="gelu", tied=True),  # head size 256, q_dim > dim
+    "olmoe-1b-7b": ModelSpec("olmoe-1b-7b", 2048, 1024, 128, 16, 16, 16, 50304, 1e4, max_seq_len=4096, n_experts=64, n_experts_active=8),
+}
+
+
 def tiny_spec(name="tiny", **kw) -> ModelSpec:
     """small shapes for unit parity (seconds on the CPU oracle)"""
     base = dict(dim=64, hidden_dim=160, head_dim=16, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=320, rope_theta=1e4, max_seq_len=64)

@@ -74,6 +74,8 @@ std::map<const void*, size_t> g_pending_uploads;
 // ... unless the host says where it belongs first: calm_hip_configure("stage", s) routes the following upload_hip / alloc_hip
 // calls to stage s's device at once (-1: back to deferring) -- for hosts that know tensor names, or fill tensors on the device
 int g_alloc_stage = -1;
+double g_hop_us = 0; // time inside the stage-to-stage copies of profiled steps, and their number (perf_hip; knobs "handoff_ns" / "handoffs")
+uint64_t g_hop_n = 0;
 int g_bpc = 0;       // cap on resident 256-thread workgroups per CU when sizing grids; 0: each kernel's default (2 -- measured: 2 beats 3 and 4 --
                      // except where kernels.hip.h KShape names another)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
@@ -209,6 +211,10 @@ struct Ctx {
 	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, behind vc in ONE allocation (prepare_ctx)
 	size_t kv_layer_bytes = 0;
 	int attn_chunk = 1 << 30; // cached positions per attention split of the step being enqueued (launch_attn_lpr)
+	// The transposed value cache mirrors rows [0, vt_rows) of the value cache.  Only steps with split attention write it (k_qkv's
+	// 2-byte scattered stores cost 1-3 % of a short-context token, profiles/r04_startup.txt); vt_sync brings it up to date first.
+	int vt_rows = 0;
+	bool write_vt = true; // the step being enqueued writes V^T (run_step; part of the graph key through n_split)
 	// mixture-of-experts routing ahead of k_ffn_up (kernels.hip.h k_attn_out GATE): per layer a [dim][gate_ep] fp32 table
 	// moegate[e][j] * ffn_norm[j] (+ gate_ep column sums), and the [gate_ep + 2][GATE_COLS] partial sums of the last k_attn_out
 	float *gate_mt = nullptr, *gate_part = nullptr;
@@ -220,6 +226,8 @@ struct Ctx {
 	unsigned* pf_tile_count = nullptr;
 	float2* pf_rope = nullptr;
 	int* pf_tok = nullptr;
+	unsigned* pf_flag = nullptr;     // pinned host word the prompt kernels raise when an activation leaves the binary16 range (prefill.hip.h)
+	unsigned* pf_flag_dev = nullptr; // ... as the device sees it
 	// ... of a mixture-of-experts model: gate logits, per-expert row lists, one expert's gathered rows
 	float *pf_gate = nullptr, *pf_wsel = nullptr, *pf_xe = nullptr, *pf_y = nullptr;
 	int *pf_rows = nullptr, *pf_colexp = nullptr, *pf_slot = nullptr;
@@ -332,7 +340,7 @@ void launch_qkv(Ctx* c, int l) {
 	a.q = c->q;
 	a.kc = (char*)c->kc + (size_t)l * c->kv_layer_bytes;
 	a.vc = (char*)c->vc + (size_t)l * c->kv_layer_bytes;
-	a.vt = c->vt ? (char*)c->vt + (size_t)l * c->kv_layer_bytes : nullptr;
+	a.vt = (c->vt && c->write_vt) ? (char*)c->vt + (size_t)l * c->kv_layer_bytes : nullptr;
 	a.xb_dump = p->norm_par ? c->xb : nullptr;
 	a.ts = c->ts;
 	a.rope_cs = c->rope_cs;
@@ -671,6 +679,22 @@ uint64_t stage_bytes(Ctx* c, int stage, int kv_len) {
 	return 0;
 }
 
+// rows [vt_rows, upto) of every layer's value cache -> the transposed cache (they were written by steps that skip it)
+void vt_sync(Ctx* c, int upto) {
+	if (!c->vt || c->vt_rows >= upto) {
+		return;
+	}
+	const int n = (upto - c->vt_rows) * c->kv_dim;
+	const size_t layer_elems = (size_t)c->kv_dim * c->seq_len;
+	const dim3 grid((n + 255) / 256, c->n_layers);
+	if (c->kvbits == 16) {
+		hipLaunchKernelGGL(k_vt_backfill<16>, grid, dim3(256), 0, g_stream, c->vc, c->vt, layer_elems, c->kv_dim, c->head_dim, c->seq_len, c->vt_rows, upto);
+	} else {
+		hipLaunchKernelGGL(k_vt_backfill<8>, grid, dim3(256), 0, g_stream, c->vc, c->vt, layer_elems, c->kv_dim, c->head_dim, c->seq_len, c->vt_rows, upto);
+	}
+	c->vt_rows = upto;
+}
+
 // ---------------------------------------------------------------- one decode step ---------------
 
 struct StepPlan {
@@ -812,6 +836,15 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	if (g_prof_json) {
 		account_step(c, sp, kv_len);
 	}
+	// the transposed value cache: written by split steps only (their graphs; the unsplit kernel does not read it), after the rows
+	// before this one have been brought up to date; an unsplit step leaves its row -- and so everything behind it -- unmirrored
+	c->write_vt = c->vt && sp.n_split > 1;
+	if (c->write_vt) {
+		vt_sync(c, kv_sink ? c->seq_len : kv_pos);
+		c->vt_rows = c->vt_rows > kv_pos + 1 ? c->vt_rows : kv_pos + 1;
+	} else if (c->vt) {
+		c->vt_rows = c->vt_rows < kv_pos ? c->vt_rows : kv_pos;
+	}
 
 	c->ba.token = token;
 	c->ba.embed = embed ? c->t->weights.token_embedding_table : nullptr;
@@ -940,6 +973,9 @@ void pf_alloc(Ctx* c) {
 	c->pf_h = frag(c->hidden, erows);
 	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
 	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
+	HIP_CHECK(hipHostMalloc((void**)&c->pf_flag, sizeof(unsigned), hipHostMallocMapped));
+	*c->pf_flag = 0;
+	HIP_CHECK(hipHostGetDevicePointer((void**)&c->pf_flag_dev, c->pf_flag, 0));
 	// k_pf_gemm_wide with K cut into ranges: partial tiles (64 KiB each) and the tiles' arrival counters (left at zero by every launch)
 	c->pf_partial = (float*)dev_alloc(PF_SPLIT_SLOTS * 16384 * sizeof(float));
 	c->pf_tile_count = (unsigned*)dev_alloc(PF_SPLIT_TILES * sizeof(unsigned));
@@ -1282,6 +1318,13 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		return old_stage;
 	} else if (!strcmp(key, "stages")) {
 		return (int)g_devs.size();
+	} else if (!strcmp(key, "stage_device")) { // the device stage `value` sits on
+		CALM_REQUIRE(value >= 0 && value < (int)g_devs.size(), "calm_hip_configure(\"stage_device\"): no such stage");
+		return g_devs[value].dev;
+	} else if (!strcmp(key, "handoffs")) { // hand-off copies timed so far (profiled steps of a model split over stages)
+		return (int)g_hop_n;
+	} else if (!strcmp(key, "handoff_ns")) { // ... and their average duration
+		return g_hop_n ? (int)(g_hop_us * 1e3 / (double)g_hop_n) : 0;
 	} else if (!strcmp(key, "pf_redone")) {
 		return (int)g_pf_redone; // prompt tokens prefill_hip sent back through the serial path (activations beyond binary16)
 	} else {
@@ -1343,19 +1386,34 @@ extern "C" void init_hip(void) {
 			HIP_CHECK(hipGetDeviceProperties(&pr, d.dev));
 			d.ncu = pr.multiProcessorCount;
 			HIP_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
-			if (d.dev != dev) {
-				int can = 0;
-				HIP_CHECK(hipDeviceCanAccessPeer(&can, d.dev, g_devs[s_ - 1].dev));
-				// no silent fallback: without peer access every hand-off would be staged through host memory by the runtime
-				CALM_REQUIRE(can || g_devs[s_ - 1].dev == d.dev || env_int("CALM_HIP_ALLOW_NO_PEER", 0),
+			const int prev = g_devs[s_ - 1].dev;
+			if (d.dev != prev) {
+				// Adjacent stages on different devices: stage s - 1 PUSHES the residual stream into stage s's memory with
+				// hipMemcpyPeerAsync on its own stream (forward_multi), and a tensor a host placed on the other device is pulled with
+				// hipMemcpyPeer (upload_pending).  hipMemcpyPeer* is documented to work without peer access (the runtime then stages
+				// through host memory) -- which is exactly the silent fallback this path must not take: with access enabled the copy
+				// is one DMA over xGMI.  hipDeviceEnablePeerAccess(peer) grants the CURRENT device access to peer's memory and is
+				// one-directional, so it is enabled BOTH ways: d -> prev (pulls, and the runtime's choice of the copying engine) and
+				// prev -> d (the push).  No silent fallback: refuse devices that cannot reach each other.
+				int can_fwd = 0, can_back = 0;
+				HIP_CHECK(hipDeviceCanAccessPeer(&can_back, d.dev, prev));
+				HIP_CHECK(hipDeviceCanAccessPeer(&can_fwd, prev, d.dev));
+				CALM_REQUIRE((can_fwd && can_back) || env_int("CALM_HIP_ALLOW_NO_PEER", 0),
 				             "CALM_HIP_DEVICES: adjacent pipeline stages sit on devices without peer access (xGMI / PCIe P2P); set CALM_HIP_ALLOW_NO_PEER=1 to run anyway");
-				if (can && g_devs[s_ - 1].dev != d.dev) {
-					hipError_t e = hipDeviceEnablePeerAccess(g_devs[s_ - 1].dev, 0); // the residual stream arrives from the stage before
+				auto enable = [&](int from, int to, int can) {
+					if (!can) {
+						return;
+					}
+					HIP_CHECK(hipSetDevice(from));
+					hipError_t e = hipDeviceEnablePeerAccess(to, 0);
 					if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) {
 						HIP_CHECK(e);
 					}
 					(void)hipGetLastError();
-				}
+				};
+				enable(d.dev, prev, can_back);
+				enable(prev, d.dev, can_fwd);
+				HIP_CHECK(hipSetDevice(d.dev));
 			}
 			g_devs.push_back(d);
 		}
@@ -1614,6 +1672,8 @@ struct MultiCtx {
 	// steps -- run.c's prompt loop -- are only enqueued: without this a faster stage s runs ahead into stage s + 1's residual.
 	std::vector<hipEvent_t> done;
 	std::vector<char> done_valid;
+	// CALM_HIP_PROF / knob "prof": an event pair around every hand-off copy (created on first use)
+	std::vector<hipEvent_t> hop0, hop1;
 };
 std::map<struct Transformer*, MultiCtx*> g_multi;
 
@@ -1732,7 +1792,21 @@ float* forward_multi(MultiCtx* m, int token, int pos, unsigned flags) {
 			if (m->done_valid[s + 1]) {
 				HIP_CHECK(hipStreamWaitEvent(g_stream, m->done[s + 1], 0)); // ... of the step before: its x may go now
 			}
+			const bool timed = g_prof && !kv_only;
+			if (timed && m->hop0.empty()) {
+				m->hop0.assign(P - 1, nullptr), m->hop1.assign(P - 1, nullptr);
+			}
+			if (timed && !m->hop0[s]) { // (an event belongs to the device that is current when it is created: stage s's)
+				HIP_CHECK(hipEventCreate(&m->hop0[s]));
+				HIP_CHECK(hipEventCreate(&m->hop1[s]));
+			}
+			if (timed) {
+				HIP_CHECK(hipEventRecord(m->hop0[s], g_stream));
+			}
 			HIP_CHECK(hipMemcpyPeerAsync(nx->x, g_devs[s + 1].dev, c->x, g_devs[s].dev, (size_t)c->dim * sizeof(float), g_stream));
+			if (timed) {
+				HIP_CHECK(hipEventRecord(m->hop1[s], g_stream));
+			}
 			HIP_CHECK(hipEventRecord(m->handoff[s], g_stream));
 		}
 	}
@@ -1740,6 +1814,14 @@ float* forward_multi(MultiCtx* m, int token, int pos, unsigned flags) {
 	if (!kv_only) {
 		HIP_CHECK(hipStreamSynchronize(g_stream)); // the last stage's stream: everything before it is ordered by the events
 		out = ctx_of(m->stage[P - 1])->logits_h;
+		if (g_prof && !m->hop0.empty()) { // the hand-offs of this step (every copy precedes the last stage's work)
+			for (int s = 0; s + 1 < P; ++s) {
+				float ms = 0;
+				HIP_CHECK(hipEventElapsedTime(&ms, m->hop0[s], m->hop1[s]));
+				g_hop_us += ms * 1e3;
+				g_hop_n++;
+			}
+		}
 	}
 	use_dev(0);
 	return out;
@@ -1754,6 +1836,18 @@ extern "C" void prepare_hip(struct Transformer* t) {
 	} else {
 		prepare_ctx(t);
 	}
+	// the uploads are complete (prepare_ctx drains every device): the pinned staging buffers (2 x 32 MiB per device) go back
+	for (auto& kv : g_stagers) {
+		HIP_CHECK(hipSetDevice(kv.first));
+		for (int b = 0; b < 2; ++b) {
+			if (kv.second.pin[b]) {
+				HIP_CHECK(hipHostFree(kv.second.pin[b]));
+				HIP_CHECK(hipEventDestroy(kv.second.done[b]));
+			}
+		}
+	}
+	g_stagers.clear();
+	use_dev(0);
 }
 
 extern "C" void release_hip(struct Transformer* t) {
@@ -1774,6 +1868,12 @@ extern "C" void release_hip(struct Transformer* t) {
 		}
 		for (hipEvent_t e : m->done) {
 			HIP_CHECK(hipEventDestroy(e));
+		}
+		for (size_t i = 0; i < m->hop0.size(); ++i) {
+			if (m->hop0[i]) {
+				HIP_CHECK(hipEventDestroy(m->hop0[i]));
+				HIP_CHECK(hipEventDestroy(m->hop1[i]));
+			}
 		}
 		use_dev(0);
 		delete m;
@@ -1813,6 +1913,9 @@ extern "C" void release_hip(struct Transformer* t) {
 		}
 	}
 	HIP_CHECK(hipHostFree(c->logits_h));
+	if (c->pf_flag) {
+		HIP_CHECK(hipHostFree(c->pf_flag));
+	}
 	if (g_prof_ctx == c) {
 		g_prof_ctx = nullptr;
 	}
@@ -1933,6 +2036,9 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 			pf_alloc(st[s]);
 			// the K-range GEMMs leave their tile counters at zero; a launch that did not run to its end must not poison the next call
 			HIP_CHECK(hipMemsetAsync(st[s]->pf_tile_count, 0, PF_SPLIT_TILES * sizeof(unsigned), g_stream));
+			// this model's range flag is the one this device's prompt kernels raise from here on (ordered on the stream)
+			*st[s]->pf_flag = 0;
+			HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(calm_pf_range_ptr), &st[s]->pf_flag_dev, sizeof(unsigned*), 0, hipMemcpyHostToDevice, g_stream));
 		}
 		if (logprob && !last->pf_logits) { // (the last stage's device is current)
 			last->pf_logits = (float*)dev_alloc((size_t)PF_NT * last->vocab * sizeof(float));
@@ -1963,7 +2069,11 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 					}
 					HIP_CHECK(hipMemcpyAsync(c->pf_target, target, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
 				}
+				vt_sync(c, pos + done); // the prompt kernels read (and extend) the transposed value cache: rows before the chunk first
 				dispatch_prefill_chunk(c, nb, pos + done, score, s == 0);
+				if (c->vt && c->vt_rows < pos + done + nb) {
+					c->vt_rows = pos + done + nb;
+				}
 				if (s > 0) {
 					HIP_CHECK(hipEventRecord(m->done[s], g_stream));
 					m->done_valid[s] = 1;
@@ -1980,27 +2090,27 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 				HIP_CHECK(hipMemcpyAsync(logprob + done, last->pf_lp, (size_t)nb * sizeof(float), hipMemcpyDeviceToHost, g_stream));
 				HIP_CHECK(hipStreamSynchronize(g_stream));
 			}
-			// did every activation of the chunk fit the hi + lo binary16 form (prefill.hip.h: pf_split2)?  If not -- values beyond
-			// +-65504, NaN -- the chunk's cache rows (and scores) are redone by the serial fp32 decode path, token by token.
-			bool redo = false;
-			for (int s = 0; s < P; ++s) {
-				on_stage(s);
-				HIP_CHECK(hipStreamSynchronize(g_stream));
-				unsigned hit = 0;
-				HIP_CHECK(hipMemcpyFromSymbol(&hit, HIP_SYMBOL(calm_pf_range_hit), sizeof(hit)));
-				if (hit) {
-					redo = true;
-					hit = 0;
-					HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(calm_pf_range_hit), &hit, sizeof(hit)));
-				}
-			}
-			if (redo) {
-				g_pf_redone += nb;
-				for (int i = done; i < done + nb; ++i) {
-					serial_token(i);
-				}
-			}
 			done += nb;
+		}
+	}
+	if (done > 0) {
+		// Did every activation of the batched chunks fit the hi + lo binary16 form (prefill.hip.h: pf_split2)?  The flags are host
+		// words the kernels raise: ONE synchronisation per call (of the last stage, which is behind every hand-off), not one
+		// per chunk and stage.  If a flag is up -- values beyond +-65504, NaN -- the batched part of the prompt (later chunks read
+		// the rows of the one that overflowed) is redone by the serial fp32 decode path, token by token, before anything is built on
+		// it: the batched path never decides a result it cannot represent.  (Its positions lie before the rolling buffer wraps: a
+		// serial step there is idempotent.)
+		on_stage(P - 1);
+		HIP_CHECK(hipStreamSynchronize(g_stream));
+		bool redo = false;
+		for (int s = 0; s < P; ++s) {
+			redo = redo || *st[s]->pf_flag != 0;
+		}
+		if (redo) {
+			g_pf_redone += done;
+			for (int i = 0; i < done; ++i) {
+				serial_token(i);
+			}
 		}
 	}
 	for (; done < n; ++done) {
@@ -2067,6 +2177,10 @@ extern "C" float* decode_sample_hip(struct Transformer* t, int token, int pos, i
 }
 
 extern "C" void perf_hip(void) {
+	if (g_hop_n) {
+		printf("\nlayer pipeline: %llu hand-offs of the residual stream between stages, avg %.1f usec each (event pair around the peer copy)\n", (unsigned long long)g_hop_n,
+		       g_hop_us / (double)g_hop_n);
+	}
 	Ctx* c = g_prof_ctx;
 	if (!c) {
 		return;
@@ -2103,6 +2217,7 @@ extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, ui
 	}
 	int n_split = attn_splits(c, kv_len);
 	c->attn_chunk = (kv_len + n_split - 1) / n_split;
+	c->write_vt = c->vt && n_split > 1;
 	auto one = [&](int l) {
 #define ST(db, kvb)                                  \
 	if (c->dbits == db && c->kvbits == kvb) {        \

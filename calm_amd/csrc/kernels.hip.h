@@ -79,6 +79,8 @@ struct Fmt {
 	static constexpr int PAD = 8 / F4;
 	static constexpr int ROW = 64 + PAD;
 	static constexpr int CS = ROW * (F4 + (DB == 4 ? 1 : 0));
+	// what a finished row sum of dot16<DB> is still to be multiplied by (gf4: see dot16<4>; a power of two, exact)
+	static constexpr float POST = DB == 4 ? -4194304.0f : 1.0f;
 };
 
 __device__ __forceinline__ int lane_id() {
@@ -240,14 +242,16 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		acc += acc_b;
 	} else {
 		// gf4: word = 8-bit e5m2 scale S + 8 x 3-bit codes, w_k = (q_k - 4) * S / -4   (src/infer.c:37-40)
-		//   sum_k w_k x_k = (-S/4) * sum_k q_k x_k + S * sum_k x_k
+		//   sum_k w_k x_k = (-S/4) * sum_k (q_k - 4) x_k
 		// The codes are never converted.  A 3-bit field anywhere in the mantissa of a binary16 half, everything
 		// else masked off, IS the subnormal q * 2^(a-24), and v_fma_mix_f32 multiplies a half by an fp32
 		// activation into an fp32 accumulator in one instruction; the LDS image carries x_k * 2^-a per column
 		// (exact), so the product is q x 2^-24 whatever a is.  One rotation of the word puts c5 c6 c7 into the
 		// mantissa of the low half and c0 c1 c2 into that of the high half, so three ANDs isolate six codes;
-		// c3 and c4 already sit in the high half's mantissa of the word itself: 6 integer ops + 8 fma_mix per
-		// 8 weights, and the activation sum of the word comes precomputed from the image (float4 #8).
+		// c3 and c4 already sit in the high half's mantissa of the word itself.  The chain of a word STARTS from
+		// -2^-22 sum_k x_k, which the image carries precomputed per word (float4 #8), so it ends as 2^-24 sum_k (q_k - 4) x_k and
+		// one multiply-add by S files it: 1 conversion + 6 integer ops + 8 fma_mix + 1 fma per 8 weights; the common factor
+		// -2^22 = (-1/4) 2^24 is applied once per row (Fmt<4>::POST, run_rows_impl).
 		f32x4 xv[4][2];
 		unsigned m[4][5];
 		float t[4], S[4];
@@ -270,7 +274,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		// One chain per word; the four words' chains are interleaved code-major for ILP.
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			t[j] = mul_mix_hi(m[j][0], xv[j][0][0]);
+			t[j] = fma_mix_hi(m[j][0], xv[j][0][0], xsum[j]);
 		}
 #pragma unroll
 		for (int k = 1; k < 8; ++k) {
@@ -282,8 +286,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		}
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			// (-S/4) * 2^24 * t + S * xsum  =  S * (xsum - 2^22 t): two fmas on one chain
-			acc[0] = fmaf(S[j], fmaf(t[j], -4194304.0f, xsum[j]), acc[0]);
+			acc[0] = fmaf(S[j], t[j], acc[0]);
 		}
 	}
 	return acc;
@@ -295,7 +298,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 // 4p..4p+3) belongs to chunk p / (16G), lane (p % 16G) / F4, sub-index i = p % F4 and is stored at
 // float4 slot chunk*CS + i*ROW + lane (Fmt<DB>: ROW = 64 + PAD): a wave reading "its float4 #i" hits 64 consecutive slots.
 // gf4 only: the image holds x_k * 2^-a(k % 8), a = {1,4,7,1,4,0,3,6} (dot16<4> multiplies by codes that
-// sit 2^a too high), and slot chunk*CS + 8*ROW + lane holds the four UNSCALED 8-column sums of the lane.
+// sit 2^a too high), and slot chunk*CS + 8*ROW + lane holds -2^-22 x the four (unscaled) 8-column sums of the lane.
 template <int DB>
 __device__ __forceinline__ int swz4(int p) {
 	constexpr int G = Fmt<DB>::G, F4 = Fmt<DB>::F4;
@@ -314,7 +317,7 @@ __host__ __device__ constexpr int xs_slots(int n) {
 	return ((n + 64 * Fmt<DB>::G - 1) / (64 * Fmt<DB>::G)) * Fmt<DB>::CS;
 }
 
-// gf4: write float4 p of the image (scaled per column) and, from the even p of a pair, the pair's unscaled sum.
+// gf4: write float4 p of the image (scaled per column) and, from the even p of a pair, -2^-22 x the pair's unscaled sum.
 // Lanes p and p^1 are adjacent threads (p = tid + i * BLOCK, BLOCK even) and are active together (n % 32 == 0).
 __device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
 	float s = (t.x + t.y) + (t.z + t.w);
@@ -327,7 +330,7 @@ __device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
 	xs4[swz4<4>(p)] = t;
 	if (!odd) {
 		const int chunk = p / 512, r = p % 512; // 512 logical float4 per gf4 chunk; lane r / 8, word (r % 8) / 2
-		((float*)&xs4[chunk * Fmt<4>::CS + 8 * Fmt<4>::ROW + r / 8])[(r % 8) >> 1] = s;
+		((float*)&xs4[chunk * Fmt<4>::CS + 8 * Fmt<4>::ROW + r / 8])[(r % 8) >> 1] = s * -2.384185791015625e-07f; // -2^-22 (dot16<4>: where a word's chain starts)
 	}
 }
 
@@ -686,7 +689,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 			if (last_k) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
-					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
+					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]) * Fmt<DB>::POST; // valid in lane RED_LANE
 					acc2[r] = (f32x2){0.f, 0.f};
 				}
 				epi(t, acc, aux);
@@ -871,6 +874,26 @@ __global__ void k_rotate_sink(void* kc, const float2* rope_cs1, int n_kv_heads, 
 		f32x2 v = bf8x2_lo(b);
 		float a = v[0] * cs.x - v[1] * cs.y, c = v[0] * cs.y + v[1] * cs.x;
 		*p = e5m2x2_sat(a, c);
+	}
+}
+
+// Rows [r0, r1) of every layer's value cache copied into the transposed cache (attn_vt_offset).  The decode step writes V^T only in
+// steps whose attention is split (the only reader, k_attn_vt): a sequence's first split step -- and a prompt chunk behind rows that
+// came from unsplit steps -- first brings the transposed copy up to date with this (infer_hip.hip run_step, Ctx::vt_rows).  Rare
+// (once per sequence): one thread per element.  grid = (ceil((r1 - r0) * kv_dim / 256), n_layers)
+template <int KVB>
+__global__ void k_vt_backfill(const void* vc, void* vt, size_t layer_elems, int kv_dim, int head_dim, int seq_len, int r0, int r1) {
+	const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (r1 - r0) * kv_dim) {
+		return;
+	}
+	const int p = r0 + idx / kv_dim, row = idx % kv_dim; // row = (kv head, dim)
+	const size_t src = (size_t)blockIdx.y * layer_elems + ((size_t)(row / head_dim) * seq_len + p) * head_dim + row % head_dim;
+	const size_t dst = (size_t)blockIdx.y * layer_elems + attn_vt_offset(row, p, head_dim, seq_len, KVB / 8);
+	if constexpr (KVB == 16) {
+		((unsigned short*)vt)[dst] = ((const unsigned short*)vc)[src];
+	} else {
+		((unsigned char*)vt)[dst] = ((const unsigned char*)vc)[src];
 	}
 }
 
@@ -2091,7 +2114,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 			}
 			acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
 			if (k == chunks - 1) {
-				const float logit = wave_sum63(acc2[0] + acc2[1]) * nscale;
+				const float logit = wave_sum63(acc2[0] + acc2[1]) * (nscale * Fmt<DB>::POST);
 				if (lane == RED_LANE && e < n_experts) {
 					gate[e] = logit;
 				}

@@ -12,7 +12,7 @@
 // instructions.  Narrowing the activations to ONE fp16 / bf16 number costs 3e-4..2e-3 per matvec and breaks the
 // 1e-3 logits parity with the CPU path; the split measures 4..8e-7 (tools/hilo_study.py), the same as the f32
 // MFMA form this file used before (bit-for-bit an fmaf chain, 157 TF peak).  An activation beyond +-65504 (or a NaN) raises
-// calm_pf_range_hit and the chunk is redone by the serial fp32 path (infer_hip.hip: prefill_impl).
+// the model's range flag (calm_pf_range_ptr) and the prompt is redone by the serial fp32 path (infer_hip.hip: prefill_impl).
 //
 // Two GEMM forms.  k_pf_gemm (next paragraph) fills the chip from few tiles by splitting K over the waves of a workgroup: short
 // prompts.  k_pf_gemm_wide (further down: B staged once per workgroup through LDS, A through a wave-private LDS image, XCD-aware
@@ -56,16 +56,18 @@ constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing ha
 __device__ __forceinline__ size_t pf_unit(int t, int k, int nsteps) {
 	return ((((size_t)(t >> 5) * nsteps + (k >> 6)) * 4 + ((k & 31) >> 3)) << 7) + (((k >> 5) & 1) << 5) + (t & 31);
 }
-// Set (never cleared by a kernel) when an activation did not fit the hi + lo form: beyond the binary16 range, or not a number.
-// prefill_impl reads it after every chunk and runs that chunk again through the serial fp32 decode path, so the batched path
-// either agrees with the serial one to fp32 rounding or is not used (one flag per module and device).
-__device__ unsigned calm_pf_range_hit;
+// Raised (never cleared by a kernel) when an activation did not fit the hi + lo form: beyond the binary16 range, or not a number.
+// The word lives in pinned host memory of the model being ingested (Ctx::pf_flag; prefill_impl points this device's copy of
+// calm_pf_range_ptr at it on the stream ahead of the call's kernels) and is read by the host at the call's own final
+// synchronisation -- no extra round trip per chunk, no flag shared between models: a prompt during which it was raised is redone
+// through the serial fp32 decode path, so the batched path either agrees with the serial one to fp32 rounding or is not used.
+__device__ unsigned* calm_pf_range_ptr;
 
 // x = hi + lo, two binary16 numbers each.  Out-of-range values saturate HERE (NaN stays NaN: the compares are ordered) and
-// raise calm_pf_range_hit, which sends the whole chunk back through the serial path.
+// raise the model's range flag (calm_pf_range_ptr), which sends the prompt back through the serial path.
 __device__ __forceinline__ void pf_split2(float a, float b, unsigned& hi, unsigned& lo) {
 	if (!(fabsf(a) <= 65504.f) || !(fabsf(b) <= 65504.f)) { // also true for NaN
-		calm_pf_range_hit = 1u;
+		*calm_pf_range_ptr = 1u;
 	}
 	a = a > 65504.f ? 65504.f : (a < -65504.f ? -65504.f : a);
 	b = b > 65504.f ? 65504.f : (b < -65504.f ? -65504.f : b);
@@ -949,7 +951,7 @@ __device__ __forceinline__ void pf_epilogue_rows(const PfGemmArgs& a, const f32x
 // ---- chunks of 3 or 4 tokens: every weight streamed ONCE, at the decode kernels' rate ----------------------------------------------
 // The GEMM forms below cost a flat ~160 us per layer for a handful of tokens (every weight streamed once at 1.4 TB/s), four serial
 // decode steps 200.  k_pf_skinny is the decode row engine's stream with T tokens' activations behind it
-// (tools/exp_skinny.hip, profiles/r03_multi_token_probe.txt: four tokens in 1.55-2.3 x one token's launch):
+// (tools/experiments/exp_skinny.hip, profiles/r03_multi_token_probe.txt: four tokens in 1.55-2.3 x one token's launch):
 //   * a wave-load covers 256 bytes of each of FOUR weight rows (lane 4 b + n: bytes [16 b, 16 b + 16) of row n's chunk) -- the operand
 //     layout of v_mfma_f32_4x4x4_16b_f16: sixteen independent 4 x 4 x 4 products per wave, block b = lane / 4, B column n = lane % 4 =
 //     the weight ROW, A row i = lane % 4 = the TOKEN, K = 4 weights per instruction;

@@ -47,8 +47,9 @@ void* upload_hip(void* host, size_t size);
 void* alloc_hip(size_t size);
 
 /* replaces prepare_cuda (src/run.c:23,580; src/infer.cu:73-131): allocates activations, the KV
- * cache (state.kvbits must already be 8 or 16; for head size 128 the VALUE cache is kept twice, the second copy transposed for the
- * matrix-core attention of long contexts -- state.value_cache points at an allocation twice the reference's size) and the host-visible logits buffer, and snapshots
+ * cache (state.kvbits must already be 8 or 16; for head size 128, windows of whole 64-position blocks longer than "split_min" positions and the knob
+ * "attn_vt" on at this point, the VALUE cache is kept twice, the second copy transposed for the matrix-core attention of long contexts -- + 50 % of
+ * the KV cache's memory; state.value_cache then points at an allocation twice the reference's size; if that does not fit, the backend runs without it) and the host-visible logits buffer, and snapshots
  * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits, and -- an extension, the reference's
  * GPU backend leaves it unset -- state.exp: device memory holding the routing of the last decode step, [n_layers][CALM_MAX_EXPERTS]
  * float weights in rank order followed by as many int expert ids (dense models: weight 1, expert 0).
@@ -105,7 +106,8 @@ float* decode_sample_hip(struct Transformer* transformer, int token, int pos, in
  * i.e. of the reference's serial prompt loop (src/run.c:208,216-218; README.md:80 "prompt processing is
  * serial"), computed up to 1024 tokens at a time: weights are streamed once per chunk and the multiply-adds run on
  * the f16 matrix cores with the fp32 activations carried as hi + lo binary16 (every product exact, fp32 accumulation:
- * 3-7e-7 per GEMM), so the cache rows agree with the serial path to fp32 rounding.  Activations beyond +-65504 saturate.
+ * 3-7e-7 per GEMM), so the cache rows agree with the serial path to fp32 rounding.  A chunk in which an activation leaves the binary16 range (beyond +-65504, or NaN)
+ * is redone token by token through the serial fp32 decode path inside the call (knob "pf_redone" counts such tokens).
  * Returns after the work is complete (`tokens` is host memory and may be reused).
  * Mixture-of-experts models are routed per token on the device and each expert runs one GEMM over the rows
  * routed to it.  Positions at or beyond seq_len (rolling buffer, sink rotation between tokens) are processed
@@ -156,17 +158,27 @@ double perf_stage_hip(struct Transformer* transformer, int stage, int iters, uin
 /* name of the HIP device in use (static storage) */
 const char* calm_hip_device_name(void);
 
-/* Run-time knobs (same as the CALM_HIP_* environment variables read by init_hip):
- *   "graph"   1 = replay each step from a hipGraph (default), 0 = eager launches
- *   "prof"    1 = eager launches bracketed by per-stage events, reported by perf_hip
- *   "bpc"     cap on resident 256-thread workgroups per CU when sizing grids (default 0: each kernel's own -- 2, the gf4 classifier 4)
- *   "split_t" cached positions per attention KV split (default 128)
+/* Run-time knobs (the CALM_HIP_* environment variables read by init_hip set the same switches before the first model):
+ *   "graph"     1 = replay each step from a hipGraph (default), 0 = eager launches
+ *   "prof"      1 = eager launches bracketed by per-stage events, reported by perf_hip (a model split over stages: also an event pair
+ *               around every stage-to-stage copy)
+ *   "bpc"       cap on resident 256-thread workgroups per CU when sizing grids (default 0: each kernel's own -- 2, the gf4 classifier 4)
+ *   "split_t"   cached positions per attention KV split (default 128)
  *   "split_min" contexts up to this many positions are not split (default 384)
- *   "attn_vt" 1 = split attention on the matrix cores over the transposed value cache (default; head size 128), 0 = lane arithmetic
- *   "qkv_mode" / "out_one" / "down_one" / "down_u" / "down_u4": tile-shape overrides of single kernels (0 = the launchers' rules by
- *             matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
- * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.
- * Changing "bpc"/"split_t" only affects graphs captured afterwards. */
+ *   "attn_vt"   1 = split attention on the matrix cores over the transposed value cache (default; head size 128), 0 = lane arithmetic.
+ *               Read by prepare_hip: 0 at that point also saves the transposed cache's memory
+ *   "attn_waves" waves per workgroup of the unsplit attention kernel: 16 (default), 8 or 4
+ *   "moe_route" 1 = a mixture-of-experts layer's routing is derived from partial sums the attention output projection leaves
+ *               (default), 0 = every workgroup of the FFN kernel computes the gate from the vector first
+ *   "qkv_half" / "out_one" / "down_one" / "down_u" / "down_u4": tile-shape overrides of single kernels (0 = the launchers' rules by
+ *               matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
+ *   "pf_wide" / "pf_attn_mfma" / "pf_skinny": forms of the prompt-ingestion kernels (1 = default forms)
+ *   "stage"     multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip)
+ * Queries (value ignored): "stages" (pipeline stages of this process), "stage_device" (value = stage -> its device), "pf_redone"
+ * (prompt tokens prefill_hip sent back through the serial path), "handoffs" / "handoff_ns" (stage-to-stage copies timed under "prof"
+ * and their average duration).
+ * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.  Changing a knob that shapes the launches drops
+ * the captured graphs of every prepared model (they are re-captured on next use). */
 int calm_hip_configure(const char* key, int value);
 
 #ifdef __cplusplus

@@ -167,6 +167,47 @@ def test_fp16_cache_to_the_end_of_a_4096_context_and_past_it(hiplib, more_cpu_th
         ref.close()
 
 
+@pytest.mark.parametrize("kvbits", [16, 8])
+def test_transposed_value_cache_catches_up_when_a_sequence_crosses_the_split_threshold(hiplib, more_cpu_threads, kvbits):
+    """The decode step writes the transposed value cache only in steps whose attention is split (positions beyond "split_min");
+    the first split step of a sequence first copies the rows the unsplit steps left out (k_vt_backfill), and a sequence restarted
+    from position 0 invalidates them again.  Decoded from position 0 -- no pre-filled caches -- across the threshold, twice, the
+    second time with a batched prompt over the first positions (prefill_hip extends the transposed cache itself)."""
+    seq_len = 1024
+    spec = attention_true_spec(seq_len)
+    tensors, md = cf.synth_model_big(spec, "fp8", 23)
+    model = HostModel(tensors, md, context=seq_len)
+    ref = oracle.OracleBackend(model, kvbits=kvbits)
+    hip = HipBackend(model, kvbits=kvbits)
+    rng = np.random.default_rng(9)
+    vocab = model.config.vocab_size
+    try:
+        for rnd in range(2):
+            toks = [int(t) for t in rng.integers(0, vocab, size=430)]
+            check = {0, 383, 384, 385, 400, 429}
+            start = 0
+            if rnd == 1:  # the first 100 positions as one prompt chunk, then token by token
+                start = 100
+                import ctypes as C
+                arr = (C.c_int * start)(*toks[:start])
+                hiplib.prefill_hip(C.byref(hip.t), arr, start, 0)
+                for pos in range(start):
+                    ref.forward(toks[pos], pos, FF)
+            worst = 0.0
+            for pos in range(start, len(toks)):
+                if pos in check:
+                    lr, lg = ref.forward(toks[pos], pos, 0), hip.forward(toks[pos], pos, 0)
+                    assert np.isfinite(lg).all(), pos
+                    worst = max(worst, rel_err(lg, lr))
+                else:
+                    ref.forward(toks[pos], pos, FF)
+                    hip.forward(toks[pos], pos, FF)
+            assert worst < LOGIT_TOL, (rnd, worst)
+    finally:
+        hip.close()
+        ref.close()
+
+
 def test_fp8_cache_to_the_end_of_an_8192_context_and_past_it(hiplib, more_cpu_threads):
     """seq_len = 8192 with the fp8 (e5m2) cache on both sides -- the configuration src/run.c:536-540 picks for contexts beyond
     4096 on a GPU backend; same protocol as above"""

@@ -36,7 +36,8 @@ WORKER = textwrap.dedent(
             b.forward(tok, pos, 0)
         out.append(b.forward(tok, pos, 0).copy())
     np.save(os.environ["CALM_OUT"], np.stack(out))
-    sys.stdout.write(json.dumps({"stages": b.stages, "devices": b.lib.calm_hip_device_count()}) + "\\n")
+    sys.stdout.write(json.dumps({"stages": b.stages, "devices": b.lib.calm_hip_device_count(),
+                                 "stage_devices": [b.lib.calm_hip_configure(b"stage_device", s) for s in range(b.stages)]}) + "\\n")
     b.close()
     """
 )
@@ -90,11 +91,7 @@ KVONLY_WORKER = textwrap.dedent(
 )
 
 
-@pytest.mark.parametrize("case,kvbits", [("sink_fp16", 16), ("tiny_fp8", 16), ("moe_fp8", 16), ("hd256_sink_fp8", 8), ("tiny_fp16", 8)])
-def test_runs_of_kv_only_steps_on_a_sharded_model(hiplib, tmp_path, case, kvbits):
-    """FF_UPDATE_KV_ONLY steps are only enqueued: nothing but the stages' own events keeps stage 0 from running ahead into stage
-    1's residual stream.  Prompts of several lengths (past seq_len for the sink model) fed as runs of KV-only steps, then one
-    step with logits: the golden logits of the reference, and the unsharded backend bit for bit."""
+def check_kv_only_runs(case, kvbits, tmp_path):
     model, z = load_golden(case)
     if model.config.n_layers < 2:
         pytest.skip("fewer layers than stages")
@@ -116,6 +113,14 @@ def test_runs_of_kv_only_steps_on_a_sharded_model(hiplib, tmp_path, case, kvbits
             assert np.array_equal(got[i], b.forward(toks[n], n, 0)), (case, n)
         finally:
             b.close()
+
+
+@pytest.mark.parametrize("case,kvbits", [("sink_fp16", 16), ("tiny_fp8", 16), ("moe_fp8", 16), ("hd256_sink_fp8", 8), ("tiny_fp16", 8)])
+def test_runs_of_kv_only_steps_on_a_sharded_model(hiplib, tmp_path, case, kvbits):
+    """FF_UPDATE_KV_ONLY steps are only enqueued: nothing but the stages' own events keeps stage 0 from running ahead into stage
+    1's residual stream.  Prompts of several lengths (past seq_len for the sink model) fed as runs of KV-only steps, then one
+    step with logits: the golden logits of the reference, and the unsharded backend bit for bit."""
+    check_kv_only_runs(case, kvbits, tmp_path)
 
 
 PREFILL_WORKER = textwrap.dedent(
@@ -141,11 +146,7 @@ PREFILL_WORKER = textwrap.dedent(
 )
 
 
-@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "dbrx_like_fp8"])
-def test_prompt_ingestion_on_a_sharded_model(hiplib, tmp_path, case):
-    """prefill_hip / prefill_logprobs_hip on CALM_HIP_DEVICES=2: a chunk runs stage after stage, the residual rows crossing like
-    one token's x does; the logits of the next decode step and every scored log-probability equal the unsharded backend's bit
-    for bit (sink_fp16: the prompt runs past seq_len, the tail goes through the sharded decode path inside the call)"""
+def check_prompt_ingestion(case, tmp_path):
     model, z = load_golden(case)
     toks = [int(t) for t in z["tokens"]]
     n = len(toks) - 1
@@ -170,6 +171,14 @@ def test_prompt_ingestion_on_a_sharded_model(hiplib, tmp_path, case):
         b2.close()
 
 
+@pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "dbrx_like_fp8"])
+def test_prompt_ingestion_on_a_sharded_model(hiplib, tmp_path, case):
+    """prefill_hip / prefill_logprobs_hip on CALM_HIP_DEVICES=2: a chunk runs stage after stage, the residual rows crossing like
+    one token's x does; the logits of the next decode step and every scored log-probability equal the unsharded backend's bit
+    for bit (sink_fp16: the prompt runs past seq_len, the tail goes through the sharded decode path inside the call)"""
+    check_prompt_ingestion(case, tmp_path)
+
+
 @pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip (reference CLI linked to libcalm_hip.so) not built")
 def test_reference_cli_drives_a_two_stage_model():
     """the unmodified run.c on CALM_HIP_DEVICES=2: it uploads tensors without knowing their layer (src/run.c:550-561), prepare_hip
@@ -182,15 +191,22 @@ def test_reference_cli_drives_a_two_stage_model():
 
 
 def test_stages_on_two_physical_devices(hiplib, tmp_path):
-    """needs >= 2 GPUs (self-skips on the 1-GPU box): the hand-off really crosses xGMI"""
+    """needs >= 2 GPUs (self-skips on the 1-GPU box): the hand-off really crosses xGMI -- decode steps with KV-only steps in between,
+    runs of KV-only steps (stage 0 must not run ahead into stage 1's input across devices either), prompt ingestion and scoring, a
+    mixture-of-experts model; everything bit-equal to one device.  Peer access is enabled in both directions by init_hip."""
     if load_lib().calm_hip_device_count() < 2:
-        pytest.skip("one GPU visible: the same path runs with both stages on it (test above)")
-    model, z = load_golden("tiny_fp8")
-    got, info = run_worker("tiny_fp8", 2, tmp_path)
-    assert info["devices"] >= 2
-    b = HipBackend(model)
-    try:
-        for pos, tok in enumerate(int(t) for t in z["tokens"]):
-            assert np.array_equal(got[pos], b.forward(tok, pos, 0))
-    finally:
-        b.close()
+        pytest.skip("one GPU visible: the same path runs with both stages on it (tests above)")
+    for case in ("tiny_fp8", "moe_fp8"):
+        model, z = load_golden(case)
+        got, info = run_worker(case, 2, tmp_path)
+        assert info["devices"] >= 2 and info["stage_devices"][0] != info["stage_devices"][1], info
+        b = HipBackend(model)
+        try:
+            for pos, tok in enumerate(int(t) for t in z["tokens"]):
+                assert np.array_equal(got[pos], b.forward(tok, pos, 0))
+        finally:
+            b.close()
+    check_kv_only_runs("sink_fp16", 16, tmp_path)
+    check_kv_only_runs("hd256_sink_fp8", 8, tmp_path)
+    check_prompt_ingestion("tiny_fp8", tmp_path)
+    check_prompt_ingestion("dbrx_like_fp8", tmp_path)

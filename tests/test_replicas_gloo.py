@@ -59,7 +59,24 @@ def test_bench_launches_itself_for_n_gpus():
     out = _bench("--gpus", "2")
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["dry_run"] is True
     assert abs(out["value"] - 2 * 4 / (1e-3 * 4 * 1.1)) < 1e-2  # whole-job steps over the slower rank's time
-    assert _bench()["n_gpus"] == 1
+    one = _bench()
+    assert one["n_gpus"] == 1 and "pipeline" not in one
+
+
+def test_bench_n_gpus_also_runs_the_layer_pipeline():
+    """the driver's one command per N (`bench.py --gpus N`) measures replicas -- which SURVEY.md section 8e calls "not part of the
+    metric" -- so rank 0 afterwards runs BASELINE config 5 (`--gpus N --pipeline`, DBRX-132B over N in-library stages) as a child and
+    embeds its line: the first multi-GPU lease yields the north_star's 2 / 4 / 8-GPU number without a second command"""
+    out = _bench("--gpus", "2")
+    p = out["pipeline"]
+    assert "error" not in p, p
+    assert p["n_gpus"] == 2 and p["scaling"] == "capacity" and p["steps"] == 4
+    assert p["config"]["workload"].startswith("dbrx-132b") and "2-stage layer pipeline" in p["config"]["parallelism"]
+    assert p["stage_devices"] == [0, 1] and "handoff_us" in p
+    assert "--pipeline 2" in p["command"] and "--no-cpu" in p["command"]
+    assert "pipeline" not in _bench("--gpus", "2", "--no-pipeline-leg")
+    # a run that is not 256 steps long says so (the driver's 20-step line must not be read as the BASELINE metric)
+    assert "256" in out["steps_note"] and "256" in p["steps_note"]
 
 
 def test_bench_pipeline_mode_is_config_5():

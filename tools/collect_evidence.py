@@ -1,29 +1,32 @@
 #!/usr/bin/env python3
-"""Copy the summaries of the round's evidence session (tools/gpu_final_r03.sh -> gpurun_out/final_<tag>/) into the tracked profiles/
-directory, and build the gf4 counter table before / after from profiles/r02_pmc_gf4_tables.txt and the session's counter pass."""
+"""Copy the summaries of the round's evidence session (tools/gpu_final.sh TAG -> gpurun_out/final_<tag>/) into the tracked profiles/
+directory, and build the gf4 counter table before / after from the previous round's table (profiles/r<NN-1>_pmc_gf4_tables.txt) and
+the session's counter pass.     python tools/collect_evidence.py r04"""
 import os
 import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+prev = f"r{int(tag[1:]) - 1:02d}"
 F = os.path.join(ROOT, "gpurun_out", f"final_{tag}")
 P = os.path.join(ROOT, "profiles")
 for f in (f"{tag}_kernel_stats.md", f"{tag}_kernel_stats.json", f"{tag}_pmc.json"):
-    shutil.copy(os.path.join(F, f), os.path.join(P, f))
+    if os.path.exists(os.path.join(F, f)):
+        shutil.copy(os.path.join(F, f), os.path.join(P, f))
 shutil.copy(os.path.join(F, "kernel_bytes.json"), os.path.join(P, f"{tag}_kernel_bytes.json"))
 line = [l for l in open(os.path.join(F, "bench.json")) if l.startswith("{")][-1]
 open(os.path.join(P, f"{tag}_bench.json"), "w").write(line)
 shutil.copy(os.path.join(F, "other_configs.jsonl"), os.path.join(P, f"{tag}_other_configs_full_size.jsonl"))
 with open(os.path.join(P, f"{tag}_reference_cli_on_hip.txt"), "w") as o:
-    o.write("Round 3: the reference's own CLI (src/run.c, built as oracle/_ref/run_hip against libcalm_hip.so) on the HIP backend, Mistral-7B fp8 shape at full depth\n"
-            "(tools/gpu_final_r03.sh section 4; CALM_POSO shifts the positions: the first and the last 32 positions of a 4096-token context)\n")
+    o.write(f"Round {int(tag[1:])}: the reference's own CLI (src/run.c, built as oracle/_ref/run_hip against libcalm_hip.so) on the HIP backend, Mistral-7B fp8 shape at full depth\n"
+            "(tools/gpu_final.sh section 4; CALM_POSO shifts the positions: the first and the last 32 positions of a 4096-token context)\n")
     for p in (0, 4064):
         o.write(f"-- CALM_POSO={p}\n")
         o.write(open(os.path.join(F, f"cli_poso_{p}.out")).read()[:400] + "\n")
         o.write("".join(open(os.path.join(F, f"cli_poso_{p}.err")).readlines()[-3:]))
 with open(os.path.join(P, f"{tag}_gpu_tests.txt"), "w") as o:
-    o.write("Round 3: pytest -m gpu on the MI355X box (tools/gpu_final_r03.sh section 0)\n")
+    o.write(f"Round {int(tag[1:])}: pytest -m gpu on the MI355X box (tools/gpu_final.sh section 0)\n")
     o.write("".join(open(os.path.join(F, "pytest_gpu.log")).readlines()[-8:]))
     o.write("".join(l for l in open(os.path.join(F, "summary.txt")) if "smoke ok" in l))
 
@@ -40,13 +43,11 @@ def table(lines):
 
 pm = os.path.join(F, "pmc_gf4_tables.txt")
 if os.path.exists(pm):
-    before = open(os.path.join(P, "r02_pmc_gf4_tables.txt")).read().splitlines()
+    before = open(os.path.join(P, f"{prev}_pmc_gf4_tables.txt")).read().splitlines()
     after = open(pm).read().splitlines()
     B, A = table(before), table(after)
-    out = ["Round 3: counters of the gf4 kernels BEFORE (round 2: 4 rows x 2 KiB tiles everywhere, k_ffn_down 2 x 7 KiB, image rows 1 KiB apart) and AFTER",
-           "(tile shape per kernel: k_qkv 2x2, k_attn_out 2x1, k_ffn_up 4x1, k_ffn_down 2x2, k_output 2x2 at up to 4 workgroups per CU; padded image rows;",
-           "RMSNorm's scalar left to the epilogue).  Llama-3-8B gf4 shape.  before: profiles/r02_pmc_gf4_tables.txt (8 layers, tools/tune.py under",
-           "rocprofv3); after: tools/pmc_kernel.sh (full depth, bench.py under rocprofv3 --pmc, three separate passes).  Per launch, averaged over the",
+    out = [f"Round {int(tag[1:])}: counters of the gf4 kernels BEFORE (profiles/{prev}_pmc_gf4_tables.txt, the previous round's kernels) and AFTER (this round's),",
+           "Llama-3-8B gf4 shape at full depth: tools/pmc_kernel.sh (bench.py under rocprofv3 --pmc, three separate passes).  Per launch, averaged over the",
            "launches of the run; SQ_* cycle counters in quad-cycles summed over the waves (MI355X_MICROARCH.md); FETCH_SIZE in its raw unit",
            "(x 64 B x 2 on gfx950 = bytes).", ""]
     cols = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One-shot deep-prefetch probe (tools/exp_mega.hip: k_burst); run on the GPU box."""
+"""One-shot deep-prefetch probe (tools/experiments/exp_mega.hip: k_burst); run on the GPU box."""
 import ctypes as C, os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
 so = os.path.join(here, "libexp_mega.so")

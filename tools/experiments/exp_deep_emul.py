@@ -1,4 +1,4 @@
-"""CPU emulation of tools/exp_overlap.hip: k_deep's coordinator / streamer protocol (one Python thread per wave)."""
+"""CPU emulation of tools/experiments/exp_overlap.hip: k_deep's coordinator / streamer protocol (one Python thread per wave)."""
 import threading, time, math, random, sys
 GRID, STREAMERS, VEC, DEPTH, MAXT = int(sys.argv[1]) if len(sys.argv)>1 else 3, 7, 64, int(sys.argv[2]) if len(sys.argv)>2 else 3, 64
 ntasks = [30, 5, 50, 22, 3, 41, 64, 9]

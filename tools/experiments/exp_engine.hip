@@ -12,7 +12,7 @@
 //     while the loader keeps filling the ring: up to 128 KiB = 5.2 us of the CU's share of the stream per edge.
 // Same arithmetic per task as k_stream / k_mega: the final vector must equal exp_chain's bit for bit.
 //
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_engine.so tools/exp_engine.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/experiments/libexp_engine.so tools/experiments/exp_engine.hip
 #include "exp_overlap.hip"
 
 constexpr int EG_MAXP = 136;

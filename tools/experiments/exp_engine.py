@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Driver of the LDS-DMA loader/consumer engine experiment (tools/exp_engine.hip); run on the GPU box.
+"""Driver of the LDS-DMA loader/consumer engine experiment (tools/experiments/exp_engine.hip); run on the GPU box.
 usage: exp_engine.py [cfg ...]   cfg = NL*100000 + NC*1000 + R*10 + D"""
 import ctypes as C
 import os

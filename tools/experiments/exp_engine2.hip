@@ -16,7 +16,7 @@
 // k_ref_phase computes the same chain with one plain launch per phase over the same granule buffers: the engine's final vector
 // must equal it bit for bit.
 //
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_engine2.so tools/exp_engine2.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/experiments/libexp_engine2.so tools/experiments/exp_engine2.hip
 #include "exp_overlap.hip"
 
 #include <string.h>

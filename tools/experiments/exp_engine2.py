@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Driver of the second-cut LDS-DMA loader/consumer engine (tools/exp_engine2.hip) -- round 3's time-boxed gate; run on the GPU box.
+"""Driver of the second-cut LDS-DMA loader/consumer engine (tools/experiments/exp_engine2.hip) -- round 3's time-boxed gate; run on the GPU box.
 usage: exp_engine2.py [cfg ...] [noedge]     cfg = R * 10 + D (ring slots of 16 KiB, fills in flight)
 Gate: <= 42 us/layer against ~47 for launch-per-kernel on this chain."""
 import ctypes as C

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Loader study for the engine gate (tools/exp_engine2.hip: k_loader_only): the rate at which LDS-DMA alone streams a layer's
+"""Loader study for the engine gate (tools/experiments/exp_engine2.hip: k_loader_only): the rate at which LDS-DMA alone streams a layer's
 weights -- loader waves per CU, fills in flight per wave, slot placement, cache policy -- against the same stream through
 registers.  One persistent launch over 8 layers of the chain's four phases; no consumers, no edges."""
 import ctypes as C

@@ -16,7 +16,7 @@
 //     first is waited for.
 // The arithmetic per task equals k_stream's, so the final vector must match exp_chain's checksum bit for bit.
 //
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_mega.so tools/exp_mega.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/experiments/libexp_mega.so tools/experiments/exp_mega.hip
 #include "exp_overlap.hip"
 #include <algorithm>
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Driver of the second persistent-launch experiment (tools/exp_mega.hip); run on the GPU box.
+"""Driver of the second persistent-launch experiment (tools/experiments/exp_mega.hip); run on the GPU box.
 usage: exp_mega.py [dbg] [cfg ...]   cfg = NS*1000 + NH*100 + DEPTH*10 + SYS"""
 import ctypes as C
 import os

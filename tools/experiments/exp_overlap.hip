@@ -20,7 +20,7 @@
 // it) and reduces it; the epilogue writes the wave's results into the next activation vector.
 // The final activation vector must be bit-identical between the modes.
 //
-// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/libexp_overlap.so tools/exp_overlap.hip
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -o tools/experiments/libexp_overlap.so tools/experiments/exp_overlap.hip
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>

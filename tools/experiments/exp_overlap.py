@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Driver of the kernel-overlap experiment (tools/exp_overlap.hip); run on the GPU box."""
+"""Driver of the kernel-overlap experiment (tools/experiments/exp_overlap.hip); run on the GPU box."""
 import ctypes as C
 import os
 import subprocess

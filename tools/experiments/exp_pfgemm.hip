@@ -1,6 +1,6 @@
 // exp_pfgemm.hip -- the prompt GEMM (calm_amd/csrc/prefill.hip.h: k_pf_gemm) on its own: correctness against a float64 dot
 // product on sampled outputs, and the time per launch, for the shapes of a BASELINE layer.  EXPERIMENT TOOLING, not product.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/exp_pfgemm tools/exp_pfgemm.hip && tools/exp_pfgemm [nb] [iters]
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/experiments/exp_pfgemm tools/experiments/exp_pfgemm.hip && tools/experiments/exp_pfgemm [nb] [iters]
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 #include <math.h>

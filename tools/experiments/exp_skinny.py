@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""T tokens through one weight stream (tools/exp_skinny.hip): a Mistral-7B fp8 layer's matrix shapes, 4 / 8 tokens at once on the
+"""T tokens through one weight stream (tools/experiments/exp_skinny.hip): a Mistral-7B fp8 layer's matrix shapes, 4 / 8 tokens at once on the
 v_mfma_f32_4x4x4_16b_f16 path, against the decode kernels' time for ONE token (tools/tune.py) -- is a multi-token row engine worth
 building for chunks of 3-16 prompt tokens?"""
 import ctypes as C

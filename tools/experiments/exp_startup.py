@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Start-up probe (tools/exp_mega.hip: k_startup): what delays a streaming kernel's first tile?  Run on the GPU box."""
+"""Start-up probe (tools/experiments/exp_mega.hip: k_startup): what delays a streaming kernel's first tile?  Run on the GPU box."""
 import ctypes as C, os, subprocess
 here = os.path.dirname(os.path.abspath(__file__))
 so = os.path.join(here, "libexp_mega.so")

@@ -1,21 +1,70 @@
 #!/bin/bash
-# GPU-box session that refreshes the round's evidence: the default bench line, the rocprofv3 kernel trace of the bench
-# command and its FETCH_SIZE pass (separate run), summarised into profiles/${TAG}_*.
-TAG=${1:-r01}
+# Evidence session on the GPU box (outputs under gpurun_out/final_r03, summaries copied to profiles/ afterwards):
+#  0. the whole GPU test suite as the driver runs it
+#  2. tools/hipprof.sh over the bench command: rocprofv3 kernel trace + the library's algorithmic-byte account + FETCH_SIZE pass
+#     (first: the bench line of section 1 then quotes roofline.traffic / roofline.rocprof from the files this pass stamps)
+#  1. the default bench line (CPU reference timed on the same model, full-depth parity inside)
+#  3. bench lines of the other BASELINE shapes at full size, each WITH its CPU leg and parity (host copy of the model: 46.7 GB for
+#     Mixtral-8x7B, 131.6 GB for DBRX-132B); DBRX also as a 4-stage pipeline in one process (config 5's partitioning on one GPU)
+#  4. the reference CLI on this backend, first 32 / last 32 positions of a 4096 context (CALM_POSO), full 32-layer Mistral shape
+#  5. PMC counters of the gf4 kernels (tools/pmc_kernel.sh)
+#  SECTIONS="1 2 3" selects (default: all)
+TAG=${1:-r04}
+SECTIONS=${SECTIONS:-"0 2 1 3 4 5"}
+want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd "$(dirname "$0")/.."
-echo "== bench" | tee $OUT/summary.txt
+: > $OUT/summary.txt
+if want 0; then
+echo "== 0. pytest -m gpu" | tee -a $OUT/summary.txt
+( time timeout 2400 python -m pytest tests -x -q -m gpu ) > $OUT/pytest_gpu.log 2>&1; echo "exit $?" >> $OUT/summary.txt
+tail -6 $OUT/pytest_gpu.log >> $OUT/summary.txt
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" >> $OUT/summary.txt 2>&1
+fi
+if want 2; then
+echo "== 2. hipprof" | tee -a $OUT/summary.txt
+tools/hipprof.sh -t $TAG -w "mistral-7b fp8" -- python bench.py --no-cpu --no-device-greedy --steps 64 --warmup 8 >> $OUT/summary.txt 2>&1
+cp profiles/${TAG}_kernel_stats.md profiles/${TAG}_kernel_stats.json profiles/${TAG}_pmc.json $OUT/ 2>/dev/null
+cp gpurun_out/$TAG/kernel_bytes.json $OUT/ 2>/dev/null
+fi
+if want 1; then
+echo "== 1. bench" | tee -a $OUT/summary.txt
 ( time timeout 600 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
-tail -c 3200 $OUT/bench.json >> $OUT/summary.txt; tail -6 $OUT/bench.err >> $OUT/summary.txt
-echo "== rocprof kernel trace of the bench command" | tee -a $OUT/summary.txt
-timeout 400 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --no-cpu --no-device-greedy --steps 64 --warmup 8 > $OUT/prof_bench.log 2>&1
-echo "exit $?" >> $OUT/summary.txt
-echo "== rocprof PMC pass (FETCH_SIZE), its own run" | tee -a $OUT/summary.txt
-timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc -o fetch -- python bench.py --no-cpu --no-device-greedy --steps 8 --warmup 2 > $OUT/prof_pmc.log 2>&1
-echo "exit $?" >> $OUT/summary.txt
-python tools/prof_summary.py $OUT/prof $OUT/pmc --tag $TAG >> $OUT/summary.txt 2>&1
-mkdir -p $OUT/profiles && cp profiles/${TAG}_kernel_stats.md profiles/${TAG}_pmc.json $OUT/profiles/ 2>/dev/null
-find $OUT/prof $OUT/pmc -type f -size +20M -delete 2>/dev/null
+tail -c 3800 $OUT/bench.json >> $OUT/summary.txt; tail -4 $OUT/bench.err >> $OUT/summary.txt
+fi
+if want 3; then
+echo "== 3. other shapes at full size, CPU leg and parity included" | tee -a $OUT/summary.txt
+rm -f $OUT/other_configs.jsonl
+for cfg in "llama-3-8b gf4" "tinyllama-1.1b fp16" "mixtral-8x7b fp8" "dbrx-132b fp8"; do
+  set -- $cfg
+  timeout 900 python bench.py --model $1 --dtype $2 --steps 128 >> $OUT/other_configs.jsonl 2>> $OUT/other.err; echo "$cfg exit $?" >> $OUT/summary.txt
+done
+timeout 900 python bench.py --gpus 4 --pipeline --no-cpu --steps 128 >> $OUT/other_configs.jsonl 2>> $OUT/other.err; echo "dbrx pipeline 4 exit $?" >> $OUT/summary.txt
+python - >> $OUT/summary.txt <<PY
+import json
+for l in open("$OUT/other_configs.jsonl"):
+    d = json.loads(l)
+    print(d["config"]["workload"][:34], "|", d["config"]["parallelism"][:34], "|", d["value"], "tok/s", d["achieved_GBps"], "GB/s", d["hbm_frac_of_spec"], "| cpu", (d.get("cpu_baseline") or {}).get("value"),
+          "| parity", (d.get("parity") or {}).get("max_rel_err"), (d.get("parity") or {}).get("greedy_identical"), "| load", d["load_seconds"], "s")
+PY
+fi
+if want 4; then
+echo "== 4. reference CLI on the HIP backend: first / last 32 positions of a 4096 context" | tee -a $OUT/summary.txt
+if [ -x oracle/_ref/run_hip ]; then
+  python -m calm_amd.calmfile mistral-7b fp8 /tmp/mistral7b_fp8.calm >> $OUT/summary.txt 2>&1
+  for poso in 0 4064; do
+    echo "-- CALM_POSO=$poso" >> $OUT/summary.txt
+    CALM_POSO=$poso timeout 300 oracle/_ref/run_hip /tmp/mistral7b_fp8.calm -i "abc" -t 0 -n 32 > $OUT/cli_poso_$poso.out 2> $OUT/cli_poso_$poso.err
+    head -c 300 $OUT/cli_poso_$poso.out | head -2 >> $OUT/summary.txt; tail -2 $OUT/cli_poso_$poso.err >> $OUT/summary.txt
+  done
+  rm -f /tmp/mistral7b_fp8.calm
+fi
+fi
+if want 5; then
+echo "== 5. counters of the gf4 kernels (Llama-3-8B shape, full depth; three separate passes)" | tee -a $OUT/summary.txt
+bash tools/pmc_kernel.sh ${TAG}_pmc_gf4 llama-3-8b gf4 > $OUT/pmc_gf4.log 2>&1
+cp gpurun_out/${TAG}_pmc_gf4/summary.txt $OUT/pmc_gf4_tables.txt 2>/dev/null; tail -12 $OUT/pmc_gf4_tables.txt | cut -c1-400 >> $OUT/summary.txt
+fi
 cat $OUT/summary.txt
