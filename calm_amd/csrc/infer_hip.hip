@@ -91,6 +91,8 @@ int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the mat
 int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_moe_route = 1;   // mixture-of-experts models: the router's logits from partial sums k_attn_out's epilogue leaves (k_ffn_up MOE == 2); 0: every
                        // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
+int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every active expert's hidden vector in LDS and streams their rows as one task
+                       // stream (kernels.hip.h k_ffn_down SEG) where all images together stay under 96 KiB; 0: one pass per expert
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -580,6 +582,13 @@ int ffn_down_cols(int hidden) {
 	return (per + unit - 1) / unit * unit;
 }
 
+// k_ffn_down with all active experts' images side by side (SEG)?  Only where they are small -- the premise of that form: OLMoE's
+// eight 4-KiB vectors, not Mixtral's two of 57 KiB (measured slower there, profiles/r04_moe.txt) -- and hidden_dim is one column range
+template <int DB>
+bool ffn_down_segs(const Ctx* c, int kn) {
+	return g_down_seg && c->n_active > 1 && kn == c->hidden && (size_t)c->n_active * xs_slots<DB>(kn) * 16 <= 96 * 1024;
+}
+
 template <int DB>
 void launch_ffn_down(Ctx* c, int l) {
 	constexpr int BLOCK = 512;
@@ -595,25 +604,48 @@ void launch_ffn_down(Ctx* c, int l) {
 		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : (few_rows ? 1 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0));
 		int ntasks = c->dim / (uo == 1 ? 1 : (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
-		size_t lds = lds_bytes<DB>(kn);
+		const bool segs = ffn_down_segs<DB>(c, kn);
+		size_t lds = segs ? (size_t)c->n_active * xs_slots<DB>(kn) * 16 + LDS_EXTRA : lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
 			hipLaunchKernelGGL(kern, grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
 			                   c->hidden, c->n_active, k0, kn);
 		};
+		if (segs) {
+			// small images: the 4-register staging form.  Steps of the largest of 4 / 2 / 1 chunks that divides a segment's chunk
+			// count (a segment is walked in whole steps: OLMoE's 1-KiB rows in steps of 4 asked for 4 KiB per KiB used), one row
+			// per task by the same rule as the dense form
+			const bool full = rows_full<DB>(kn), one = few_rows;
+			const int cpi = (kn / (128 / DB) + 63) / 64, u = cpi % 4 == 0 ? 4 : (cpi % 2 == 0 ? 2 : 1);
+			ntasks = c->dim / (one ? 1 : 2);
+			grid = dim3(pick_blocks(ntasks, BLOCK / 64));
+			auto pick = [&](auto FULLc, auto ONEc) {
+				constexpr bool F = decltype(FULLc)::value;
+				constexpr int O = decltype(ONEc)::value ? 8 : 0;
+				if (u == 4) {
+					go(k_ffn_down<DB, BLOCK, 4, 4 + O, F, true>);
+				} else if (u == 2) {
+					go(k_ffn_down<DB, BLOCK, 4, 2 + O, F, true>);
+				} else {
+					go(k_ffn_down<DB, BLOCK, 4, 1 + O, F, true>);
+				}
+			};
+			by_bool(full, [&](auto FULLc) { by_bool(one, [&](auto ONEc) { pick(FULLc, ONEc); }); });
+			continue;
+		}
 		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
 			constexpr int V = decltype(V4)::value ? 4 : 8;
 			if (uo == 7) {
-				go(k_ffn_down<DB, BLOCK, V, 7, true>);
+				go(k_ffn_down<DB, BLOCK, V, 7, true, false>);
 			} else if (uo == 1 && rows_full<DB>(kn)) {
-				go(k_ffn_down<DB, BLOCK, V, 1, true>);
+				go(k_ffn_down<DB, BLOCK, V, 1, true, false>);
 			} else if (uo == 1) {
-				go(k_ffn_down<DB, BLOCK, V, 1, false>);
+				go(k_ffn_down<DB, BLOCK, V, 1, false, false>);
 			} else if (uo == 2) {
-				go(k_ffn_down<DB, BLOCK, V, 2, true>);
+				go(k_ffn_down<DB, BLOCK, V, 2, true, false>);
 			} else if (rows_full<DB>(kn)) {
-				go(k_ffn_down<DB, BLOCK, V, 0, true>);
+				go(k_ffn_down<DB, BLOCK, V, 0, true, false>);
 			} else {
-				go(k_ffn_down<DB, BLOCK, V, 0, false>);
+				go(k_ffn_down<DB, BLOCK, V, 0, false, false>);
 			}
 		});
 	}
@@ -1239,10 +1271,19 @@ void set_lds_attrs(Ctx* c) {
 		const size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
 		auto all = [&](auto V) {
 			constexpr int v = decltype(V)::value;
-			allow_lds(k_ffn_down<DB, 512, v, 7, true>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true>, big);
-			allow_lds(k_ffn_down<DB, 512, v, 1, false>, big), allow_lds(k_ffn_down<DB, 512, v, 0, true>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false>, big);
+			allow_lds(k_ffn_down<DB, 512, v, 7, true, false>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true, false>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true, false>, big);
+			allow_lds(k_ffn_down<DB, 512, v, 1, false, false>, big), allow_lds(k_ffn_down<DB, 512, v, 0, true, false>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false, false>, big);
 		};
 		all(std::integral_constant<int, 4>()), all(std::integral_constant<int, 8>());
+		if (c->n_active > 1) { // the side-by-side form (ffn_down_segs): at most 96 KiB + the scratch behind it
+			const size_t sb = 96 * 1024 + LDS_EXTRA;
+			auto seg_all = [&](auto UOc) {
+				constexpr int uo = decltype(UOc)::value;
+				allow_lds(k_ffn_down<DB, 512, 4, uo, true, true>, sb), allow_lds(k_ffn_down<DB, 512, 4, uo, false, true>, sb);
+			};
+			seg_all(std::integral_constant<int, 1>()), seg_all(std::integral_constant<int, 2>()), seg_all(std::integral_constant<int, 4>());
+			seg_all(std::integral_constant<int, 9>()), seg_all(std::integral_constant<int, 10>()), seg_all(std::integral_constant<int, 12>());
+		}
 		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
 		if (d > 48 * 1024) {
 			allow_lds(k_qkv<DB, 16, 8, true, false>, d), allow_lds(k_qkv<DB, 16, 8, false, false>, d), allow_lds(k_qkv<DB, 8, 8, true, false>, d), allow_lds(k_qkv<DB, 8, 8, false, false>, d);
@@ -1299,10 +1340,13 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_qkv_half;
 	} else if (!strcmp(key, "down_one")) {
 		slot = &g_down_one;
+
 	} else if (!strcmp(key, "out_one")) {
 		slot = &g_out_one;
 	} else if (!strcmp(key, "moe_route")) {
 		slot = &g_moe_route;
+	} else if (!strcmp(key, "down_seg")) {
+		slot = &g_down_seg;
 
 
 	} else if (!strcmp(key, "pf_wide")) {

@@ -79,8 +79,6 @@ struct Fmt {
 	static constexpr int PAD = 8 / F4;
 	static constexpr int ROW = 64 + PAD;
 	static constexpr int CS = ROW * (F4 + (DB == 4 ? 1 : 0));
-	// what a finished row sum of dot16<DB> is still to be multiplied by (gf4: see dot16<4>; a power of two, exact)
-	static constexpr float POST = DB == 4 ? -4194304.0f : 1.0f;
 };
 
 __device__ __forceinline__ int lane_id() {
@@ -242,16 +240,17 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		acc += acc_b;
 	} else {
 		// gf4: word = 8-bit e5m2 scale S + 8 x 3-bit codes, w_k = (q_k - 4) * S / -4   (src/infer.c:37-40)
-		//   sum_k w_k x_k = (-S/4) * sum_k (q_k - 4) x_k
+		//   sum_k w_k x_k = (-S/4) * sum_k q_k x_k + S * sum_k x_k
 		// The codes are never converted.  A 3-bit field anywhere in the mantissa of a binary16 half, everything
 		// else masked off, IS the subnormal q * 2^(a-24), and v_fma_mix_f32 multiplies a half by an fp32
 		// activation into an fp32 accumulator in one instruction; the LDS image carries x_k * 2^-a per column
 		// (exact), so the product is q x 2^-24 whatever a is.  One rotation of the word puts c5 c6 c7 into the
 		// mantissa of the low half and c0 c1 c2 into that of the high half, so three ANDs isolate six codes;
-		// c3 and c4 already sit in the high half's mantissa of the word itself.  The chain of a word STARTS from
-		// -2^-22 sum_k x_k, which the image carries precomputed per word (float4 #8), so it ends as 2^-24 sum_k (q_k - 4) x_k and
-		// one multiply-add by S files it: 1 conversion + 6 integer ops + 8 fma_mix + 1 fma per 8 weights; the common factor
-		// -2^22 = (-1/4) 2^24 is applied once per row (Fmt<4>::POST, run_rows_impl).
+		// c3 and c4 already sit in the high half's mantissa of the word itself: 6 integer ops + 8 fma_mix per
+		// 8 weights, and the activation sum of the word comes precomputed from the image (float4 #8).
+		// (Round 4: the chain started FROM -2^-22 x that sum, one multiply-add fewer per word and the factor -2^22 applied once per row,
+		// measured the same to the tenth of a microsecond on every gf4 kernel -- profiles/r04_gf4.txt: the kernels are not bound by
+		// their VALU count.  Not kept.)
 		f32x4 xv[4][2];
 		unsigned m[4][5];
 		float t[4], S[4];
@@ -274,7 +273,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		// One chain per word; the four words' chains are interleaved code-major for ILP.
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			t[j] = fma_mix_hi(m[j][0], xv[j][0][0], xsum[j]);
+			t[j] = mul_mix_hi(m[j][0], xv[j][0][0]);
 		}
 #pragma unroll
 		for (int k = 1; k < 8; ++k) {
@@ -286,7 +285,8 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		}
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
-			acc[0] = fmaf(S[j], t[j], acc[0]);
+			// (-S/4) * 2^24 * t + S * xsum  =  S * (xsum - 2^22 t): two fmas on one chain
+			acc[0] = fmaf(S[j], fmaf(t[j], -4194304.0f, xsum[j]), acc[0]);
 		}
 	}
 	return acc;
@@ -298,7 +298,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 // 4p..4p+3) belongs to chunk p / (16G), lane (p % 16G) / F4, sub-index i = p % F4 and is stored at
 // float4 slot chunk*CS + i*ROW + lane (Fmt<DB>: ROW = 64 + PAD): a wave reading "its float4 #i" hits 64 consecutive slots.
 // gf4 only: the image holds x_k * 2^-a(k % 8), a = {1,4,7,1,4,0,3,6} (dot16<4> multiplies by codes that
-// sit 2^a too high), and slot chunk*CS + 8*ROW + lane holds -2^-22 x the four (unscaled) 8-column sums of the lane.
+// sit 2^a too high), and slot chunk*CS + 8*ROW + lane holds the four UNSCALED 8-column sums of the lane.
 template <int DB>
 __device__ __forceinline__ int swz4(int p) {
 	constexpr int G = Fmt<DB>::G, F4 = Fmt<DB>::F4;
@@ -317,7 +317,7 @@ __host__ __device__ constexpr int xs_slots(int n) {
 	return ((n + 64 * Fmt<DB>::G - 1) / (64 * Fmt<DB>::G)) * Fmt<DB>::CS;
 }
 
-// gf4: write float4 p of the image (scaled per column) and, from the even p of a pair, -2^-22 x the pair's unscaled sum.
+// gf4: write float4 p of the image (scaled per column) and, from the even p of a pair, the pair's unscaled sum.
 // Lanes p and p^1 are adjacent threads (p = tid + i * BLOCK, BLOCK even) and are active together (n % 32 == 0).
 __device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
 	float s = (t.x + t.y) + (t.z + t.w);
@@ -330,7 +330,7 @@ __device__ __forceinline__ void stage_store_gf4(float4* xs4, int p, float4 t) {
 	xs4[swz4<4>(p)] = t;
 	if (!odd) {
 		const int chunk = p / 512, r = p % 512; // 512 logical float4 per gf4 chunk; lane r / 8, word (r % 8) / 2
-		((float*)&xs4[chunk * Fmt<4>::CS + 8 * Fmt<4>::ROW + r / 8])[(r % 8) >> 1] = s * -2.384185791015625e-07f; // -2^-22 (dot16<4>: where a word's chain starts)
+		((float*)&xs4[chunk * Fmt<4>::CS + 8 * Fmt<4>::ROW + r / 8])[(r % 8) >> 1] = s;
 	}
 }
 
@@ -571,11 +571,24 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // register tiles alternate through a 2x-unrolled loop body so all tile indices are compile-time.
 // aux_of(t, aux) may issue small loads the epilogue needs (residual value, RoPE pair); it runs before the
 // task's last multiply-add so that latency hides behind it.  epi(t, acc, aux): sums valid in lane RED_LANE.
-template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
-__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+//
+// SEGS (k_ffn_down of a mixture of MANY SMALL experts): a task's "row" is the CONCATENATION of `segs` rows of n columns each -- the
+// same output row of several experts' matrices, each against its own expert's hidden vector, all of them side by side in LDS -- so
+// that one uninterrupted tile stream covers all of them (one pass per expert pays a whole kernel start-up each time: OLMoE's eight
+// 2048 x 1024 matrices took 21.6 us for 16.8 MB, profiles/r04_shape_sweep.txt; where the images are large -- Mixtral's 57 KB, DBRX's
+// 43 KB -- the longer prologue costs more than the restarts: profiles/r04_moe.txt, and the launcher keeps one pass per expert).  rows_of(t, seg, rows)
+// names segment seg's rows; segment seg's image starts seg * (chunks of n) * CS slots into xs4; every segment is walked in whole
+// steps (its last step's surplus chunks clamp into the row, as they do at the end of any row); at the end of EVERY segment the
+// sums are reduced and handed to epi(t, seg, acc, aux), which keeps the running value -- the experts are added in rank order by
+// the same lane, exactly as with one pass per expert.  aux_of runs before segment 0's last multiply-add.
+template <int DB, int NR, int U, bool FULL, bool SEGS, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+__device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                               StageFn stage, AuxFn aux_of, EpiFn epi) {
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
+	const int cpi = (nl + 63) >> 6;           // chunks of one segment's row (and of its image)
+	const int cps = (cpi + U - 1) / U * U;    // ... walked in whole steps
+	const int ksteps = SEGS ? segs * cps : 0; // chunk positions of a task
 	const unsigned char* rows[2][NR];
 	Tile<NR, U> tile[2];
 	f32x2 acc2[NR];
@@ -591,15 +604,20 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	// compiler's vmcnt bookkeeping is exact and every wait is "the tile two issues ago".
 	auto advance = [&](int& t, int& k0, bool& live) { // -> the step after (t, k0)
 		k0 += U;
-		if (k0 * 64 >= nl) {
+		if (SEGS ? k0 >= ksteps : k0 * 64 >= nl) {
 			k0 = 0;
 			t += stride;
 			live = live && t < ntasks;
 		}
 	};
+	auto seg_start = [&](int k0) { return SEGS ? k0 % cps == 0 : k0 == 0; }; // (t, k0) opens a row (SEGS: a segment)
 	auto issue = [&](int ph, int t, int k0, bool live) {
-		if (k0 == 0 || !live) {
-			rows_of(min(t, ntasks - 1), rows[ph]);
+		if (seg_start(k0) || !live) {
+			if constexpr (SEGS) {
+				rows_of(min(t, ntasks - 1), live ? k0 / cps : 0, rows[ph]);
+			} else {
+				rows_of(min(t, ntasks - 1), rows[ph]);
+			}
 		}
 		if (!live) {
 #pragma unroll
@@ -607,7 +625,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 				rows[ph][r] = (const unsigned char*)dummy;
 			}
 		}
-		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? k0 : 0, nl, lane);
+		tile_load<DB, NR, U, FULL>(tile[ph], rows[ph], live ? (SEGS ? k0 % cps : k0) : 0, nl, lane);
 	};
 
 #ifdef CALM_TIMELINE
@@ -640,7 +658,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	bool live1 = live;
 	issue(0, t, 0, live);
 	advance(t1, k1, live1);
-	if (k1 != 0) { // same task, next k-offset: same rows
+	if (!seg_start(k1)) { // same task (and segment), next k-offset: same rows
 #pragma unroll
 		for (int r = 0; r < NR; ++r) {
 			rows[1][r] = rows[0][r];
@@ -665,11 +683,12 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 #pragma unroll
 		for (int ph = 0; ph < 2; ++ph) {
 			// (t, k0) lives in tile[ph]; (t1, k1) in tile[ph ^ 1]
-			const bool last_k = (k0 + U) * 64 >= nl;
-			if (last_k) {
+			const int seg = SEGS ? k0 / cps : 0, kl = SEGS ? k0 - seg * cps : k0; // segment, chunk offset inside it
+			const bool last_k = SEGS ? kl + U >= cps : (k0 + U) * 64 >= nl;          // the row's (segment's) last step
+			if (last_k && seg == 0) {
 				aux_of(t, aux);
 			}
-			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, xs4, k0, nl, lane);
+			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, SEGS ? xs4 + seg * cpi * Fmt<DB>::CS : xs4, kl, nl, lane);
 #ifdef CALM_TIMELINE
 			if (tl[2] == 0) {
 				asm volatile("" ::"v"(acc2[0][0]));
@@ -679,7 +698,7 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 			int t2 = t1, k2 = k1;
 			bool live2 = live1;
 			advance(t2, k2, live2);
-			if (k2 != 0 && live2) { // continues the task of step s+1: same rows
+			if (!seg_start(k2) && live2) { // continues the row of step s+1: same rows
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
 					rows[ph][r] = rows[ph ^ 1][r];
@@ -689,10 +708,14 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 			if (last_k) {
 #pragma unroll
 				for (int r = 0; r < NR; ++r) {
-					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]) * Fmt<DB>::POST; // valid in lane RED_LANE
+					acc[r] = wave_sum63(acc2[r][0] + acc2[r][1]); // valid in lane RED_LANE
 					acc2[r] = (f32x2){0.f, 0.f};
 				}
-				epi(t, acc, aux);
+				if constexpr (SEGS) {
+					epi(t, seg, acc, aux);
+				} else {
+					epi(t, acc, aux);
+				}
 			}
 			if (!live1) {
 #ifdef CALM_TIMELINE
@@ -712,7 +735,13 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                          StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL>(ntasks, first, stride, n, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+	run_rows_impl<DB, NR, U, FULL, false>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+}
+// ... over rows of `segs` segments of n columns each (run_rows_impl: SEGS)
+template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+__device__ __forceinline__ void run_rows_segs(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
+                                              StageFn stage, AuxFn aux_of, EpiFn epi) {
+	run_rows_impl<DB, NR, U, FULL, true>(ntasks, first, stride, n, segs, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
 // Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
@@ -2030,36 +2059,47 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		const int ne = n_experts & 0xff, cols = n_experts >> 8, nq = ne + 2;
 		const float* part = (const float*)moegate;
 		stage_load<WG_THREADS>(sr, x, norm_w);
-		constexpr int QB = 5, C4 = GATE_COLS / 256; // quantities per wave and batch, float4s per lane and quantity
-		for (int qb = 0; qb < nq; qb += WG_WAVES * QB) {
-			float4 v[QB][C4];
+		// quantities per wave and batch x float4s per lane and quantity: up to 20 loads in flight per lane whichever way -- few live
+		// columns (a small model's k_attn_out grid) leave room for more quantities per round trip (64 experts: 17 per wave)
+		auto fold = [&](auto QBc, auto C4c) {
+			constexpr int QB = decltype(QBc)::value, C4 = decltype(C4c)::value;
+			for (int qb = 0; qb < nq; qb += WG_WAVES * QB) {
+				float4 v[QB][C4];
 #pragma unroll
-			for (int j = 0; j < QB; ++j) {
-				const int q = qb + wave + WG_WAVES * j;
-#pragma unroll
-				for (int i = 0; i < C4; ++i) {
-					v[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-					if (q < nq && i * 256 < cols) { // wave-uniform
-						v[j][i] = *((const float4*)(part + (size_t)q * GATE_COLS) + i * 64 + lane);
-					}
-				}
-			}
-#pragma unroll
-			for (int j = 0; j < QB; ++j) {
-				const int q = qb + wave + WG_WAVES * j;
-				if (q < nq) { // wave-uniform
-					float s_ = 0.f;
+				for (int j = 0; j < QB; ++j) {
+					const int q = qb + wave + WG_WAVES * j;
 #pragma unroll
 					for (int i = 0; i < C4; ++i) {
-						const int c0 = i * 256 + lane * 4;
-						s_ += (c0 < cols ? v[j][i].x : 0.f) + (c0 + 1 < cols ? v[j][i].y : 0.f) + (c0 + 2 < cols ? v[j][i].z : 0.f) + (c0 + 3 < cols ? v[j][i].w : 0.f);
+						v[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+						if (q < nq && i * 256 < cols) { // wave-uniform
+							v[j][i] = *((const float4*)(part + (size_t)q * GATE_COLS) + i * 64 + lane);
+						}
 					}
-					s_ = wave_sum63(s_);
-					if (lane == RED_LANE) {
-						gate[q] = s_;
+				}
+#pragma unroll
+				for (int j = 0; j < QB; ++j) {
+					const int q = qb + wave + WG_WAVES * j;
+					if (q < nq) { // wave-uniform
+						float s_ = 0.f;
+#pragma unroll
+						for (int i = 0; i < C4; ++i) {
+							const int c0 = i * 256 + lane * 4;
+							s_ += (c0 < cols ? v[j][i].x : 0.f) + (c0 + 1 < cols ? v[j][i].y : 0.f) + (c0 + 2 < cols ? v[j][i].z : 0.f) + (c0 + 3 < cols ? v[j][i].w : 0.f);
+						}
+						s_ = wave_sum63(s_);
+						if (lane == RED_LANE) {
+							gate[q] = s_;
+						}
 					}
 				}
 			}
+		};
+		if (cols <= 256) {
+			fold(std::integral_constant<int, 17>(), std::integral_constant<int, 1>());
+		} else if (cols <= 512) {
+			fold(std::integral_constant<int, 9>(), std::integral_constant<int, 2>());
+		} else {
+			fold(std::integral_constant<int, 5>(), std::integral_constant<int, GATE_COLS / 256>());
 		}
 		__syncthreads();
 		{
@@ -2114,7 +2154,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 			}
 			acc2 = dot16<DB>(w, (const f32x4*)xs4 + k * Fmt<DB>::CS + lane, acc2);
 			if (k == chunks - 1) {
-				const float logit = wave_sum63(acc2[0] + acc2[1]) * (nscale * Fmt<DB>::POST);
+				const float logit = wave_sum63(acc2[0] + acc2[1]) * nscale;
 				if (lane == RED_LANE && e < n_experts) {
 					gate[e] = logit;
 				}
@@ -2159,19 +2199,83 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 // row the concatenation of the experts' rows (Mixtral 22.4 against 21.5 us, DBRX 51 against 49: the longer prologue costs more than
 // the restart it saves), and one tile stream across the expert boundary with the image swapped in-stream behind a barrier (22.2 / 58:
 // the swap's loads go out only after the slowest wave has arrived, where a restart's go out as each wave finishes).)
-template <int DB, int BLOCK, int V, int UO, bool FULL>
+// SEG (mixtures of many small experts; the launcher decides, ffn_down_segs): ALL active experts' hidden vectors side by side in LDS
+// and a task = the same output rows of every active expert, one tile stream (run_rows_impl SEGS).  The epilogue adds expert after
+// expert in rank order through one lane: bit-identical to the one-pass-per-expert form.  Lane s of every wave holds rank s's
+// expert id and weight (n_active <= 64); a segment's are broadcast from there (v_readlane), no memory access on the way.
+template <int DB, int BLOCK, int V, int UO, bool FULL, bool SEG>
 __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, const void* w2, const float* moe_w, const int* moe_e, int dim, int hidden,
                                                     int n_active, int k0, int kn) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// UO: tiles of 2 rows x UO chunks instead of the format's shape; UO = 1: ONE row x 4 chunks, for matrices of fewer row pairs than
 	// the chip has waves (TinyLlama's 2048 rows: 7.9 -> 6.6 us)
-	constexpr int NR = UO == 1 ? 1 : (UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR), U = UO == 1 ? 4 : (UO ? UO : KShape<DB, KS_FFN_DOWN>::U);
+	// (Round 4: ONE row x 11 chunks for DBRX's ragged 10.5-KiB rows -- one exact step instead of 4 + 4 + 3 and a clamped surplus load --
+	// measured 51 us against 49: profiles/r04_moe.txt.)
+	// SEG: UO = chunks per step (1 / 2 / 4: the largest that divides a segment's chunk count -- a segment is walked in whole steps)
+	// + 8 for ONE row per task
+	constexpr int NR = SEG ? ((UO & 8) ? 1 : 2) : (UO == 1 ? 1 : (UO ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
+	constexpr int U = SEG ? (UO & 7) : (UO == 1 ? 4 : (UO ? UO : KShape<DB, KS_FFN_DOWN>::U));
 	constexpr int NW = BLOCK / 64;
 	float4* xs4 = (float4*)smem;
-	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	const size_t row_bytes = (size_t)hidden * DB / 8;
 	const int lane = lane_id();
 	const int nact = n_active > 0 ? n_active : 1;
+	if constexpr (SEG) {
+		const int seg_slots = xs_slots<DB>(kn); // float4 slots of one expert's image
+		float* red = (float*)(xs4 + nact * seg_slots);
+		const int my_e = moe_e[min(lane, nact - 1)];
+		const float my_w = moe_w[min(lane, nact - 1)];
+		const unsigned char* const wcol = (const unsigned char*)w2 + (size_t)k0 * DB / 8;
+		const size_t expert_bytes = (size_t)dim * row_bytes;
+		auto rows_of = [&](int t, int seg, const unsigned char*(&rows)[NR]) {
+			const unsigned char* base = wcol + (size_t)__builtin_amdgcn_readlane(my_e, seg) * expert_bytes;
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				rows[r] = base + (size_t)(t * NR + r) * row_bytes;
+			}
+		};
+		// FULL (whole-chunk vectors): the experts' images side by side ARE the image of the concatenated vector he[0 .. nact) -- one
+		// staging pass for all of them, its loads ahead of the first tiles like any dense kernel's.  Ragged vectors: the first
+		// expert's goes out ahead of the tiles, the others are staged one after the other behind them.
+		StageRegs<V, false> sr;
+		auto pre = [&]() { stage_load<BLOCK>(sr, he + k0, nullptr); stage_first_barrier(); };
+		auto stage = [&]() {
+			if constexpr (FULL) {
+				stage_finish<DB, BLOCK>(sr, xs4, red, he + k0, nullptr, nact * kn, 0.f, false, nullptr); // (launcher: k0 == 0, kn == hidden)
+			} else {
+				stage_finish<DB, BLOCK>(sr, xs4, red, he + k0, nullptr, kn, 0.f, false, nullptr);
+				for (int s_ = 1; s_ < nact; ++s_) {
+					const float* hk = he + (size_t)s_ * hidden + k0;
+					StageRegs<V, false> s2;
+					stage_load<BLOCK>(s2, hk, nullptr);
+					stage_finish<DB, BLOCK>(s2, xs4 + s_ * seg_slots, red, hk, nullptr, kn, 0.f, false, nullptr);
+				}
+			}
+		};
+		auto aux_of = [&](int t, float(&aux)[NR]) { // residual so far
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				aux[r] = x[t * NR + r];
+			}
+		};
+		float carry[NR]; // the task's running value between its segments (meaningful in lane RED_LANE)
+		auto epi = [&](int t, int seg, float(&acc)[NR], float(&aux)[NR]) {
+			const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_w), seg));
+#pragma unroll
+			for (int r = 0; r < NR; ++r) {
+				carry[r] = (seg == 0 ? aux[r] : carry[r]) + acc[r] * w;
+			}
+			if (seg == nact - 1 && lane == RED_LANE) {
+#pragma unroll
+				for (int r = 0; r < NR; ++r) {
+					x[t * NR + r] = carry[r];
+				}
+			}
+		};
+		run_rows_segs<DB, NR, U, FULL>(dim / NR, blockIdx.x * NW + wave_id(), gridDim.x * NW, kn, nact, xs4, he, rows_of, pre, stage, aux_of, epi);
+		return;
+	}
+	float* red = (float*)(xs4 + xs_slots<DB>(kn));
 	for (int k = 0; k < nact; ++k) {
 		const float wk = moe_w[k];
 		const unsigned char* wbase = (const unsigned char*)w2 + (size_t)moe_e[k] * dim * row_bytes + (size_t)k0 * DB / 8;

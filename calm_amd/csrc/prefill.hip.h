@@ -67,7 +67,9 @@ __device__ unsigned* calm_pf_range_ptr;
 // raise the model's range flag (calm_pf_range_ptr), which sends the prompt back through the serial path.
 __device__ __forceinline__ void pf_split2(float a, float b, unsigned& hi, unsigned& lo) {
 	if (!(fabsf(a) <= 65504.f) || !(fabsf(b) <= 65504.f)) { // also true for NaN
-		*calm_pf_range_ptr = 1u;
+		if (calm_pf_range_ptr) { // (null only for kernels launched outside prefill_impl: the unit-test hooks)
+			*calm_pf_range_ptr = 1u;
+		}
 	}
 	a = a > 65504.f ? 65504.f : (a < -65504.f ? -65504.f : a);
 	b = b > 65504.f ? 65504.f : (b < -65504.f ? -65504.f : b);

@@ -193,16 +193,23 @@ def test_transposed_value_cache_catches_up_when_a_sequence_crosses_the_split_thr
                 hiplib.prefill_hip(C.byref(hip.t), arr, start, 0)
                 for pos in range(start):
                     ref.forward(toks[pos], pos, FF)
-            worst = 0.0
+            errs = {}
             for pos in range(start, len(toks)):
                 if pos in check:
                     lr, lg = ref.forward(toks[pos], pos, 0), hip.forward(toks[pos], pos, 0)
                     assert np.isfinite(lg).all(), pos
-                    worst = max(worst, rel_err(lg, lr))
+                    errs[pos] = rel_err(lg, lr)
                 else:
                     ref.forward(toks[pos], pos, FF)
                     hip.forward(toks[pos], pos, FF)
-            assert worst < LOGIT_TOL, (rnd, worst)
+            # an e5m2 cache: an fp32 sum that differs in its last bits now and then lands on the other side of a rounding boundary,
+            # one code of a 2-bit mantissa apart (test_fp8_kv_cache_matches_the_oracle) -- the logits then differ by ~1e-3 on this
+            # 2-layer model whichever attention kernel reads the row; what matters here is that nothing changes at the threshold
+            tol = LOGIT_TOL if kvbits == 16 else 2.5 * LOGIT_TOL
+            assert max(errs.values()) < tol, (rnd, errs)
+            before = max(e for p_, e in errs.items() if p_ <= 383)
+            after = max(e for p_, e in errs.items() if p_ > 383)
+            assert after < max(4 * before, LOGIT_TOL), (rnd, errs)
     finally:
         hip.close()
         ref.close()

@@ -14,7 +14,7 @@ knob = sys.argv[1].encode()
 name = sys.argv[2] if len(sys.argv) > 2 else "mistral-7b"
 dtype = sys.argv[3] if len(sys.argv) > 3 else "fp8"
 L = int(sys.argv[4]) if len(sys.argv) > 4 else 8
-spec = cf.SPECS[name]
+spec = cf.SPECS.get(name) or cf.ARCH_SPECS[name]
 lib = load_lib()
 model = HostModel(cf.stub_tensors(spec, dtype, L), cf.dataclasses.replace(spec, n_layers=L).metadata(dtype))
 be = HipBackend(model, device_synth=(spec, dtype, 1, L))

@@ -15,7 +15,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "mistral-7b"
 dtype = sys.argv[2] if len(sys.argv) > 2 else "fp8"
 L = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 brief = len(sys.argv) > 4
-spec = cf.SPECS[name]
+spec = cf.SPECS.get(name) or cf.ARCH_SPECS[name]
 lib = load_lib()
 for kv_ in os.environ.get("KNOBS", "").split():  # e.g. KNOBS="down_u4=0 attn_waves=8"
     key, val = kv_.split("=")
