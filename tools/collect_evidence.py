@@ -31,6 +31,11 @@ with open(os.path.join(P, f"{tag}_gpu_tests.txt"), "w") as o:
     o.write("".join(l for l in open(os.path.join(F, "summary.txt")) if "smoke ok" in l))
 
 
+for src, dst in (("long_context.txt", f"{tag}_long_context_table.txt"), ("shape_sweep.txt", f"{tag}_shape_sweep.txt")):
+    if os.path.exists(os.path.join(F, src)):
+        shutil.copy(os.path.join(F, src), os.path.join(P, dst))
+
+
 def table(lines):
     d = {}
     h = [l for l in lines if l.startswith("kernel |")][0].split(" | ")

@@ -8,9 +8,11 @@
 #     Mixtral-8x7B, 131.6 GB for DBRX-132B); DBRX also as a 4-stage pipeline in one process (config 5's partitioning on one GPU)
 #  4. the reference CLI on this backend, first 32 / last 32 positions of a 4096 context (CALM_POSO), full 32-layer Mistral shape
 #  5. PMC counters of the gf4 kernels (tools/pmc_kernel.sh)
+#  6. the long-context table (tools/longctx.py: Mistral geometry at 4k fp16 / 32k e5m2, DBRX geometry at 4k)
+#  7. the real-architecture shape sweep with per-stage timings (tests/test_shape_sweep.py, CALM_SHAPE_SWEEP_OUT)
 #  SECTIONS="1 2 3" selects (default: all)
 TAG=${1:-r04}
-SECTIONS=${SECTIONS:-"0 2 1 3 4 5"}
+SECTIONS=${SECTIONS:-"0 2 1 3 4 5 6 7"}
 want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 OUT=gpurun_out/final_$TAG
 mkdir -p $OUT
@@ -66,5 +68,17 @@ if want 5; then
 echo "== 5. counters of the gf4 kernels (Llama-3-8B shape, full depth; three separate passes)" | tee -a $OUT/summary.txt
 bash tools/pmc_kernel.sh ${TAG}_pmc_gf4 llama-3-8b gf4 > $OUT/pmc_gf4.log 2>&1
 cp gpurun_out/${TAG}_pmc_gf4/summary.txt $OUT/pmc_gf4_tables.txt 2>/dev/null; tail -12 $OUT/pmc_gf4_tables.txt | cut -c1-400 >> $OUT/summary.txt
+fi
+if want 6; then
+echo "== 6. long context (attention stage us, full-depth tok/s)" | tee -a $OUT/summary.txt
+timeout 600 python tools/longctx.py 8 > $OUT/long_context.txt 2>&1
+MODEL=dbrx-132b POS=4000 timeout 600 python tools/longctx.py 2 >> $OUT/long_context.txt 2>&1
+cat $OUT/long_context.txt >> $OUT/summary.txt
+fi
+if want 7; then
+echo "== 7. shape sweep" | tee -a $OUT/summary.txt
+rm -f $OUT/shape_sweep.txt
+CALM_SHAPE_SWEEP_OUT=$PWD/$OUT/shape_sweep.txt timeout 900 python -m pytest tests/test_shape_sweep.py -m gpu -q > $OUT/shape_sweep.log 2>&1; tail -2 $OUT/shape_sweep.log >> $OUT/summary.txt
+cat $OUT/shape_sweep.txt >> $OUT/summary.txt
 fi
 cat $OUT/summary.txt
