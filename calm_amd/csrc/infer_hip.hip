@@ -93,6 +93,7 @@ int g_moe_route = 1;   // mixture-of-experts models: the router's logits from pa
                        // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
 int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every active expert's hidden vector in LDS and streams their rows as one task
                        // stream (kernels.hip.h k_ffn_down SEG) where all images together stay under 96 KiB; 0: one pass per expert
+int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -314,6 +315,13 @@ void allow_lds(K kernel, size_t bytes) {
 	}
 }
 
+// the register-resident form of a dim-sized matvec (kernels.hip.h XREG): rows of exactly xreg_chunks() KiB -- 4096 input columns at
+// fp8 (4 chunks) or gf4 (2), 2048 at fp16 (4): the BASELINE models' dim
+template <int DB>
+inline bool use_xreg(int n) {
+	return g_xreg && n == xreg_chunks<DB, true>() * 64 * (128 / DB);
+}
+
 // ---------------------------------------------------------------- stage launchers ---------------
 
 template <int DB>
@@ -508,6 +516,13 @@ void launch_attn_out(Ctx* c, int l) {
 		by_bool(rows_full<DB>(c->q_dim), [&](auto FULL) {
 			by_bool(one, [&](auto ONE) {
 				by_bool(gate, [&](auto GATE) {
+					if constexpr (decltype(V4)::value && decltype(FULL)::value) {
+						if (use_xreg<DB>(c->q_dim)) {
+							hipLaunchKernelGGL((k_attn_out<DB, 4, true, decltype(ONE)::value, decltype(GATE)::value, true>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim, mt,
+							                   c->gate_part, c->gate_ep);
+							return;
+						}
+					}
 					hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(ONE)::value, decltype(GATE)::value>), grid, block, lds, g_stream, c->x,
 					                   c->att, wo, c->dim, c->q_dim, mt, c->gate_part, c->gate_ep);
 				});
@@ -546,6 +561,16 @@ void launch_ffn_up(Ctx* c, int l) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			constexpr int V = decltype(V4)::value ? 4 : 8;
 			constexpr bool F = decltype(FULL)::value;
+			if constexpr (V == 4 && F) {
+				if (use_xreg<DB>(c->dim) && moe != 1) {
+					if (moe == 2) {
+						go(k_ffn_up<DB, 4, true, 2, true>);
+					} else {
+						go(k_ffn_up<DB, 4, true, 0, true>);
+					}
+					return;
+				}
+			}
 			if (moe == 2) {
 				go(k_ffn_up<DB, V, F, 2>);
 			} else if (moe == 1) {
@@ -659,6 +684,13 @@ void launch_output(Ctx* c) {
 	size_t lds = lds_bytes<DB>(c->dim);
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
+			if constexpr (decltype(V4)::value && decltype(FULL)::value) {
+				if (use_xreg<DB>(c->dim)) {
+					hipLaunchKernelGGL((k_output<DB, 4, true, true>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab,
+					                   p->norm_eps, (int)p->norm_ln);
+					return;
+				}
+			}
 			hipLaunchKernelGGL((k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
 			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
 		});
@@ -1345,6 +1377,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_out_one;
 	} else if (!strcmp(key, "moe_route")) {
 		slot = &g_moe_route;
+	} else if (!strcmp(key, "xreg")) {
+		slot = &g_xreg;
 	} else if (!strcmp(key, "down_seg")) {
 		slot = &g_down_seg;
 

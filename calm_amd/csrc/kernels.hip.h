@@ -213,15 +213,16 @@ __device__ __forceinline__ float fma_mix_hi(unsigned h2, float x, float acc) {
 // converted weight pair, the activation pair from ds_read_b128, the accumulator pair.
 // xp points at this lane's first float4 of the chunk in the swizzled LDS image; float4 #i of the
 // lane is at xp[i * ROW] (ROW = Fmt<DB>::ROW slots).
-template <int DB>
-__device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
+// X(i): the lane's float4 #i of the chunk's activations -- from the LDS image (dot16) or from registers (run_rows_impl XR)
+template <int DB, class XF>
+__device__ __forceinline__ f32x2 dot16x(u32x4 v, XF X, f32x2 acc) {
 	// (fp16 / fp8: a second, call-local accumulator pair halves the length of the dependent v_pk_fma chain
 	// -- PMC showed 30-40 % of wave cycles in issue stalls with one chain per row)
 	if constexpr (DB == 16) {
 		f32x2 acc_b = {0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 2; ++i) {
-			f32x4 x = xp[i * Fmt<DB>::ROW];
+			f32x4 x = X(i);
 			unsigned w0 = v[2 * i], w1 = v[2 * i + 1];
 			f32x2 a = {half_bits_to_float((unsigned short)(w0 & 0xffff)), half_bits_to_float((unsigned short)(w0 >> 16))};
 			f32x2 b = {half_bits_to_float((unsigned short)(w1 & 0xffff)), half_bits_to_float((unsigned short)(w1 >> 16))};
@@ -233,7 +234,7 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		f32x2 acc_b = {0.f, 0.f};
 #pragma unroll
 		for (int i = 0; i < 4; ++i) {
-			f32x4 x = xp[i * Fmt<DB>::ROW];
+			f32x4 x = X(i);
 			acc = __builtin_elementwise_fma(bf8x2_lo(v[i]), x.lo, acc);
 			acc_b = __builtin_elementwise_fma(bf8x2_hi(v[i]), x.hi, acc_b);
 		}
@@ -254,12 +255,12 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		f32x4 xv[4][2];
 		unsigned m[4][5];
 		float t[4], S[4];
-		const f32x4 xsum = xp[8 * Fmt<4>::ROW];
+		const f32x4 xsum = X(8);
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const unsigned w = v[j];
-			xv[j][0] = xp[(2 * j) * Fmt<4>::ROW];
-			xv[j][1] = xp[(2 * j + 1) * Fmt<4>::ROW];
+			xv[j][0] = X(2 * j);
+			xv[j][1] = X(2 * j + 1);
 			S[j] = bf8_byte0(w);
 			const unsigned r = __builtin_amdgcn_alignbit(w, w, 23); // rotate right by 23
 			m[j][0] = r & 0x000E0007u; // lo: c5 (a = 0)   hi: c0 (a = 1)
@@ -290,6 +291,11 @@ __device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
 		}
 	}
 	return acc;
+}
+
+template <int DB>
+__device__ __forceinline__ f32x2 dot16(u32x4 v, const f32x4* xp, f32x2 acc) {
+	return dot16x<DB>(v, [&](int i) { return xp[i * Fmt<DB>::ROW]; }, acc);
 }
 
 // ---------------------------------------------------------------- activation staging ----------
@@ -560,6 +566,25 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 	}
 }
 
+// The same with the lane's activations held in REGISTERS (run_rows_impl XR): a lane only ever multiplies with "its" float4s of every
+// chunk of the vector -- the same ones for every row -- so where a row is XR chunks long and XR x NF float4s fit the register file
+// (dim 4096 at gf4: 2 x 9 float4 = 72 VGPRs) they are read from the LDS image ONCE, after it is built, and no step reads LDS again.
+// c0: the (compile-time after unrolling) chunk the step starts at.  Rows are whole chunks (the launcher's condition).
+template <int DB>
+struct XRegs {
+	static constexpr int NF = Fmt<DB>::F4 + (DB == 4 ? 1 : 0);
+};
+template <int DB, int NR, int U, int XR>
+__device__ __forceinline__ void tile_fma_regs(const Tile<NR, U>& t, f32x2 (&acc)[NR], const f32x4 (&xr)[XR > 0 ? XR : 1][XRegs<DB>::NF], int c0) {
+#pragma unroll
+	for (int u = 0; u < U; ++u) {
+#pragma unroll
+		for (int r = 0; r < NR; ++r) {
+			acc[r] = dot16x<DB>(t.w[u][r], [&](int i) { return xr[c0 + u][i]; }, acc[r]);
+		}
+	}
+}
+
 // Runs `ntasks` row-group tasks over the workgroup's waves.  Wave-task t (t = first, first +
 // stride, ...) owns NR rows given by rows_of(t, rows).  stage() builds the LDS activation image and
 // must end with a barrier; it is called AFTER the first tile's loads have been issued so that the
@@ -581,9 +606,13 @@ __device__ __forceinline__ void tile_fma(const Tile<NR, U>& t, f32x2 (&acc)[NR],
 // steps (its last step's surplus chunks clamp into the row, as they do at the end of any row); at the end of EVERY segment the
 // sums are reduced and handed to epi(t, seg, acc, aux), which keeps the running value -- the experts are added in rank order by
 // the same lane, exactly as with one pass per expert.  aux_of runs before segment 0's last multiply-add.
-template <int DB, int NR, int U, bool FULL, bool SEGS, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+// XR > 0: rows of exactly XR chunks, the lane's activations in registers (tile_fma_regs); a row is then one step (U == XR) or two
+// (2 U == XR) long, and because every task has that many steps and the first one starts in phase 0 of the two-phase loop body, the
+// phase IS the step within the row: the chunk index is a compile-time constant.
+template <int DB, int NR, int U, bool FULL, bool SEGS, int XR, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                               StageFn stage, AuxFn aux_of, EpiFn epi) {
+	static_assert(XR == 0 || (!SEGS && FULL && (XR == U || XR == 2 * U)), "XR: whole rows of one or two steps");
 	const int lane = lane_id();
 	const int nl = n / Fmt<DB>::G;
 	const int cpi = (nl + 63) >> 6;           // chunks of one segment's row (and of its image)
@@ -666,6 +695,16 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 	}
 	issue(1, t1, k1, live1);
 	stage();
+	f32x4 xr[XR > 0 ? XR : 1][XRegs<DB>::NF];
+	if constexpr (XR > 0) {
+#pragma unroll
+		for (int c_ = 0; c_ < XR; ++c_) {
+#pragma unroll
+			for (int i = 0; i < XRegs<DB>::NF; ++i) {
+				xr[c_][i] = ((const f32x4*)xs4)[c_ * Fmt<DB>::CS + i * Fmt<DB>::ROW + lane];
+			}
+		}
+	}
 #ifdef CALM_TIMELINE
 	tl[1] = wall_clock64();
 #endif
@@ -688,7 +727,11 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 			if (last_k && seg == 0) {
 				aux_of(t, aux);
 			}
-			tile_fma<DB, NR, U, FULL>(tile[ph], acc2, SEGS ? xs4 + seg * cpi * Fmt<DB>::CS : xs4, kl, nl, lane);
+			if constexpr (XR > 0) {
+				tile_fma_regs<DB, NR, U, XR>(tile[ph], acc2, xr, XR == U ? 0 : ph * U);
+			} else {
+				tile_fma<DB, NR, U, FULL>(tile[ph], acc2, SEGS ? xs4 + seg * cpi * Fmt<DB>::CS : xs4, kl, nl, lane);
+			}
 #ifdef CALM_TIMELINE
 			if (tl[2] == 0) {
 				asm volatile("" ::"v"(acc2[0][0]));
@@ -732,16 +775,16 @@ __device__ __forceinline__ void run_rows_impl(int ntasks, int first, int stride,
 // FULL (rows are whole KiB chunks) is a KERNEL template parameter picked by the host: carrying both variants
 // in one kernel doubled its code size for a branch that never changes (kernels this short feel their
 // instruction-cache warm-up).
-template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
+template <int DB, int NR, int U, bool FULL, int XR = 0, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows(int ntasks, int first, int stride, int n, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                          StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL, false>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+	run_rows_impl<DB, NR, U, FULL, false, XR>(ntasks, first, stride, n, 1, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 // ... over rows of `segs` segments of n columns each (run_rows_impl: SEGS)
 template <int DB, int NR, int U, bool FULL, class RowsFn, class PreFn, class StageFn, class AuxFn, class EpiFn>
 __device__ __forceinline__ void run_rows_segs(int ntasks, int first, int stride, int n, int segs, const float4* xs4, const void* dummy, RowsFn rows_of, PreFn pre,
                                               StageFn stage, AuxFn aux_of, EpiFn epi) {
-	run_rows_impl<DB, NR, U, FULL, true>(ntasks, first, stride, n, segs, xs4, dummy, rows_of, pre, stage, aux_of, epi);
+	run_rows_impl<DB, NR, U, FULL, true, 0>(ntasks, first, stride, n, segs, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
 // Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
@@ -777,6 +820,13 @@ __device__ __forceinline__ void stage_first_barrier() {
 //     48.9, 45.2, 44.2, 47.2.
 // (The CALM_* macros are for A/B builds.)
 enum KernelId { KS_QKV, KS_ATTN_OUT, KS_FFN_UP, KS_FFN_DOWN, KS_OUTPUT };
+// XREG kernels (knob "xreg"): the launcher picks them where the input vector has exactly 4096 columns at fp8 (rows of 4 chunks) or at
+// gf4 (2 chunks), 2048 at fp16 (4 chunks) -- the BASELINE models' dim -- and every lane keeps its float4s of the image in registers
+// (run_rows_impl XR: 64-72 VGPRs at fp8 / gf4, 32 at fp16)
+template <int DB, bool XREG>
+constexpr int xreg_chunks() {
+	return XREG ? (DB == 4 ? 2 : 4) : 0;
+}
 #ifndef CALM_F8_QKV
 #define CALM_F8_QKV 2, 4
 #endif
@@ -951,7 +1001,7 @@ struct QkvArgs {
 // struct argument is copied to scratch memory, +4 us per launch when that was tried).
 // HALF: tiles half as deep -- for matrices so small that a wave's share is less than one full tile (TinyLlama's 10.5 MB at fp16: 6.3 ->
 // 5.45 us; the host decides, launch_qkv)
-template <int DB, int KVB, int V, bool FULL, bool HALF>
+template <int DB, int KVB, int V, bool FULL, bool HALF, bool XREG = false>
 __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = KShape<DB, KS_QKV>::NR, U = (HALF && KShape<DB, KS_QKV>::U > 1) ? KShape<DB, KS_QKV>::U / 2 : KShape<DB, KS_QKV>::U;
@@ -1044,7 +1094,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -1828,7 +1878,7 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 // routing left that kernel's critical path, where it stood between the launch and the first weight byte.
 constexpr int GATE_COLS = 1024; // workgroups of k_attn_out the partial buffer has columns for
 constexpr int GATE_MAX_E = 64;  // experts (one per lane)
-template <int DB, int V, bool FULL, bool ONE, bool GATE>
+template <int DB, int V, bool FULL, bool ONE, bool GATE, bool XREG = false>
 __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* att, const void* wo, int dim, int q_dim, const float* gate_mt, float* gate_part, int ep) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = ONE ? 1 : KShape<DB, KS_ATTN_OUT>::NR, U = ONE ? CALM_ONE_U * KShape<DB, KS_ATTN_OUT>::U : KShape<DB, KS_ATTN_OUT>::U;
@@ -1876,7 +1926,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_attn_out(float* x, const float* 
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(dim / NR, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(dim / NR, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, q_dim, xs4, att, rows_of, pre, stage, aux_of, epi);
 	if constexpr (GATE) {
 		// the waves' sums -> LDS -> one column of the partial buffer, waves added in index order
 		constexpr int W = GATE_MAX_E + 2;
@@ -1997,7 +2047,7 @@ __device__ __forceinline__ float act_gelu(float x) {
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
 // MOE: 0 dense; 1 the gate computed here, by every workgroup, from the vector (below); 2 the gate folded from the partials
 // k_attn_out's epilogue left (`moegate` then points at gate_part, `n_experts` carries n_experts | k_attn_out's grid << 8).
-template <int DB, int V, bool FULL, int MOE>
+template <int DB, int V, bool FULL, int MOE, bool XREG = false>
 __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -2042,7 +2092,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	if constexpr (MOE == 0) {
 		auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
 		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+		run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -2113,7 +2163,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		}
 		auto nothing = [&]() {};
 		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, nothing, stage, no_aux, epi);
+		run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, nothing, stage, no_aux, epi);
 		return;
 	}
 
@@ -2313,7 +2363,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 }
 
 // ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
-template <int DB, int V, bool FULL>
+template <int DB, int V, bool FULL, bool XREG = false>
 __global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = KShape<DB, KS_OUTPUT>::NR, U = KShape<DB, KS_OUTPUT>::U;
@@ -2344,7 +2394,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const floa
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----
