@@ -93,6 +93,7 @@ int g_moe_route = 1;   // mixture-of-experts models: the router's logits from pa
                        // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
 int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every active expert's hidden vector in LDS and streams their rows as one task
                        // stream (kernels.hip.h k_ffn_down SEG) where all images together stay under 96 KiB; 0: one pass per expert
+int g_skew = 14;       // k_ffn_up: percent more tasks for the first-dispatched workgroup of each CU than an even split gives it (0: even) (k_ffn_up, k_output at two workgroups per CU; kernels.hip.h task_range)
 int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
@@ -313,6 +314,23 @@ void allow_lds(K kernel, size_t bytes) {
 		CALM_REQUIRE(bytes <= 160 * 1024, "activation vector does not fit the 160 KiB LDS");
 		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
 	}
+}
+
+// tasks the first-dispatched half of a two-workgroups-per-CU grid takes (kernels.hip.h task_range): whole ROUNDS of the half grid
+// (a cut inside a round measured no gain where a whole-round cut gave 0.7 us: profiles/r04_startup.txt), (50 + skew / 2) % of them;
+// for k_ffn_up where the kernel is 12-32 rounds long -- Mistral-7B's 14 (20.8 -> 20.4 us, 20.3 -> 19.6 on another box; whole token
+// + 0.8-1.5 %), Mixtral's 28 (- 0.3 us); DBRX's 42 rounds and the classifier measured slower with it, coarser rounds cannot be cut
+// finely enough (Llama-3 gf4: 7 rounds, already 4 + 3).  0: no skew
+inline int skew_cut(int ntasks, int grid, int waves_per_block) {
+	if (g_skew <= 0 || grid != 2 * g_ncu) {
+		return 0;
+	}
+	const int stride = (grid / 2) * waves_per_block, rounds = (ntasks + stride - 1) / stride;
+	if (rounds < 12 || rounds > 32) {
+		return 0;
+	}
+	const int r_old = (int)(rounds * (100 + g_skew) / 200.0 + 0.5);
+	return r_old >= rounds ? 0 : r_old * stride;
 }
 
 // the register-resident form of a dim-sized matvec (kernels.hip.h XREG): rows of exactly xreg_chunks() KiB -- 4096 input columns at
@@ -551,6 +569,7 @@ void launch_ffn_up(Ctx* c, int l) {
 	// 0: dense; 1: the gate inside the kernel; 2: from k_attn_out's partials (its grid rides in the upper bits of n_experts)
 	const int moe = c->n_experts > 0 ? (moe_route_ahead<DB>(c) ? 2 : 1) : 0;
 	a.gate_c = nullptr;
+	a.cut = moe == 1 ? 0 : skew_cut(ntasks, (int)grid.x, WG_WAVES);
 	if (moe == 2) {
 		a.moegate = c->gate_part;
 		a.n_experts = c->n_experts | (attn_out_grid<DB>(c) << 8);
@@ -687,12 +706,12 @@ void launch_output(Ctx* c) {
 			if constexpr (decltype(V4)::value && decltype(FULL)::value) {
 				if (use_xreg<DB>(c->dim)) {
 					hipLaunchKernelGGL((k_output<DB, 4, true, true>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab,
-					                   p->norm_eps, (int)p->norm_ln);
+					                   p->norm_eps, (int)p->norm_ln, 0);
 					return;
 				}
 			}
 			hipLaunchKernelGGL((k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
-			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln);
+			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln, 0);
 		});
 	});
 }
@@ -1379,6 +1398,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_moe_route;
 	} else if (!strcmp(key, "xreg")) {
 		slot = &g_xreg;
+	} else if (!strcmp(key, "skew")) {
+		slot = &g_skew;
 	} else if (!strcmp(key, "down_seg")) {
 		slot = &g_down_seg;
 

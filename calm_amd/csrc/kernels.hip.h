@@ -819,6 +819,25 @@ __device__ __forceinline__ void stage_first_barrier() {
 //     15.8, 14.9-16.5; k_ffn_down (7-chunk rows) 2x7 12.8, 4x2 14.2, 4x1 13.5, 2x2 9.7, 2x1 10.0; k_output (up to 4 workgroups per CU)
 //     48.9, 45.2, 44.2, 47.2.
 // (The CALM_* macros are for A/B builds.)
+// Task ranges of a wave when the grid is two workgroups per CU and the FIRST-dispatched one is given more tasks (`cut` > 0; knob
+// "skew"): a CU's older workgroup wins its memory queue and used to leave 2-3 us before the younger one, whose waves then ran the
+// kernel's tail alone at half the bytes in flight (profiles/r02_kernel_timeline.txt).  Blocks [0, G/2) deal tasks [0, cut) among
+// their waves, blocks [G/2, G) tasks [cut, ntasks).  Placement-independent: another dispatch order only changes who finishes when.
+struct TaskRange {
+	int first, stride, ntasks;
+};
+__device__ __forceinline__ TaskRange task_range(int ntasks, int waves_per_block, int wave, int cut) {
+	const int b = blockIdx.x, g = gridDim.x;
+	if (cut <= 0 || (g & 1)) {
+		return {b * waves_per_block + wave, g * waves_per_block, ntasks};
+	}
+	const int half = g >> 1, stride = half * waves_per_block;
+	if (b < half) {
+		return {b * waves_per_block + wave, stride, cut};
+	}
+	return {cut + (b - half) * waves_per_block + wave, stride, ntasks};
+}
+
 enum KernelId { KS_QKV, KS_ATTN_OUT, KS_FFN_UP, KS_FFN_DOWN, KS_OUTPUT };
 // XREG kernels (knob "xreg"): the launcher picks them where the input vector has exactly 4096 columns at fp8 (rows of 4 chunks) or at
 // gf4 (2 chunks), 2048 at fp16 (4 chunks) -- the BASELINE models' dim -- and every lane keeps its float4s of the image in registers
@@ -1992,6 +2011,7 @@ struct FfnUpArgs {
 	int dim, hidden, n_experts, n_active;
 	float eps;
 	int ln, gelu;
+	int cut;             // tasks of the first-dispatched half of the grid (task_range); 0: tasks dealt round robin over all workgroups
 	const float* gate_c; // MOE == 2: c[e] behind the layer's gate_mt table (k_gate_prep), what a LayerNorm's mean takes off logit e
 };
 
@@ -2092,7 +2112,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	if constexpr (MOE == 0) {
 		auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
 		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+		const TaskRange tr = task_range(ntasks, WG_WAVES, wave, a.cut);
+		run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(tr.ntasks, tr.first, tr.stride, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 		if (blockIdx.x == 0 && threadIdx.x == 0) {
 			a.moe_w[0] = 1.0f; // src/infer.c:430-432
 			a.moe_e[0] = 0;
@@ -2163,7 +2184,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		}
 		auto nothing = [&]() {};
 		auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, nullptr); };
-		run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, dim, xs4, x, rows_of, nothing, stage, no_aux, epi);
+		const TaskRange tr = task_range(ntasks, WG_WAVES, wave, a.cut);
+		run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(tr.ntasks, tr.first, tr.stride, dim, xs4, x, rows_of, nothing, stage, no_aux, epi);
 		return;
 	}
 
@@ -2364,7 +2386,7 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 
 // ---- final norm + classifier   (src/infer.c:465-469) -----------------------------------------
 template <int DB, int V, bool FULL, bool XREG = false>
-__global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln) {
+__global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const float* x, const float* norm_w, const void* wcls, int dim, int vocab, float eps, int ln, int cut) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	constexpr int NR = KShape<DB, KS_OUTPUT>::NR, U = KShape<DB, KS_OUTPUT>::U;
 	float4* xs4 = (float4*)smem;
@@ -2394,7 +2416,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_output(float* logits, const floa
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
+	const TaskRange tr = task_range(ntasks, WG_WAVES, wave_id(), cut);
+	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(tr.ntasks, tr.first, tr.stride, dim, xs4, x, rows_of, pre, stage, no_aux, epi);
 }
 
 // ---- greedy sampler on the device: first index of the strict maximum (src/sampler.c:34-42) ----

@@ -69,7 +69,7 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 			by_bool(rows_full<DB>(n), [&](auto FULL) {
 				auto k = k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>;
 				allow_lds(k, lds_bytes<DB>(n));
-				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(ntasks)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln);
+				hipLaunchKernelGGL(k, dim3(pick_blocks_wg(ntasks)), dim3(WG_THREADS), lds_bytes<DB>(n), g_stream, dout, dx, dnw, dw, n, d, eps, ln, 0);
 			});
 		});
 	});
