@@ -2057,6 +2057,8 @@ __device__ __forceinline__ void moe_route(float logit, int n_experts, int n_acti
 	}
 }
 
+// (Round 4: v_exp_f32 + v_rcp_f32 in place of libm's expf and the IEEE division -- ~45 of the ~150 instructions of a k_ffn_up task's
+// epilogue -- measured the same to the tenth of a microsecond: profiles/r04_startup.txt.  The exact form stays.)
 __device__ __forceinline__ float act_silu(float x) {
 	return x / (1.0f + expf(-x)); // src/infer.c:273-275
 }
@@ -2085,8 +2087,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	const int ntasks = nact * per_expert;
 	constexpr bool moe = MOE != 0;
 
+	// task t -> expert slot k = t / per_expert and hidden unit j: dense models have one slot; otherwise a float reciprocal and one
+	// correction step (an integer division is ~25 scalar instructions per task, twice)
+	const float inv_pe = 1.0f / (float)per_expert;
+	auto split = [&](int t, int& k, int& j) {
+		if constexpr (!moe) {
+			k = 0, j = t * JP;
+		} else {
+			k = (int)(((float)t + 0.5f) * inv_pe);
+			int r = t - k * per_expert;
+			if (r < 0) {
+				--k, r += per_expert;
+			} else if (r >= per_expert) {
+				++k, r -= per_expert;
+			}
+			j = r * JP;
+		}
+	};
 	auto rows_of = [&](int t, const unsigned char*(&rows)[NR]) {
-		int k = t / per_expert, j = (t % per_expert) * JP;
+		int k, j;
+		split(__builtin_amdgcn_readfirstlane(t), k, j);
 		int e = moe ? sel_e[k] : 0;
 		size_t base = ((size_t)e * hidden + j) * row_bytes;
 #pragma unroll
@@ -2099,7 +2119,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 	float nscale = 1.f; // what the norm leaves to the epilogue (stage_finish)
 	auto epi = [&](int t, float(&acc)[NR], float(&)[NR]) {
 		if (lane == RED_LANE) {
-			int k = t / per_expert, j = (t % per_expert) * JP;
+			int k, j;
+			split(t, k, j);
 #pragma unroll
 			for (int p = 0; p < JP; ++p) {
 				float u = acc[2 * p] * nscale, g = acc[2 * p + 1] * nscale;
