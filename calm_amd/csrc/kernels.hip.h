@@ -818,6 +818,8 @@ __device__ __forceinline__ void stage_first_barrier() {
 //     burst weighs twice as much.  k_qkv 4x2 8.6, 4x1 7.9, 2x2 6.8, 2x1 7.3-8.2; k_attn_out 4.9, 4.7, 4.5, 4.45; k_ffn_up 15.5, 13.9,
 //     15.8, 14.9-16.5; k_ffn_down (7-chunk rows) 2x7 12.8, 4x2 14.2, 4x1 13.5, 2x2 9.7, 2x1 10.0; k_output (up to 4 workgroups per CU)
 //     48.9, 45.2, 44.2, 47.2.
+//     Round 4: with the activations in registers (XREG) no row shares an image read any more and 2 x 2 -- 14 rounds of tasks, so the skewed
+//     deal applies -- is k_ffn_up's best: 4x1 13.70, 2x1 14.15, 2x2 13.43 us (profiles/r04_gf4.txt).
 // (The CALM_* macros are for A/B builds.)
 // Task ranges of a wave when the grid is two workgroups per CU and the FIRST-dispatched one is given more tasks (`cut` > 0; knob
 // "skew"): a CU's older workgroup wins its memory queue and used to leave 2-3 us before the younger one, whose waves then ran the
@@ -883,7 +885,7 @@ constexpr int xreg_chunks() {
 #define CALM_GF4_ATTN_OUT 2, 1
 #endif
 #ifndef CALM_GF4_FFN_UP
-#define CALM_GF4_FFN_UP 4, 1
+#define CALM_GF4_FFN_UP 2, 2
 #endif
 #ifndef CALM_GF4_FFN_DOWN
 #define CALM_GF4_FFN_DOWN 2, 2

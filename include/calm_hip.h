@@ -170,6 +170,11 @@ const char* calm_hip_device_name(void);
  *   "attn_waves" waves per workgroup of the unsplit attention kernel: 16 (default), 8 or 4
  *   "moe_route" 1 = a mixture-of-experts layer's routing is derived from partial sums the attention output projection leaves
  *               (default), 0 = every workgroup of the FFN kernel computes the gate from the vector first
+ *   "down_seg"  1 = a mixture of many small experts keeps all active experts' hidden vectors in LDS and streams their down-projection
+ *               rows as one task stream (default; where the vectors together stay under 96 KiB), 0 = one pass per expert
+ *   "xreg"      1 = input vectors of exactly 4 KiB of weights per row (4096 columns at fp8 / gf4, 2048 at fp16) are held in registers
+ *               after staging (default), 0 = read from LDS at every step
+ *   "skew"      percent more of the FFN up-projection's tasks for the first-dispatched workgroup of each CU (default 14; 0 = even)
  *   "qkv_half" / "out_one" / "down_one" / "down_u" / "down_u4": tile-shape overrides of single kernels (0 = the launchers' rules by
  *               matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
  *   "pf_wide" / "pf_attn_mfma" / "pf_skinny": forms of the prompt-ingestion kernels (1 = default forms)

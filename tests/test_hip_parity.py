@@ -243,6 +243,39 @@ def test_alternative_tile_shapes_give_the_reference_logits(hiplib, case):
             hiplib.calm_hip_configure(k, 0)
 
 
+@pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 1), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1)])
+def test_launch_forms_that_only_reorder_work_are_bit_identical(hiplib, name, dtype, layers):
+    """Round 4's forms that change WHO does a row or WHERE its activations are read from, not its arithmetic -- activations in registers
+    ("xreg"), the skewed deal of k_ffn_up's task rounds ("skew"), all experts' images side by side in k_ffn_down ("down_seg") -- must
+    leave every logit bit-identical to the plain forms (full-width shapes: the knobs only engage at dim 4096 / 2048 and full grids).
+    "moe_route" changes the router's summation order: same experts away from near-ties, logits within the common tolerance."""
+    spec = cf.SPECS[name]
+    tensors, md = cf.synth_model_big(spec, dtype, seed=17, n_layers=layers)
+    model = HostModel(tensors, md, context=64)
+    toks = [11, 4242, 7, 31000]
+
+    def run():
+        b = HipBackend(model)
+        try:
+            return np.stack([b.forward(t, pos, 0).copy() for pos, t in enumerate(toks)])
+        finally:
+            b.close()
+
+    base = run()
+    for knob, off in ((b"xreg", 0), (b"skew", 0), (b"down_seg", 0)):
+        old = hiplib.calm_hip_configure(knob, off)
+        try:
+            assert np.array_equal(run(), base), knob
+        finally:
+            hiplib.calm_hip_configure(knob, old)
+    if spec.n_experts:
+        old = hiplib.calm_hip_configure(b"moe_route", 0)
+        try:
+            assert rel_err(run(), base) < LOGIT_TOL
+        finally:
+            hiplib.calm_hip_configure(b"moe_route", old)
+
+
 @pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4"])
 def test_greedy_stream_identical_and_device_decode_agrees(hiplib, case):
     """free-running greedy decode: forward_hip + host argmax, generate(), and the device-side
