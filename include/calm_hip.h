@@ -53,6 +53,8 @@ void* alloc_hip(size_t size);
  * the per-layer weight pointers. Fills state.x/hb/he/q/att/key_cache/value_cache/logits, and -- an extension, the reference's
  * GPU backend leaves it unset -- state.exp: device memory holding the routing of the last decode step, [n_layers][CALM_MAX_EXPERTS]
  * float weights in rank order followed by as many int expert ids (dense models: weight 1, expert 0).
+ * Mixture-of-experts models also get, per layer, a [dim][n_experts] fp32 table derived from moegate and the FFN norm weight (the router's
+ * logits are accumulated by the attention output projection's epilogue: 4 MB for Mixtral-8x7B, 16 MB for DBRX).
  * Aborts (like every error here) on shapes outside the backend's limits: dbits 4/8/16; dim, hidden_dim and
  * n_heads*head_dim multiples of 128/dbits; head_dim a multiple of 8, at most 512; and -- the one limit the reference's
  * backends do not have -- dim and n_heads*head_dim must fit one CU's 160 KiB LDS as an fp32 vector (about 40K elements at
