@@ -704,7 +704,9 @@ void launch_output(Ctx* c) {
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			if constexpr (decltype(V4)::value && decltype(FULL)::value) {
-				if (use_xreg<DB>(c->dim)) {
+				// (not the gf4 classifier: its 4 workgroups per CU no longer fit with 145 VGPRs -- 3 fit, the grid's last quarter ran as a
+				// second batch: 46.9 against 45.0 us without, profiles/r04_gf4.txt)
+				if (use_xreg<DB>(c->dim) && DB != 4) {
 					hipLaunchKernelGGL((k_output<DB, 4, true, true>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab,
 					                   p->norm_eps, (int)p->norm_ln, 0);
 					return;
