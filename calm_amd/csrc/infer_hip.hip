@@ -1400,6 +1400,7 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_moe_route;
 	} else if (!strcmp(key, "xreg")) {
 		slot = &g_xreg;
+
 	} else if (!strcmp(key, "skew")) {
 		slot = &g_skew;
 	} else if (!strcmp(key, "down_seg")) {

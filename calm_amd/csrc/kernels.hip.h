@@ -2304,6 +2304,9 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	// UO: tiles of 2 rows x UO chunks instead of the format's shape; UO = 1: ONE row x 4 chunks, for matrices of fewer row pairs than
 	// the chip has waves (TinyLlama's 2048 rows: 7.9 -> 6.6 us)
+	// (Round 4: every task split along K between an older and a younger wave of the workgroup -- 8 + 6 of Mistral-7B's 14 chunks, the partial sums
+	// handed over through LDS: the older four waves of a workgroup leave 0.8-1.1 us before the younger four -- 12.18 -> 12.0 us, gf4 unchanged:
+	// profiles/r04_startup.txt; not kept.)
 	// (Round 4: ONE row x 11 chunks for DBRX's ragged 10.5-KiB rows -- one exact step instead of 4 + 4 + 3 and a clamped surplus load --
 	// measured 51 us against 49: profiles/r04_moe.txt.)
 	// SEG: UO = chunks per step (1 / 2 / 4: the largest that divides a segment's chunk count -- a segment is walked in whole steps)
