@@ -215,6 +215,35 @@ def test_transposed_value_cache_catches_up_when_a_sequence_crosses_the_split_thr
         ref.close()
 
 
+def test_prompt_chunk_behind_unsplit_decode_steps_syncs_the_transposed_cache_first(hiplib, more_cpu_threads):
+    """decode 20 positions one by one (unsplit attention: no transposed-cache writes), THEN hand prefill_hip the next 400 tokens: the
+    prompt kernels read the transposed value cache over all earlier rows, so the chunk must first copy rows 0..19 (vt_sync); then a
+    split decode step on top.  Against the oracle."""
+    seq_len = 1024
+    spec = attention_true_spec(seq_len)
+    tensors, md = cf.synth_model_big(spec, "fp8", 24)
+    model = HostModel(tensors, md, context=seq_len)
+    ref = oracle.OracleBackend(model)
+    hip = HipBackend(model)
+    rng = np.random.default_rng(10)
+    toks = [int(t) for t in rng.integers(0, model.config.vocab_size, size=424)]
+    try:
+        for pos in range(20):
+            ref.forward(toks[pos], pos, FF)
+            hip.forward(toks[pos], pos, FF)
+        import ctypes as C
+        arr = (C.c_int * 400)(*toks[20:420])
+        hiplib.prefill_hip(C.byref(hip.t), arr, 400, 20)
+        for pos in range(20, 420):
+            ref.forward(toks[pos], pos, FF)
+        for pos in range(420, 424):
+            lr, lg = ref.forward(toks[pos], pos, 0), hip.forward(toks[pos], pos, 0)
+            assert np.isfinite(lg).all() and rel_err(lg, lr) < LOGIT_TOL, (pos, rel_err(lg, lr))
+    finally:
+        hip.close()
+        ref.close()
+
+
 def test_fp8_cache_to_the_end_of_an_8192_context_and_past_it(hiplib, more_cpu_threads):
     """seq_len = 8192 with the fp8 (e5m2) cache on both sides -- the configuration src/run.c:536-540 picks for contexts beyond
     4096 on a GPU backend; same protocol as above"""
