@@ -94,6 +94,7 @@ int g_moe_route = 1;   // mixture-of-experts models: the router's logits from pa
 int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every active expert's hidden vector in LDS and streams their rows as one task
                        // stream (kernels.hip.h k_ffn_down SEG) where all images together stay under 96 KiB; 0: one pass per expert
 int g_skew = 14;       // k_ffn_up: percent more tasks for the first-dispatched workgroup of each CU than an even split gives it (0: even) (k_ffn_up, k_output at two workgroups per CU; kernels.hip.h task_range)
+int g_qkv_wgs = 0;     // workgroups per CU of k_qkv's grid where the tasks exceed it (0: the rule in launch_qkv; A/B switch)
 int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
@@ -376,6 +377,15 @@ void launch_qkv(Ctx* c, int l) {
 	a.eps = p->norm_eps, a.clip = p->qkv_clip, a.ln = p->norm_ln;
 	int ntasks = (c->q_dim + 2 * c->kv_dim) / KShape<DB, KS_QKV>::NR;
 	dim3 grid(pick_blocks_wg(ntasks, KShape<DB, KS_QKV>::BPC)), block(WG_THREADS);
+	{
+		// pick_blocks settles on ONE workgroup per CU for the 3072 row pairs of the BASELINE shapes (1.5 rounds of two per CU); measured
+		// (profiles/r04_startup.txt): right for fp8 (7.61 us; two per CU 8.15, three 7.62), wrong for gf4, whose half-size matrix wants the
+		// eight waves per CU: 6.86 -> 6.37 us
+		const int wgs = g_qkv_wgs > 0 ? g_qkv_wgs : (DB == 4 ? 2 : 0);
+		if (wgs > 0 && (ntasks + WG_WAVES - 1) / WG_WAVES > g_ncu * wgs) {
+			grid = dim3(g_ncu * wgs);
+		}
+	}
 	size_t lds = lds_bytes<DB>(c->dim);
 	// Tiles half as deep (a) for a matrix so small that a wave's share of it (all 2 x 4 x ncu waves of a full grid) is less than one tile
 	// -- the wave starts multiplying after half the bytes (TinyLlama) -- and (b) for rows the full depth does not divide but half of it
@@ -1400,6 +1410,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_moe_route;
 	} else if (!strcmp(key, "xreg")) {
 		slot = &g_xreg;
+	} else if (!strcmp(key, "qkv_wgs")) {
+		slot = &g_qkv_wgs;
 
 	} else if (!strcmp(key, "skew")) {
 		slot = &g_skew;
