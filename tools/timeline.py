@@ -35,7 +35,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 name = args[0] if len(args) > 0 else "mistral-7b"
 dtype = args[1] if len(args) > 1 else "fp8"
 L = int(args[2]) if len(args) > 2 else 8
-spec = cf.SPECS[name]
+spec = cf.SPECS.get(name) or cf.ARCH_SPECS[name]
 model = HostModel(cf.stub_tensors(spec, dtype, L), cf.dataclasses.replace(spec, n_layers=L).metadata(dtype))
 b = HipBackend(model, device_synth=(spec, dtype, 1, L))
 lib = b.lib._product
