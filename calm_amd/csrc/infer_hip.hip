@@ -47,6 +47,10 @@ namespace {
 
 constexpr int LDS_EXTRA = 2048; // reduction scratch + MoE routing scratch (k_ffn_up) / the waves' gate partials (k_attn_out) behind the activation image
 constexpr int MAX_SPLIT = ATTN_MAX_SPLIT; // (k_attn_merge holds one partial per split in registers)
+// the scratch behind the image: k_attn_out<GATE> parks every wave's ep + 2 partial sums there, k_ffn_up its reduction words, the router's
+// logits and the picks (kernels.hip.h)
+static_assert((size_t)WG_WAVES * (GATE_MAX_E + 2) * sizeof(float) <= LDS_EXTRA, "LDS_EXTRA: k_attn_out's gate partials of all waves");
+static_assert((16 + (GATE_MAX_E + 2) + 2 * GATE_MAX_E) * sizeof(float) <= LDS_EXTRA, "LDS_EXTRA: k_ffn_up's routing scratch");
 
 hipStream_t g_stream; // the CURRENT device's decode stream (multi-device: switched by use_dev)
 int g_device = -1;
@@ -1326,8 +1330,6 @@ void dispatch_prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed = t
 
 template <int DB>
 void set_lds_attrs(Ctx* c) {
-	// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
-	// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
 	{
 		// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
 		// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
@@ -1394,7 +1396,6 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_attn_waves;
 	} else if (!strcmp(key, "attn_vt")) {
 		slot = &g_attn_vt;
-
 	} else if (!strcmp(key, "down_u")) {
 		slot = &g_down_u;
 	} else if (!strcmp(key, "down_u4")) {
@@ -1403,7 +1404,6 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_qkv_half;
 	} else if (!strcmp(key, "down_one")) {
 		slot = &g_down_one;
-
 	} else if (!strcmp(key, "out_one")) {
 		slot = &g_out_one;
 	} else if (!strcmp(key, "moe_route")) {
@@ -1412,13 +1412,10 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_xreg;
 	} else if (!strcmp(key, "qkv_wgs")) {
 		slot = &g_qkv_wgs;
-
 	} else if (!strcmp(key, "skew")) {
 		slot = &g_skew;
 	} else if (!strcmp(key, "down_seg")) {
 		slot = &g_down_seg;
-
-
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
 	} else if (!strcmp(key, "pf_attn_mfma")) {
@@ -1547,7 +1544,6 @@ extern "C" void init_hip(void) {
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
-
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);

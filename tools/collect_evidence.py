@@ -33,7 +33,10 @@ with open(os.path.join(P, f"{tag}_gpu_tests.txt"), "w") as o:
 
 for src, dst in (("long_context.txt", f"{tag}_long_context_table.txt"), ("shape_sweep.txt", f"{tag}_shape_sweep.txt")):
     if os.path.exists(os.path.join(F, src)):
-        shutil.copy(os.path.join(F, src), os.path.join(P, dst))
+        # the tracked file = the session's raw table + whatever reading of it was written underneath (kept across re-collections)
+        old = open(os.path.join(P, dst)).read() if os.path.exists(os.path.join(P, dst)) else ""
+        notes = old[old.index("\n== reading"):] if "\n== reading" in old else ""
+        open(os.path.join(P, dst), "w").write(open(os.path.join(F, src)).read().rstrip("\n") + "\n" + notes)
 
 
 def table(lines):
