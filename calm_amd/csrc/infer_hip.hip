@@ -104,6 +104,8 @@ int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
+int g_pf_chunk = PF_NT_DENSE; // tokens per prompt chunk of a dense model (read when a model's prompt buffers are allocated; PF_NT ... PF_NT_DENSE)
+int g_pf_big = 1;      // ... and the big form (512 units x 128 tokens per workgroup) for the FFN-up / classifier of long chunks (0: never; 2: always, for tests)
 char g_devname[256] = "none";
 
 // CALM_HIP_PROF_JSON=<path>: algorithmic bytes per kernel, accumulated over every decode step of the process and written at
@@ -230,7 +232,8 @@ struct Ctx {
 	int gate_ep = 0;
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
-	// batched prompt ingestion (allocated on first use): token-major [PF_NT][...] activations of one chunk
+	// batched prompt ingestion (allocated on first use): token-major [pf_nt][...] activations of one chunk
+	int pf_nt = 0; // tokens per chunk, fixed when the buffers are allocated: PF_NT for mixtures of experts, else the knob "pf_chunk"
 	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr, *pf_partial = nullptr;
 	unsigned* pf_tile_count = nullptr;
 	float2* pf_rope = nullptr;
@@ -1063,15 +1066,17 @@ void pf_alloc(Ctx* c) {
 		return p;
 	};
 	// a mixture-of-experts chunk packs (token, expert) pairs into 64-row columns, one group per expert
-	c->pf_max_cols = c->n_experts > 0 ? (PF_NT * c->n_active + 63) / 64 + c->n_experts : 0;
-	const int erows = c->n_experts > 0 ? c->pf_max_cols * 64 : PF_NT;
-	c->pf_x = (float*)dev_alloc((size_t)PF_NT * c->dim * sizeof(float));
-	c->pf_xn = frag(c->dim, PF_NT);
-	c->pf_q = (float*)dev_alloc((size_t)PF_NT * c->q_dim * sizeof(float));
-	c->pf_att = frag(c->q_dim, PF_NT);
+	c->pf_nt = c->n_experts > 0 ? PF_NT : g_pf_chunk;
+	const int NT = c->pf_nt;
+	c->pf_max_cols = c->n_experts > 0 ? (NT * c->n_active + 63) / 64 + c->n_experts : 0;
+	const int erows = c->n_experts > 0 ? c->pf_max_cols * 64 : NT;
+	c->pf_x = (float*)dev_alloc((size_t)NT * c->dim * sizeof(float));
+	c->pf_xn = frag(c->dim, NT);
+	c->pf_q = (float*)dev_alloc((size_t)NT * c->q_dim * sizeof(float));
+	c->pf_att = frag(c->q_dim, NT);
 	c->pf_h = frag(c->hidden, erows);
-	c->pf_rope = (float2*)dev_alloc((size_t)PF_NT * (c->head_dim / 2) * sizeof(float2));
-	c->pf_tok = (int*)dev_alloc(PF_NT * sizeof(int));
+	c->pf_rope = (float2*)dev_alloc((size_t)NT * (c->head_dim / 2) * sizeof(float2));
+	c->pf_tok = (int*)dev_alloc(NT * sizeof(int));
 	HIP_CHECK(hipHostMalloc((void**)&c->pf_flag, sizeof(unsigned), hipHostMallocMapped));
 	*c->pf_flag = 0;
 	HIP_CHECK(hipHostGetDevicePointer((void**)&c->pf_flag_dev, c->pf_flag, 0));
@@ -1080,11 +1085,11 @@ void pf_alloc(Ctx* c) {
 	c->pf_tile_count = (unsigned*)dev_alloc(PF_SPLIT_TILES * sizeof(unsigned));
 	HIP_CHECK(hipMemset(c->pf_tile_count, 0, PF_SPLIT_TILES * sizeof(unsigned)));
 	if (c->n_experts > 0) {
-		c->pf_gate = (float*)dev_alloc((size_t)PF_NT * c->n_experts * sizeof(float));
+		c->pf_gate = (float*)dev_alloc((size_t)NT * c->n_experts * sizeof(float));
 		c->pf_rows = (int*)dev_alloc((size_t)erows * sizeof(int));
 		c->pf_colexp = (int*)dev_alloc((size_t)c->pf_max_cols * sizeof(int));
-		c->pf_slot = (int*)dev_alloc((size_t)PF_NT * c->n_active * sizeof(int));
-		c->pf_wsel = (float*)dev_alloc((size_t)PF_NT * c->n_active * sizeof(float));
+		c->pf_slot = (int*)dev_alloc((size_t)NT * c->n_active * sizeof(int));
+		c->pf_wsel = (float*)dev_alloc((size_t)NT * c->n_active * sizeof(float));
 		c->pf_xe = frag(c->dim, erows);
 		c->pf_y = (float*)dev_alloc((size_t)erows * c->dim * sizeof(float));
 	}
@@ -1160,7 +1165,7 @@ void launch_pf_attn(Ctx* c, int l, int nb, int pos0) {
 	}
 }
 
-// one chunk of nb <= PF_NT tokens at positions pos0 .. pos0 + nb - 1 (no wrap of the rolling buffer):
+// one chunk of nb <= Ctx::pf_nt tokens at positions pos0 .. pos0 + nb - 1 (no wrap of the rolling buffer):
 // the layer loop of src/infer.c:349-458 with a token dimension
 template <int DB, int KVB>
 void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
@@ -1200,6 +1205,20 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 					allow_lds(kern, lds);
 					hipLaunchKernelGGL(kern, dim3(blocks), block, lds, g_stream, a, k0, kn);
 				}
+				return;
+			}
+		}
+		// The big form (prefill.hip.h k_pf_gemm_big: 512 units x 128 tokens per 8-wave workgroup, one per CU) for the GEMMs with enough
+		// units to fill the chip with such tiles -- the FFN-up and the classifier of a dense model from ~384 tokens: ahead of the wide
+		// form from 5/8 of the CUs covered (+6...20 %), behind below that (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt).
+		// fp8 / gf4 weights.  Knob "pf_big": 0 off, 2 whatever the grid (tests).
+		if constexpr ((epi == PF_EPI_FFN_UP || epi == PF_EPI_STORE) && DB != 16) {
+			const int nxb = (a.M + PfBig<epi>::UNITS - 1) / PfBig<epi>::UNITS, ncb = (a.nb + PfBig<epi>::TOKENS - 1) / PfBig<epi>::TOKENS;
+			if (g_pf_big && !a.col_expert && (g_pf_big >= 2 || (long)nxb * ncb * 8 >= (long)g_ncu * 5)) {
+				a.ncols = ncb, a.ksplit = 1;
+				auto kern = k_pf_gemm_big<DB, epi>;
+				allow_lds(kern, PfBigA<DB>::LDS_BYTES);
+				hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nxb, ncb)), dim3(512), PfBigA<DB>::LDS_BYTES, g_stream, a);
 				return;
 			}
 		}
@@ -1418,6 +1437,11 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_down_seg;
 	} else if (!strcmp(key, "pf_wide")) {
 		slot = &g_pf_wide;
+	} else if (!strcmp(key, "pf_big")) {
+		slot = &g_pf_big;
+	} else if (!strcmp(key, "pf_chunk")) {
+		CALM_REQUIRE(value < 0 || (value >= PF_NT && value <= PF_NT_DENSE && value % 128 == 0), "calm_hip_configure(\"pf_chunk\"): 1024 ... 2048 in steps of 128");
+		slot = &g_pf_chunk;
 	} else if (!strcmp(key, "pf_attn_mfma")) {
 		slot = &g_pf_attn_mfma;
 	} else if (!strcmp(key, "pf_skinny")) {
@@ -1545,6 +1569,9 @@ extern "C" void init_hip(void) {
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
+	g_pf_big = env_int("CALM_HIP_PF_BIG", g_pf_big);
+	g_pf_chunk = env_int("CALM_HIP_PF_CHUNK", g_pf_chunk);
+	CALM_REQUIRE(g_pf_chunk >= PF_NT && g_pf_chunk <= PF_NT_DENSE && g_pf_chunk % 128 == 0, "CALM_HIP_PF_CHUNK: 1024 ... 2048 in steps of 128");
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
@@ -2151,19 +2178,23 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 			HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(calm_pf_range_ptr), &st[s]->pf_flag_dev, sizeof(unsigned*), 0, hipMemcpyHostToDevice, g_stream));
 		}
 		if (logprob && !last->pf_logits) { // (the last stage's device is current)
-			last->pf_logits = (float*)dev_alloc((size_t)PF_NT * last->vocab * sizeof(float));
-			last->pf_lp = (float*)dev_alloc(PF_NT * sizeof(float));
-			last->pf_target = (int*)dev_alloc(PF_NT * sizeof(int));
+			last->pf_logits = (float*)dev_alloc((size_t)last->pf_nt * last->vocab * sizeof(float));
+			last->pf_lp = (float*)dev_alloc(last->pf_nt * sizeof(float));
+			last->pf_target = (int*)dev_alloc(last->pf_nt * sizeof(int));
+		}
+		int NT = first->pf_nt; // (the stages of a pipeline hold layers of ONE model; buffers of an earlier call may be smaller)
+		for (int s = 1; s < P; ++s) {
+			NT = st[s]->pf_nt < NT ? st[s]->pf_nt : NT;
 		}
 		while (done < n && pos + done < first->seq_len) {
-			int nb = n - done < PF_NT ? n - done : PF_NT;
+			int nb = n - done < NT ? n - done : NT;
 			if (pos + done + nb > first->seq_len) {
 				nb = first->seq_len - (pos + done);
 			}
 			if (nb <= 2) {
 				break; // a chunk costs about three decode steps whatever its size (it streams every weight once, less efficiently)
 			}
-			int target[PF_NT];
+			int target[PF_NT_DENSE];
 			for (int s = 0; s < P; ++s) {
 				on_stage(s);
 				Ctx* c = st[s];

@@ -2,7 +2,7 @@
 //
 // The reference feeds a prompt one token at a time through forward(token, pos, FF_UPDATE_KV_ONLY)
 // (src/run.c:208,216-218; "prompt processing is serial", README.md:80).  prefill_hip does the same work
-// -- the KV cache rows of n consecutive positions -- up to PF_NT tokens at a time, so that every weight byte
+// -- the KV cache rows of n consecutive positions -- up to PF_NT_DENSE (mixture-of-experts models: PF_NT) tokens at a time, so that every weight byte
 // is streamed once per chunk instead of once per token, and the multiply-adds move to the matrix cores.
 //
 // Numerics: exactly decoded weights (all three formats are exact in binary16), fp32 accumulation, and the fp32
@@ -41,7 +41,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PF_NT = 1024; // tokens per chunk: up to sixteen 64-token workgroup columns (the wide GEMM form fills the chip from ~512)
+constexpr int PF_NT = 1024; // tokens per chunk of a mixture-of-experts model (k_pf_route: one thread per token), and the least a dense model's is
+// Dense models take chunks of up to PF_NT_DENSE tokens (knob "pf_chunk"): at 1024 tokens the grids of the QKV / wo / w2 GEMMs cover 256-384
+// of the 512 workgroup slots, at 2048 all of them -- + 4...11 % per GEMM (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt)
+constexpr int PF_NT_DENSE = 2048;
 
 enum { PF_EPI_QKV = 0, PF_EPI_RESID = 1, PF_EPI_FFN_UP = 2, PF_EPI_STORE = 3 };
 constexpr int PF_MAX_ACTIVE = 8; // experts per token the batched MoE routing handles
@@ -1618,6 +1621,224 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 			pf_epilogue<KVB, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
 		} else { // the B ring is free: every wave has passed the loop's last barrier
 			pf_epilogue_rows<KVB, EPI, NA>(a, acc, unit0, tok0, (float*)pfw_lds + wave * (32 * 68));
+		}
+	}
+}
+
+// ---- the big form ---------------------------------------------------------------------------------------------------------
+// At the rate k_pf_gemm_wide runs, its 32 KB of operands per 64-column step of a 256-unit x 64-token workgroup are what the L2s deliver
+// (profiles/r02_prefill_gemm.txt: 567-599 TFLOP/s with the loop's global loads removed, 385-406 as built).  Where a GEMM has enough
+// units to fill the chip with tiles FOUR times the size -- the FFN-up and the classifier -- one 8-wave workgroup per CU takes
+// 512 units x 128 tokens: a wave owns 128 units x 64 tokens (4 x 2 accumulator tiles, 128 registers); the two waves of a unit strip
+// share ONE LDS image of the strip's 128 weight rows, the four waves of a token half share the B rows.  64 KB from the L2s per step
+// for four times the multiply-adds, and 24 ds_read_b128 + 8 ds_write_b128 per 64 MFMAs instead of 20 + 8 per 32.  Both operands are
+// fetched a step ahead into registers and staged into 2-slot LDS rings (fp8: A 2 x 40 KB, B 2 x 32 KB), one barrier per step.
+// Measured on the fp8 shapes at 1024 tokens (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt): FFN-up 414 -> 477
+// TFLOP/s, classifier 415 -> 498; ahead from ~5/8 of the CUs covered (384 tokens), behind below that (the launcher decides).
+// (Staging two stores behind each MFMA group instead of ahead of the step's first: 476 against 498 -- not kept.)
+// FFN-up: a strip is 64 hidden units -- rows 0..63 of its image are w1's, 64..127 w3's -- so a workgroup covers 256 of them.
+// fp8 and gf4 weights (an fp16 step of A is 128 bytes per row: the two rings would not fit the LDS).
+template <int EPI>
+struct PfBig {
+	static constexpr int UNITS = EPI == PF_EPI_FFN_UP ? 256 : 512, TOKENS = 128;
+};
+template <int DB>
+struct PfBigA {
+	static constexpr int BR = 64 * DB / 8;      // bytes of a row per step: 32 (gf4), 64 (fp8)
+	static constexpr int PR = BR / 16;          // 16-byte pieces per row
+	static constexpr int RS = BR + 16;          // row stride of the image
+	static constexpr int STRIP = 128 * RS;
+	static constexpr int A_SLOT = 4 * STRIP, B_SLOT = 32 * 1024;
+	static constexpr int EPI_BYTES = 8 * 32 * (32 * 4 + 4) * 4; // the store epilogue's eight wave-private images (pf_epilogue_rows)
+	static constexpr int LDS_BYTES = 2 * (A_SLOT + B_SLOT) > EPI_BYTES ? 2 * (A_SLOT + B_SLOT) : EPI_BYTES;
+};
+
+template <int DB, int EPI>
+__global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
+	static_assert(DB == 8 || DB == 4, "k_pf_gemm_big: fp8 and gf4 weights");
+	static_assert(EPI == PF_EPI_FFN_UP || EPI == PF_EPI_STORE, "k_pf_gemm_big: the FFN-up and the plain store");
+	constexpr int G = Fmt<DB>::G;
+	constexpr int P = 32 / G, OPP = G / 8;
+	constexpr int NA = 4, NC = 2;
+	constexpr int PR = PfBigA<DB>::PR, RS = PfBigA<DB>::RS, RPL = 64 / PR;
+	constexpr int NQ = 64 / RPL; // wave-loads of A per wave and step (its 64 rows of the strip)
+	constexpr int A_SLOT = PfBigA<DB>::A_SLOT, B_SLOT = PfBigA<DB>::B_SLOT, STRIP = PfBigA<DB>::STRIP;
+	extern __shared__ u32x4 pfb_lds[];
+	unsigned char* const lds = (unsigned char*)pfb_lds;
+	u32x4(*bst)[32][64] = (u32x4(*)[32][64])lds; // [2][token group (4) x MFMA (4) x hi, lo][64]
+	unsigned char* const abase = lds + 2 * B_SLOT;
+
+	const int lane = lane_id(), wave = wave_id();
+	const int j = lane & 31, kk = lane >> 5;
+	const int strip = wave & 3, half = wave >> 2;
+	const int ny = a.ncols; // 128-token columns
+	const int idx = blockIdx.x >> 3;
+	const int bx = (blockIdx.x & 7) + 8 * (idx / ny), by = idx % ny; // the XCD-aware order of k_pf_gemm_wide
+	if (bx * PfBig<EPI>::UNITS >= a.M) {
+		return;
+	}
+	const int unit_wg = bx * PfBig<EPI>::UNITS, tok_wg = by * 128;
+	const size_t row_bytes = (size_t)a.K * DB / 8;
+	const int row_pieces = (int)(row_bytes / 16);
+	const int nsteps = pf_steps(a.K);
+
+	// this wave stages rows half * 64 .. + 63 of its strip's image: wave-load q covers rows q * RPL + lane / PR, piece lane % PR
+	const int apiece = lane % PR;
+	const unsigned char* rowq[NQ];
+#pragma unroll
+	for (int q = 0; q < NQ; ++q) {
+		const int r = half * 64 + q * RPL + lane / PR;
+		if constexpr (EPI == PF_EPI_FFN_UP) {
+			rowq[q] = (const unsigned char*)(half ? a.w1 : a.w0) + (size_t)min(unit_wg + strip * 64 + (r & 63), a.M - 1) * row_bytes;
+		} else {
+			rowq[q] = (const unsigned char*)a.w0 + (size_t)min(unit_wg + strip * 128 + r, a.M - 1) * row_bytes;
+		}
+	}
+	const float4* xg = a.xin + (size_t)(tok_wg >> 5) * nsteps * 512 + lane;
+
+	u32x4 fa[NQ], fb[4];
+	auto load = [&](int sc) { // clamped, never branched on
+		const int scc = min(sc, nsteps - 1);
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			const int row = wave * 4 + r;
+			fb[r] = *(const u32x4*)(xg + ((size_t)(row >> 3) * nsteps + scc) * 512 + (row & 7) * 64);
+		}
+		const int piece = min(scc * PR + apiece, row_pieces - 1);
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			fa[q] = __builtin_nontemporal_load((gptr16)rowq[q] + piece);
+		}
+	};
+	auto stage = [&](int slot, int sc) {
+#pragma unroll
+		for (int r = 0; r < 4; ++r) {
+			bst[slot][wave * 4 + r][lane] = fb[r];
+		}
+		unsigned char* img = abase + slot * A_SLOT + strip * STRIP;
+		const bool valid = sc * PR + apiece < row_pieces; // ragged rows: pieces past the row's end multiply as zeros
+#pragma unroll
+		for (int q = 0; q < NQ; ++q) {
+			*(u32x4*)(img + (half * 64 + q * RPL + lane / PR) * RS + apiece * 16) = valid ? fa[q] : (u32x4){0u, 0u, 0u, 0u};
+		}
+	};
+
+	f32x16 acc[NA][NC];
+#pragma unroll
+	for (int n = 0; n < NA; ++n) {
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+#pragma unroll
+			for (int r = 0; r < 16; ++r) {
+				acc[n][c][r] = 0.f;
+			}
+		}
+	}
+	// step s out of ring slot SLOT (a compile-time constant: the loop is unrolled by two, so the stores into the other slot are
+	// visibly disjoint from this step's reads)
+	auto step = [&](auto SLOT, int s) {
+		constexpr int slot = decltype(SLOT)::value;
+		if (s + 1 < nsteps) {
+			stage(slot ^ 1, s + 1); // fetched during the step before
+		}
+		load(s + 2);
+		__builtin_amdgcn_sched_barrier(0);
+		const unsigned char* img = abase + slot * A_SLOT + strip * STRIP;
+		u32x4 w[NA][P];
+#pragma unroll
+		for (int n = 0; n < NA; ++n) {
+#pragma unroll
+			for (int i = 0; i < P; ++i) {
+				w[n][i] = *(const u32x4*)(img + (32 * n + j) * RS + (kk * P + i) * 16);
+			}
+		}
+		// B operands in halves of an MFMA group -- the two token tiles of (m, hi) or (m, lo) -- asked for one half-group (8 MFMAs, 256
+		// matrix-core cycles: an LDS round trip) ahead: a double buffer of 2 x 2 operands, not 2 x 4 (the kernel sits at the 256-register
+		// budget of two waves per SIMD)
+		u32x4 bq[2][NC];
+		auto read_b = [&](u32x4(&q)[NC], int g) { // g = 2 m + (hi: 0, lo: 1)
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+				q[c] = bst[slot][(half * 2 + c) * 8 + g][lane];
+			}
+		};
+		read_b(bq[0], 0);
+		f16x8 wa[NA];
+#pragma unroll
+		for (int g = 0; g < 8; ++g) {
+			if (g + 1 < 8) {
+				read_b(bq[(g + 1) & 1], g + 1);
+			}
+			if ((g & 1) == 0) {
+#pragma unroll
+				for (int n = 0; n < NA; ++n) {
+					wa[n] = pf_operand<DB>(w[n][(g >> 1) / OPP], (g >> 1) % OPP);
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int n = 0; n < NA; ++n) {
+					acc[n][c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[n], __builtin_bit_cast(f16x8, bq[g & 1][c]), acc[n][c], 0, 0, 0);
+				}
+			}
+		}
+		// A pieces + 2 reads | 2 reads, 8 MFMA | ... (seven times) | 8 MFMA
+		__builtin_amdgcn_sched_group_barrier(0x100, NA * P + NC, 0);
+#pragma unroll
+		for (int g = 0; g < 7; ++g) {
+			__builtin_amdgcn_sched_group_barrier(0x100, NC, 0);
+			__builtin_amdgcn_sched_group_barrier(0x008, NA * NC, 0);
+		}
+		__builtin_amdgcn_sched_group_barrier(0x008, NA * NC, 0);
+		__syncthreads();
+	};
+
+	load(0);
+	stage(0, 0);
+	load(1);
+	__syncthreads();
+	for (int s = 0; s < nsteps; s += 2) {
+		step(std::integral_constant<int, 0>(), s);
+		if (s + 1 < nsteps) {
+			step(std::integral_constant<int, 1>(), s + 1);
+		}
+	}
+
+	const int tok0 = tok_wg + half * 64;
+	if constexpr (EPI == PF_EPI_FFN_UP) {
+		// accumulators n and n + 2 are w1 and w3 of hidden units unit0 + 32 n ..; the fragment-major stores are contiguous as they are
+		const int unit0 = unit_wg + strip * 64, hsteps = pf_steps(a.M);
+#pragma unroll
+		for (int c = 0; c < NC; ++c) {
+			const int token = tok0 + 32 * c + j;
+			if (token >= a.nb) {
+				continue;
+			}
+#pragma unroll
+			for (int n = 0; n < 2; ++n) {
+#pragma unroll
+				for (int g = 0; g < 4; ++g) {
+					const int ub = unit0 + 32 * n + 8 * g + 4 * kk;
+					if (ub >= a.M) {
+						continue;
+					}
+					float h[4];
+#pragma unroll
+					for (int e = 0; e < 4; ++e) {
+						const float up = acc[n][c][4 * g + e], gt = acc[n + 2][c][4 * g + e];
+						h[e] = (a.gelu ? act_gelu(up) : act_silu(up)) * gt; // src/infer.c:440-450
+					}
+					pf_store4(a.out, token, ub, hsteps, h);
+				}
+			}
+		}
+	} else {
+		const int unit0 = unit_wg + strip * 128;
+		if (a.M & 3) { // a vocabulary that is not a multiple of 4: rows are not 16-byte aligned
+			pf_epilogue<16, EPI, NA, NC>(a, acc, unit0, tok0, j, kk);
+		} else { // the rings are free: every wave has passed the loop's last barrier
+			pf_epilogue_rows<16, EPI, NA>(a, acc, unit0, tok0, (float*)lds + wave * (32 * (32 * NA + 4)));
 		}
 	}
 }

@@ -160,7 +160,7 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	const size_t wbytes = (size_t)M * K * dbits / 8;
 	void* dw = upload_hip((void*)w, wbytes);
 	float* dx = (float*)upload_hip((void*)x, (size_t)nb * K * sizeof(float));
-	const size_t fbytes = (size_t)cols * 64 * pf_steps(K) * 64 * sizeof(float);
+	const size_t fbytes = (size_t)((nb + 127) / 128 * 128) * pf_steps(K) * 64 * sizeof(float); // (whole 128-token columns: the big form's)
 	void* dxf = dev_alloc(fbytes);
 	HIP_CHECK(hipMemsetAsync(dxf, 0, fbytes, g_stream));
 	float* dout = (float*)dev_alloc((size_t)nb * M * sizeof(float));
@@ -172,7 +172,7 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	a.ncols = cols, a.ksplit = 1;
 	constexpr int UNITS = PfWide<PF_EPI_STORE>::UNITS;
 	const int nx = (M + UNITS - 1) / UNITS, tiles = 8 * ((nx + 7) / 8) * cols;
-	if (form >= 2) {
+	if (form >= 2 && form != 9) {
 		CALM_REQUIRE(form <= 8 && pf_steps(K) >= form, "K ranges: 2..8, at least one step each");
 		a.ksplit = form;
 		a.partial = (float*)dev_alloc((size_t)tiles * form * 16384 * sizeof(float));
@@ -181,7 +181,16 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	}
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		if (form >= 1) {
+		if (form == 9) { // k_pf_gemm_big (fp8 / gf4)
+			if constexpr (DB != 16) {
+				a.ncols = (nb + 127) / 128;
+				auto kern = k_pf_gemm_big<DB, PF_EPI_STORE>;
+				allow_lds(kern, PfBigA<DB>::LDS_BYTES);
+				hipLaunchKernelGGL(kern, dim3(pf_wide_grid((M + 511) / 512, a.ncols)), dim3(512), PfBigA<DB>::LDS_BYTES, g_stream, a);
+			} else {
+				CALM_REQUIRE(false, "the big form takes fp8 / gf4 weights");
+			}
+		} else if (form >= 1) {
 			auto kern = k_pf_gemm_wide<DB, 16, PF_EPI_STORE, 1>;
 			allow_lds(kern, PfWideA<DB>::LDS_BYTES);
 			hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nx, cols, a.ksplit)), dim3(256), PfWideA<DB>::LDS_BYTES, g_stream, a);
@@ -195,7 +204,7 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	});
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, dout, (size_t)nb * M * sizeof(float));
-	if (form >= 2) {
+	if (form >= 2 && form != 9) {
 		unsigned left = 0; // every tile's counter is back at zero
 		std::vector<unsigned> cnt(tiles);
 		download_hip(cnt.data(), a.tile_count, (size_t)tiles * sizeof(unsigned));

@@ -106,7 +106,7 @@ float* decode_sample_hip(struct Transformer* transformer, int token, int pos, in
 /* Batched prompt ingestion: the KV-cache effect of
  *     for (i = 0; i < n; ++i) forward_hip(transformer, tokens[i], pos + i, FF_UPDATE_KV_ONLY);
  * i.e. of the reference's serial prompt loop (src/run.c:208,216-218; README.md:80 "prompt processing is
- * serial"), computed up to 1024 tokens at a time: weights are streamed once per chunk and the multiply-adds run on
+ * serial"), computed up to 2048 tokens at a time (mixture-of-experts models: 1024): weights are streamed once per chunk and the multiply-adds run on
  * the f16 matrix cores with the fp32 activations carried as hi + lo binary16 (every product exact, fp32 accumulation:
  * 3-7e-7 per GEMM), so the cache rows agree with the serial path to fp32 rounding.  A chunk in which an activation leaves the binary16 range (beyond +-65504, or NaN)
  * is redone token by token through the serial fp32 decode path inside the call (knob "pf_redone" counts such tokens).
@@ -179,7 +179,10 @@ const char* calm_hip_device_name(void);
  *   "skew"      percent more of the FFN up-projection's tasks for the first-dispatched workgroup of each CU (default 14; 0 = even)
  *   "qkv_half" / "out_one" / "down_one" / "down_u" / "down_u4": tile-shape overrides of single kernels (0 = the launchers' rules by
  *               matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
- *   "pf_wide" / "pf_attn_mfma" / "pf_skinny": forms of the prompt-ingestion kernels (1 = default forms)
+ *   "pf_wide" / "pf_big" / "pf_attn_mfma" / "pf_skinny": forms of the prompt-ingestion kernels (1 = default forms; "pf_big" 2: the
+ *       512-unit x 128-token GEMM form for every dense fp8 / gf4 FFN-up and classifier whatever its grid -- a test switch)
+ *   "pf_chunk": tokens per prompt chunk of a dense model, 1024 ... 2048 in steps of 128 (default 2048; read when a model's prompt
+ *       buffers are allocated, i.e. at its first prefill_hip call; mixture-of-experts models always take 1024)
  *   "stage"     multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip)
  * Queries (value ignored): "stages" (pipeline stages of this process), "stage_device" (value = stage -> its device), "pf_redone"
  * (prompt tokens prefill_hip sent back through the serial path), "handoffs" / "handoff_ns" (stage-to-stage copies timed under "prof"

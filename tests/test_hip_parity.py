@@ -647,6 +647,38 @@ def test_prefill_equals_the_serial_prompt_loop(hiplib, case, kvbits):
             o8.close()
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_prefill_big_gemm_form_on_every_golden_shape(hiplib, case):
+    """calm_hip_configure("pf_big", 2): the FFN-up and the classifier of every dense fp8 / gf4 chunk through k_pf_gemm_big (512 units x
+    128 tokens per workgroup) whatever the grid -- ragged hidden sizes, partial 128-token columns, gelu, parallel residual -- against
+    the reference's golden logits and against the same prompt with the form off; scored log-probabilities of both agree."""
+    model, z = load_golden(case)
+    toks = [int(t) for t in z["tokens"]]
+    T = len(toks)
+    big = HipBackend(model)
+    plain = HipBackend(model)
+    try:
+        assert hiplib.calm_hip_configure(b"pf_big", 2) == 1
+        try:
+            big.prefill(toks[: T - 1], 0)
+            lb = big.forward(toks[T - 1], T - 1, 0).copy()
+            lpb = big.prefill_logprobs(toks, 0)
+        finally:
+            hiplib.calm_hip_configure(b"pf_big", 0)
+        try:
+            plain.prefill(toks[: T - 1], 0)
+            lp = plain.forward(toks[T - 1], T - 1, 0).copy()
+            lpp = plain.prefill_logprobs(toks, 0)
+        finally:
+            hiplib.calm_hip_configure(b"pf_big", 1)
+        assert rel_err(lb, z["logits"][T - 1]) < LOGIT_TOL, rel_err(lb, z["logits"][T - 1])
+        assert rel_err(lb, lp) < 2e-5, rel_err(lb, lp)
+        assert np.isfinite(lpb).all() and np.abs(lpb - lpp).max() < 1e-4 * max(1.0, float(np.abs(lpp).max()))
+    finally:
+        big.close()
+        plain.close()
+
+
 def test_prefill_falls_back_to_the_serial_path_when_an_activation_leaves_binary16(hiplib):
     """The prompt GEMMs carry fp32 activations as hi + lo binary16 (range +-65504).  A model whose FFN hidden values exceed that
     (weights 100 x the usual scale: act(w1 x) * (w3 x) ~ 1e5..1e6) must not silently saturate: the chunk raises the range flag
@@ -812,9 +844,10 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
 @pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16"), ("mixtral-8x7b", "fp8")])
 def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
     """BASELINE widths, one layer, a 1100-token prompt (one full 1024-token chunk + 76): every GEMM of the full chunk runs in
-    the wide form (k_pf_gemm_wide: B staged through LDS, no K split), the short chunk in the K-split form.  Against serial
-    ingestion on the same backend, against the K-split form alone (calm_hip_configure("pf_wide", 0)), and the scored
-    log-probabilities of both forms against each other."""
+    the wide form (k_pf_gemm_wide: B staged through LDS, no K split) -- the FFN-up and the classifier of the dense fp8 / gf4 models in
+    the big form (k_pf_gemm_big: 512 units x 128 tokens per workgroup) -- the short chunk in the K-split form.  Against serial
+    ingestion on the same backend, against the K-split form alone (calm_hip_configure("pf_wide", 0) and ("pf_big", 0)), and the
+    scored log-probabilities of both against each other."""
     spec = cf.SPECS[name]
     tensors, md = cf.synth_model_big(spec, dtype, seed=10, n_layers=1)
     model = HostModel(tensors, md, context=1280)
@@ -833,12 +866,14 @@ def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
         lw = wide.forward(toks[n], n, 0).copy()
         lpw = wide.prefill_logprobs(toks[: n + 1], 0)
         hiplib.calm_hip_configure(b"pf_wide", 0)
+        assert hiplib.calm_hip_configure(b"pf_big", 0) == 1
         try:
             ksplit.prefill(toks[:n], 0)
             lk = ksplit.forward(toks[n], n, 0).copy()
             lpk = ksplit.prefill_logprobs(toks[: n + 1], 0)
         finally:
             hiplib.calm_hip_configure(b"pf_wide", 1)
+            hiplib.calm_hip_configure(b"pf_big", 1)
         assert rel_err(lw, ls) < 2e-4, rel_err(lw, ls)
         assert rel_err(lk, ls) < 2e-4, rel_err(lk, ls)
         assert np.isfinite(lpw).all() and np.abs(lpw - lpk).max() < 2e-3 * max(1.0, float(np.abs(lpk).max()))

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 GEMM_TOL = 5e-6  # max |err| / max |y|: the fp32 matvec's own rounding at these lengths; the hi + lo split adds ~1e-7
 
-FORMS = {"ksplit-1": -1, "ksplit-2": 0, "ksplit-3": -3, "wide": 1, "wide/2": 2, "wide/5": 5, "wide/8": 8}
+FORMS = {"ksplit-1": -1, "ksplit-2": 0, "ksplit-3": -3, "wide": 1, "wide/2": 2, "wide/5": 5, "wide/8": 8, "big": 9}
 
 
 def gemm(hiplib, dtype, w, x, M, K, form):
@@ -38,6 +38,8 @@ def oracle_gemm(dtype, w, x, M, K):
 def test_prompt_gemm_matches_the_oracle(hiplib, dtype, form, M, K, nb):
     if K % (128 // cf.DBITS[dtype]):
         pytest.skip("row not a whole number of 16-byte pieces for this format")
+    if form == "big" and dtype == "fp16":
+        pytest.skip("the big form takes fp8 / gf4 weights (an fp16 step of A does not fit its rings)")
     rng = np.random.default_rng(M + K + nb)
     w = _rand_w(rng, M, K, dtype)
     x = rng.standard_normal((nb, K)).astype(np.float32)
@@ -88,5 +90,5 @@ def test_full_width_shapes(hiplib):
         w = _rand_w(rng, M, K, "fp8")
         x = rng.standard_normal((nb, K)).astype(np.float32)
         want = oracle_gemm("fp8", w, x, M, K)
-        for form in ("ksplit-2", "wide", "wide/5"):
+        for form in ("ksplit-2", "wide", "wide/5", "big"):
             assert rel_err(gemm(hiplib, "fp8", w, x, M, K, FORMS[form]), want) < GEMM_TOL, (K, form)
