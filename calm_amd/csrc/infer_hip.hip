@@ -1050,7 +1050,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 // ---------------------------------------------------------------- batched prompt ingestion -----
 
-constexpr size_t PF_SPLIT_SLOTS = 768; // partial tiles of a split launch (tiles x ranges: about one per CU, x 2-3 for grid padding)
+constexpr size_t PF_SPLIT_SLOTS = 1280; // 64-KiB partial tiles of a split launch (tiles x ranges: about one per CU, x 2-3 for grid padding; the big form's are four each)
 constexpr int PF_SPLIT_TILES = 4096;
 
 void pf_alloc(Ctx* c) {
@@ -1211,14 +1211,28 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		// The big form (prefill.hip.h k_pf_gemm_big: 512 units x 128 tokens per 8-wave workgroup, one per CU) for the GEMMs with enough
 		// units to fill the chip with such tiles -- the FFN-up and the classifier of a dense model from ~384 tokens: ahead of the wide
 		// form from 5/8 of the CUs covered (+6...20 %), behind below that (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt).
-		// fp8 / gf4 weights.  Knob "pf_big": 0 off, 2 whatever the grid (tests).
-		if constexpr ((epi == PF_EPI_FFN_UP || epi == PF_EPI_STORE) && DB != 16) {
+		// fp8 / gf4 weights.  Knob "pf_big": 0 off, 2 whatever the grid (tests), 3 without the residual GEMM's form (A/B).
+		// The residual GEMM with long rows and few units (the FFN-down: 8 x 8 such tiles at 1024 tokens) takes it with K cut into 2-4 ranges,
+		// one workgroup each, while a range keeps >= 48 steps (316 -> us at 1024 tokens).
+		if constexpr ((epi == PF_EPI_FFN_UP || epi == PF_EPI_STORE || epi == PF_EPI_RESID) && DB != 16) {
 			const int nxb = (a.M + PfBig<epi>::UNITS - 1) / PfBig<epi>::UNITS, ncb = (a.nb + PfBig<epi>::TOKENS - 1) / PfBig<epi>::TOKENS;
-			if (g_pf_big && !a.col_expert && (g_pf_big >= 2 || (long)nxb * ncb * 8 >= (long)g_ncu * 5)) {
-				a.ncols = ncb, a.ksplit = 1;
+			int kr = 1;
+			if (epi == PF_EPI_RESID && g_pf_big == 3) {
+				kr = 0; // (A/B switch: the big form without the residual GEMM's ranges)
+			} else if (epi == PF_EPI_RESID) {
+				kr = g_ncu / (nxb * ncb);
+				kr = kr > 4 ? 4 : kr;
+				kr = kr > pf_steps(a.K) / 48 ? pf_steps(a.K) / 48 : kr;
+				const size_t tiles_b = (size_t)8 * ((nxb + 7) / 8) * ncb;
+				if (kr < 2 || tiles_b * kr * 4 > PF_SPLIT_SLOTS || tiles_b > (size_t)PF_SPLIT_TILES) {
+					kr = 0; // (the residual GEMM only in ranges: unsplit, its 4096 units are a quarter of the chip)
+				}
+			}
+			if (g_pf_big && kr >= 1 && !a.col_expert && (g_pf_big >= 2 || (long)nxb * ncb * kr * 8 >= (long)g_ncu * 5)) {
+				a.ncols = ncb, a.ksplit = kr, a.partial = c->pf_partial, a.tile_count = c->pf_tile_count;
 				auto kern = k_pf_gemm_big<DB, epi>;
 				allow_lds(kern, PfBigA<DB>::LDS_BYTES);
-				hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nxb, ncb)), dim3(512), PfBigA<DB>::LDS_BYTES, g_stream, a);
+				hipLaunchKernelGGL(kern, dim3(pf_wide_grid(nxb, ncb, kr)), dim3(512), PfBigA<DB>::LDS_BYTES, g_stream, a);
 				return;
 			}
 		}

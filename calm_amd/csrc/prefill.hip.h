@@ -1636,6 +1636,7 @@ __global__ __launch_bounds__(256, 2) void k_pf_gemm_wide(PfGemmArgs a) {
 // Measured on the fp8 shapes at 1024 tokens (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt): FFN-up 414 -> 477
 // TFLOP/s, classifier 415 -> 498; ahead from ~5/8 of the CUs covered (384 tokens), behind below that (the launcher decides).
 // (Staging two stores behind each MFMA group instead of ahead of the step's first: 476 against 498 -- not kept.)
+// Long rows and few units (the FFN-down): K cut into ranges across workgroups exactly as in k_pf_gemm_wide (a.ksplit).
 // FFN-up: a strip is 64 hidden units -- rows 0..63 of its image are w1's, 64..127 w3's -- so a workgroup covers 256 of them.
 // fp8 and gf4 weights (an fp16 step of A is 128 bytes per row: the two rings would not fit the LDS).
 template <int EPI>
@@ -1656,7 +1657,7 @@ struct PfBigA {
 template <int DB, int EPI>
 __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 	static_assert(DB == 8 || DB == 4, "k_pf_gemm_big: fp8 and gf4 weights");
-	static_assert(EPI == PF_EPI_FFN_UP || EPI == PF_EPI_STORE, "k_pf_gemm_big: the FFN-up and the plain store");
+	static_assert(EPI == PF_EPI_FFN_UP || EPI == PF_EPI_STORE || EPI == PF_EPI_RESID, "k_pf_gemm_big: the FFN-up, the plain store, the residual GEMM");
 	constexpr int G = Fmt<DB>::G;
 	constexpr int P = 32 / G, OPP = G / 8;
 	constexpr int NA = 4, NC = 2;
@@ -1671,9 +1672,9 @@ __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 	const int lane = lane_id(), wave = wave_id();
 	const int j = lane & 31, kk = lane >> 5;
 	const int strip = wave & 3, half = wave >> 2;
-	const int ny = a.ncols; // 128-token columns
+	const int ny = a.ncols, KS = a.ksplit; // 128-token columns; ranges of K (one workgroup each, folded by the last to arrive: as k_pf_gemm_wide)
 	const int idx = blockIdx.x >> 3;
-	const int bx = (blockIdx.x & 7) + 8 * (idx / ny), by = idx % ny; // the XCD-aware order of k_pf_gemm_wide
+	const int bx = (blockIdx.x & 7) + 8 * (idx / (ny * KS)), by = idx % ny, ks = (idx / ny) % KS; // the XCD-aware order of k_pf_gemm_wide
 	if (bx * PfBig<EPI>::UNITS >= a.M) {
 		return;
 	}
@@ -1681,6 +1682,7 @@ __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 	const size_t row_bytes = (size_t)a.K * DB / 8;
 	const int row_pieces = (int)(row_bytes / 16);
 	const int nsteps = pf_steps(a.K);
+	const int s_begin = (int)((long)ks * nsteps / KS), s_end = (int)((long)(ks + 1) * nsteps / KS); // this workgroup's steps
 
 	// this wave stages rows half * 64 .. + 63 of its strip's image: wave-load q covers rows q * RPL + lane / PR, piece lane % PR
 	const int apiece = lane % PR;
@@ -1738,7 +1740,7 @@ __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 	// visibly disjoint from this step's reads)
 	auto step = [&](auto SLOT, int s) {
 		constexpr int slot = decltype(SLOT)::value;
-		if (s + 1 < nsteps) {
+		if (s + 1 < s_end) {
 			stage(slot ^ 1, s + 1); // fetched during the step before
 		}
 		load(s + 2);
@@ -1794,14 +1796,68 @@ __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 		__syncthreads();
 	};
 
-	load(0);
-	stage(0, 0);
-	load(1);
+	load(s_begin);
+	stage(0, s_begin);
+	load(s_begin + 1);
 	__syncthreads();
-	for (int s = 0; s < nsteps; s += 2) {
+	for (int s = s_begin; s < s_end; s += 2) {
 		step(std::integral_constant<int, 0>(), s);
-		if (s + 1 < nsteps) {
+		if (s + 1 < s_end) {
 			step(std::integral_constant<int, 1>(), s + 1);
+		}
+	}
+	if (KS > 1) {
+		// Partial tile out, count in; the last workgroup of the tile to arrive folds all of them, its own included, in range order:
+		// the hand-off of k_pf_gemm_wide (write-through stores, drained, one relaxed agent-scope arrival; agent-scope loads on the
+		// folding side -- see the comment there), 256 KB per workgroup here
+		__shared__ unsigned arrived;
+		constexpr int PART = NA * NC * 16 * 64; // floats per wave
+		const int tile = bx * ny + by;
+		float* mine = a.partial + (((size_t)tile * KS + ks) * 8 + wave) * PART + lane;
+#pragma unroll
+		for (int n = 0; n < NA; ++n) {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					__hip_atomic_store(mine + ((n * NC + c) * 16 + r) * 64, acc[n][c][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+			}
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			arrived = __hip_atomic_fetch_add(a.tile_count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__syncthreads();
+		if (arrived != (unsigned)KS - 1) {
+			return;
+		}
+		if (threadIdx.x == 0) {
+			__hip_atomic_store(a.tile_count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next launch
+		}
+#pragma unroll
+		for (int n = 0; n < NA; ++n) {
+#pragma unroll
+			for (int c = 0; c < NC; ++c) {
+#pragma unroll
+				for (int r = 0; r < 16; ++r) {
+					acc[n][c][r] = 0.f;
+				}
+			}
+		}
+		for (int p = 0; p < KS; ++p) {
+			const float* src = a.partial + (((size_t)tile * KS + p) * 8 + wave) * PART + lane;
+#pragma unroll
+			for (int n = 0; n < NA; ++n) {
+#pragma unroll
+				for (int c = 0; c < NC; ++c) {
+#pragma unroll
+					for (int r = 0; r < 16; ++r) {
+						acc[n][c][r] += __hip_atomic_load(src + ((n * NC + c) * 16 + r) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+				}
+			}
 		}
 	}
 

@@ -172,7 +172,17 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	a.ncols = cols, a.ksplit = 1;
 	constexpr int UNITS = PfWide<PF_EPI_STORE>::UNITS;
 	const int nx = (M + UNITS - 1) / UNITS, tiles = 8 * ((nx + 7) / 8) * cols;
-	if (form >= 2 && form != 9) {
+	const int big_ks = form >= 90 ? form - 90 : (form == 9 ? 1 : 0); // 9: k_pf_gemm_big; 92 .. 98: with K cut into 2 .. 8 ranges
+	size_t big_tiles = 0;
+	if (big_ks > 1) {
+		CALM_REQUIRE(big_ks <= 8 && pf_steps(K) >= big_ks, "K ranges: 2..8, at least one step each");
+		big_tiles = (size_t)8 * (((M + 511) / 512 + 7) / 8) * ((nb + 127) / 128);
+		a.ksplit = big_ks;
+		a.partial = (float*)dev_alloc(big_tiles * big_ks * 65536 * sizeof(float));
+		a.tile_count = (unsigned*)dev_alloc(big_tiles * sizeof(unsigned));
+		HIP_CHECK(hipMemsetAsync(a.tile_count, 0, big_tiles * sizeof(unsigned), g_stream));
+	}
+	if (form >= 2 && !big_ks) {
 		CALM_REQUIRE(form <= 8 && pf_steps(K) >= form, "K ranges: 2..8, at least one step each");
 		a.ksplit = form;
 		a.partial = (float*)dev_alloc((size_t)tiles * form * 16384 * sizeof(float));
@@ -181,12 +191,12 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	}
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
-		if (form == 9) { // k_pf_gemm_big (fp8 / gf4)
+		if (big_ks) { // k_pf_gemm_big (fp8 / gf4)
 			if constexpr (DB != 16) {
 				a.ncols = (nb + 127) / 128;
 				auto kern = k_pf_gemm_big<DB, PF_EPI_STORE>;
 				allow_lds(kern, PfBigA<DB>::LDS_BYTES);
-				hipLaunchKernelGGL(kern, dim3(pf_wide_grid((M + 511) / 512, a.ncols)), dim3(512), PfBigA<DB>::LDS_BYTES, g_stream, a);
+				hipLaunchKernelGGL(kern, dim3(pf_wide_grid((M + 511) / 512, a.ncols, big_ks)), dim3(512), PfBigA<DB>::LDS_BYTES, g_stream, a);
 			} else {
 				CALM_REQUIRE(false, "the big form takes fp8 / gf4 weights");
 			}
@@ -204,7 +214,17 @@ extern "C" void calm_hip_test_pf_gemm(int dbits, const void* w, const float* x, 
 	});
 	HIP_CHECK(hipGetLastError());
 	download_hip(out, dout, (size_t)nb * M * sizeof(float));
-	if (form >= 2 && form != 9) {
+	if (big_ks > 1) {
+		std::vector<unsigned> cnt(big_tiles);
+		download_hip(cnt.data(), a.tile_count, big_tiles * sizeof(unsigned));
+		unsigned left = 0;
+		for (unsigned v : cnt) {
+			left |= v;
+		}
+		CALM_REQUIRE(left == 0, "a tile counter was not reset");
+		free_hip(a.partial), free_hip(a.tile_count);
+	}
+	if (form >= 2 && !big_ks) {
 		unsigned left = 0; // every tile's counter is back at zero
 		std::vector<unsigned> cnt(tiles);
 		download_hip(cnt.data(), a.tile_count, (size_t)tiles * sizeof(unsigned));

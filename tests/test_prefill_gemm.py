@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 
 GEMM_TOL = 5e-6  # max |err| / max |y|: the fp32 matvec's own rounding at these lengths; the hi + lo split adds ~1e-7
 
-FORMS = {"ksplit-1": -1, "ksplit-2": 0, "ksplit-3": -3, "wide": 1, "wide/2": 2, "wide/5": 5, "wide/8": 8, "big": 9}
+FORMS = {"ksplit-1": -1, "ksplit-2": 0, "ksplit-3": -3, "wide": 1, "wide/2": 2, "wide/5": 5, "wide/8": 8, "big": 9, "big/2": 92, "big/4": 94}
 
 
 def gemm(hiplib, dtype, w, x, M, K, form):
@@ -38,7 +38,7 @@ def oracle_gemm(dtype, w, x, M, K):
 def test_prompt_gemm_matches_the_oracle(hiplib, dtype, form, M, K, nb):
     if K % (128 // cf.DBITS[dtype]):
         pytest.skip("row not a whole number of 16-byte pieces for this format")
-    if form == "big" and dtype == "fp16":
+    if form.startswith("big") and dtype == "fp16":
         pytest.skip("the big form takes fp8 / gf4 weights (an fp16 step of A does not fit its rings)")
     rng = np.random.default_rng(M + K + nb)
     w = _rand_w(rng, M, K, dtype)
@@ -49,7 +49,7 @@ def test_prompt_gemm_matches_the_oracle(hiplib, dtype, form, M, K, nb):
     assert rel_err(got, want) < GEMM_TOL, rel_err(got, want)
 
 
-@pytest.mark.parametrize("form", ["wide/2", "wide/8"])
+@pytest.mark.parametrize("form", ["wide/2", "wide/8", "big/4"])
 def test_ranges_fold_in_a_fixed_order(hiplib, form):
     """K cut into ranges: whichever workgroup arrives last folds the partial tiles in range order -- two runs are bit-equal"""
     rng = np.random.default_rng(3)
@@ -90,5 +90,5 @@ def test_full_width_shapes(hiplib):
         w = _rand_w(rng, M, K, "fp8")
         x = rng.standard_normal((nb, K)).astype(np.float32)
         want = oracle_gemm("fp8", w, x, M, K)
-        for form in ("ksplit-2", "wide", "wide/5", "big"):
+        for form in ("ksplit-2", "wide", "wide/5", "big", "big/2"):
             assert rel_err(gemm(hiplib, "fp8", w, x, M, K, FORMS[form]), want) < GEMM_TOL, (K, form)
