@@ -843,9 +843,10 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
 
 @pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16"), ("mixtral-8x7b", "fp8")])
 def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
-    """BASELINE widths, one layer, a 1100-token prompt (one full 1024-token chunk + 76): every GEMM of the full chunk runs in
-    the wide form (k_pf_gemm_wide: B staged through LDS, no K split) -- the FFN-up and the classifier of the dense fp8 / gf4 models in
-    the big form (k_pf_gemm_big: 512 units x 128 tokens per workgroup) -- the short chunk in the K-split form.  Against serial
+    """BASELINE widths, one layer, a 1100-token prompt (one chunk for a dense model, 1024 + 76 for the mixture of experts): every GEMM
+    of the long chunk runs in the wide form (k_pf_gemm_wide: B staged through LDS, no K split) -- the FFN-up and the classifier of the dense fp8 / gf4 models in
+    the big form (k_pf_gemm_big: 512 units x 128 tokens per workgroup), as is the FFN-down with K cut into ranges -- a short chunk in the
+    K-split form.  Against serial
     ingestion on the same backend, against the K-split form alone (calm_hip_configure("pf_wide", 0) and ("pf_big", 0)), and the
     scored log-probabilities of both against each other."""
     spec = cf.SPECS[name]
