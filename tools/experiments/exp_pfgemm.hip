@@ -12,9 +12,9 @@
 #include <type_traits>
 #include <vector>
 
-#include "../include/calm_abi.h"
-#include "../calm_amd/csrc/kernels.hip.h"
-#include "../calm_amd/csrc/prefill.hip.h"
+#include "../../include/calm_abi.h"
+#include "../../calm_amd/csrc/kernels.hip.h"
+#include "../../calm_amd/csrc/prefill.hip.h"
 
 using namespace calm;
 
