@@ -105,6 +105,7 @@ int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 6
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
 int g_pf_chunk = PF_NT_DENSE; // tokens per prompt chunk of a dense model (read when a model's prompt buffers are allocated; PF_NT ... PF_NT_DENSE)
+int g_pf_rounds = 1;   // ... the wide form in 2 / 4 ranges of K where its last round of workgroups would be mostly empty (0: whole rows only; A/B switch)
 int g_pf_big = 1;      // ... and the big form (512 units x 128 tokens per workgroup) for the FFN-up / classifier of long chunks (0: never; 2: always, for tests)
 char g_devname[256] = "none";
 
@@ -1050,7 +1051,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 // ---------------------------------------------------------------- batched prompt ingestion -----
 
-constexpr size_t PF_SPLIT_SLOTS = 1280; // 64-KiB partial tiles of a split launch (tiles x ranges: about one per CU, x 2-3 for grid padding; the big form's are four each)
+constexpr size_t PF_SPLIT_SLOTS = 2560; // 64-KiB partial tiles of a split launch (tiles x ranges: about one per CU, x 2-3 for grid padding; the big form's are four each)
 constexpr int PF_SPLIT_TILES = 4096;
 
 void pf_alloc(Ctx* c) {
@@ -1253,6 +1254,28 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 					ks = k;
 				}
 			}
+		} else if (g_pf_rounds) {
+			// Enough tiles -- but the workgroups run in rounds of two per CU, and what is left for the last round runs alone: Mixtral's
+			// grouped FFN-down at 1024 tokens is 1.25 rounds (886 us, 271 TFLOP/s).  Ranges of K (one workgroup each, as above) make the
+			// rounds finer: 2 or 4 where the model below says that saves more than the fold costs (~3 % per range).  A last round that fills
+			// at most half the slots leaves one workgroup per CU, which runs at ~0.6 of a full round's time, not 0.5 (hence nothing for the
+			// QKV GEMM's 1.5 rounds at 2048 tokens: measured 32.0 against 32.4 k tok/s with it split); a grid under one round gains nothing
+			// from ranges at all (TinyLlama's FFN-down: - 5 %).  profiles/r04_prefill.txt.
+			auto cost = [](double r) {
+				const double f = r - floor(r);
+				return floor(r) + (f < 1e-9 ? 0.0 : (f <= 0.5 ? 0.6 : 1.0));
+			};
+			const double r1 = (double)nx * ncols / (2.0 * g_ncu);
+			double best = cost(r1);
+			for (int k = 2; k <= 4 && r1 > 1.0; k *= 2) {
+				if (nsteps / k < 16 || (size_t)tiles * k > PF_SPLIT_SLOTS || tiles > PF_SPLIT_TILES) {
+					break;
+				}
+				const double t = cost(r1 * k) / k * (1.0 + 0.03 * k);
+				if (t < 0.97 * best) {
+					best = t, ks = k;
+				}
+			}
 		}
 		if (g_pf_wide && ks >= 1) {
 			a.ncols = ncols;
@@ -1453,6 +1476,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_pf_wide;
 	} else if (!strcmp(key, "pf_big")) {
 		slot = &g_pf_big;
+	} else if (!strcmp(key, "pf_rounds")) {
+		slot = &g_pf_rounds;
 	} else if (!strcmp(key, "pf_chunk")) {
 		CALM_REQUIRE(value < 0 || (value >= PF_NT && value <= PF_NT_DENSE && value % 128 == 0), "calm_hip_configure(\"pf_chunk\"): 1024 ... 2048 in steps of 128");
 		slot = &g_pf_chunk;

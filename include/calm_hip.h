@@ -181,6 +181,7 @@ const char* calm_hip_device_name(void);
  *               matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
  *   "pf_wide" / "pf_big" / "pf_attn_mfma" / "pf_skinny": forms of the prompt-ingestion kernels (1 = default forms; "pf_big" 2: the
  *       512-unit x 128-token GEMM form for every dense fp8 / gf4 FFN-up and classifier whatever its grid -- a test switch)
+ *   "pf_rounds": 1 = a prompt GEMM whose last round of workgroups would be mostly empty runs in 2 / 4 ranges of K (0: never; A/B switch)
  *   "pf_chunk": tokens per prompt chunk of a dense model, 1024 ... 2048 in steps of 128 (default 2048; read when a model's prompt
  *       buffers are allocated, i.e. at its first prefill_hip call; mixture-of-experts models always take 1024)
  *   "stage"     multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip)

@@ -72,7 +72,8 @@ def main():
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     durs = kernel_durations(args[0])
     total = sum(sum(v) for v in durs.values())
-    alg = json.load(open(sys.argv[sys.argv.index("--bytes") + 1])) if "--bytes" in sys.argv else {}
+    bytes_file = sys.argv[sys.argv.index("--bytes") + 1] if "--bytes" in sys.argv else None
+    alg = json.load(open(bytes_file)) if bytes_file and os.path.exists(bytes_file) else {}  # (commands that never decode write no byte account)
     fetch = pmc_fetch(args[1]) if len(args) > 1 else {}
     fetch_by_base = defaultdict(list)
     for k, v in fetch.items():
