@@ -138,9 +138,11 @@ struct Stager {
 constexpr size_t STAGE_CHUNK = 32u << 20;
 std::map<int, Stager> g_stagers; // per device
 
+void dev_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+
 void staged_upload(void* dst, const void* src, size_t size) {
 	if (size < (1u << 20)) {
-		HIP_CHECK(hipMemcpy(dst, src, size, hipMemcpyHostToDevice));
+		dev_copy_sync(dst, src, size, hipMemcpyHostToDevice);
 		return;
 	}
 	int dev = 0;
@@ -172,6 +174,22 @@ void* dev_alloc(size_t size) {
 	void* p = nullptr;
 	HIP_CHECK(hipMalloc(&p, size + DEV_PAD));
 	return p;
+}
+
+// ONE stream orders everything this library does on a device -- the reference's discipline (src/infer.cu:40,94).  g_stream is created
+// hipStreamNonBlocking, so the NULL stream is NOT ordered against it, and a NULL-stream hipMemset of device memory returns before the
+// fill has run: a fill "ahead of" a g_stream kernel could land after it (round 4's red GPU suite: a zeroed output of a finished
+// x += W.v).  Hence no bare hipMemset / hipMemcpy anywhere under csrc/ (tests/test_abi.py lints for them): fills and copies go through
+// these helpers, on g_stream.  The copies are complete on return (their host side may be a stack object or pageable memory).
+void dev_fill(void* p, int byte, size_t bytes) {
+	HIP_CHECK(hipMemsetAsync(p, byte, bytes, g_stream));
+}
+void dev_zero(void* p, size_t bytes) {
+	dev_fill(p, 0, bytes);
+}
+void dev_copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+	HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, g_stream));
+	HIP_CHECK(hipStreamSynchronize(g_stream));
 }
 
 // compile-time dispatch on a run-time bool: f(std::true_type) / f(std::false_type)
@@ -590,7 +608,7 @@ void launch_ffn_up(Ctx* c, int l) {
 	a.cut = moe == 1 ? 0 : skew_cut(ntasks, (int)grid.x, WG_WAVES);
 	if (moe == 2) {
 		a.moegate = c->gate_part;
-		a.n_experts = c->n_experts | (attn_out_grid<DB>(c) << 8);
+		a.n_experts = c->n_experts | (attn_out_grid<DB>(c) << 8) | (c->gate_ep << 24);
 		a.gate_c = c->gate_mt + (size_t)l * ((size_t)c->dim + 1) * c->gate_ep + (size_t)c->dim * c->gate_ep;
 	}
 	auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, lds, g_stream, a.x, a.norm_w, a.w1, a.w3, a.moegate, a.dim, a.hidden, a.n_experts, a.n_active, a); };
@@ -1063,7 +1081,7 @@ void pf_alloc(Ctx* c) {
 	auto frag = [&](int n, int rows) {
 		size_t bytes = (size_t)rows * pf_steps(n) * 64 * sizeof(float);
 		float* p = (float*)dev_alloc(bytes);
-		HIP_CHECK(hipMemset(p, 0, bytes));
+		dev_zero(p, bytes);
 		return p;
 	};
 	// a mixture-of-experts chunk packs (token, expert) pairs into 64-row columns, one group per expert
@@ -1084,7 +1102,7 @@ void pf_alloc(Ctx* c) {
 	// k_pf_gemm_wide with K cut into ranges: partial tiles (64 KiB each) and the tiles' arrival counters (left at zero by every launch)
 	c->pf_partial = (float*)dev_alloc(PF_SPLIT_SLOTS * 16384 * sizeof(float));
 	c->pf_tile_count = (unsigned*)dev_alloc(PF_SPLIT_TILES * sizeof(unsigned));
-	HIP_CHECK(hipMemset(c->pf_tile_count, 0, PF_SPLIT_TILES * sizeof(unsigned)));
+	dev_zero(c->pf_tile_count, PF_SPLIT_TILES * sizeof(unsigned));
 	if (c->n_experts > 0) {
 		c->pf_gate = (float*)dev_alloc((size_t)NT * c->n_experts * sizeof(float));
 		c->pf_rows = (int*)dev_alloc((size_t)erows * sizeof(int));
@@ -1658,8 +1676,7 @@ extern "C" void free_hip(void* device) {
 
 extern "C" void download_hip(void* host, const void* device, size_t size) {
 	init_hip();
-	HIP_CHECK(hipStreamSynchronize(g_stream));
-	HIP_CHECK(hipMemcpy(host, device, size, hipMemcpyDeviceToHost));
+	dev_copy_sync(host, device, size, hipMemcpyDeviceToHost); // behind everything queued on the decode stream
 }
 
 namespace {
@@ -1714,16 +1731,16 @@ void prepare_ctx(struct Transformer* t) {
 	// routing of the last step: [layer][rank] weights, then [layer][rank] expert ids, one allocation (shown to the host as state.exp)
 	c->moe_w = (float*)dev_alloc((size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int)));
 	c->moe_e = (int*)(c->moe_w + (size_t)c->n_layers * CALM_MAX_EXPERTS);
-	HIP_CHECK(hipMemset(c->moe_w, 0, (size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int))));
+	dev_zero(c->moe_w, (size_t)c->n_layers * CALM_MAX_EXPERTS * (sizeof(float) + sizeof(int)));
 	c->next_tok = (int*)dev_alloc(sizeof(int));
 	c->sample_st = (SampleState*)dev_alloc(sizeof(SampleState));
 	c->trace_count = (int*)dev_alloc(sizeof(int));
 	c->trace_cap = 1 << 16;
 	c->trace = (int*)dev_alloc((size_t)c->trace_cap * sizeof(int));
 	c->ts = (TokState*)dev_alloc(sizeof(TokState));
-	HIP_CHECK(hipMemset(c->ts, 0, sizeof(TokState)));
-	HIP_CHECK(hipMemset(c->trace_count, 0, sizeof(int)));
-	HIP_CHECK(hipMemset(c->xb, 0, c->dim * sizeof(float)));
+	dev_zero(c->ts, sizeof(TokState));
+	dev_zero(c->trace_count, sizeof(int));
+	dev_zero(c->xb, c->dim * sizeof(float));
 
 	// KV cache, private layout [layer][kv_head][seq_len][head_dim]; zero like calloc (src/infer.c:162-163)
 	c->kv_layer_bytes = (size_t)c->kv_dim * c->seq_len * (c->kvbits / 8);
@@ -1747,8 +1764,8 @@ void prepare_ctx(struct Transformer* t) {
 		c->vc = dev_alloc(kv_bytes);
 		c->vt = nullptr;
 	}
-	HIP_CHECK(hipMemset(c->kc, 0, kv_bytes));
-	HIP_CHECK(hipMemset(c->vc, 0, kv_bytes * (c->vt ? 2 : 1)));
+	dev_zero(c->kc, kv_bytes);
+	dev_zero(c->vc, kv_bytes * (c->vt ? 2 : 1));
 
 	// mixture of experts: the router's table per layer (kernels.hip.h k_attn_out GATE / k_gate_prep) and the partial-sum buffer.  Not for
 	// parallel-residual models (their FFN reads the attention norm's output, which k_attn_out does not produce).
@@ -1761,7 +1778,7 @@ void prepare_ctx(struct Transformer* t) {
 		const size_t per_layer = ((size_t)c->dim + 1) * ep;
 		c->gate_mt = (float*)dev_alloc(per_layer * c->n_layers * sizeof(float));
 		c->gate_part = (float*)dev_alloc((size_t)(GATE_MAX_E + 2) * GATE_COLS * sizeof(float));
-		HIP_CHECK(hipMemsetAsync(c->gate_part, 0, (size_t)(GATE_MAX_E + 2) * GATE_COLS * sizeof(float), g_stream));
+		dev_zero(c->gate_part, (size_t)(GATE_MAX_E + 2) * GATE_COLS * sizeof(float));
 		for (int l = 0; l < c->n_layers; ++l) {
 			float* mt = c->gate_mt + per_layer * l;
 			const dim3 grid(ep + (c->dim + 255) / 256);
@@ -1793,8 +1810,8 @@ void prepare_ctx(struct Transformer* t) {
 	c->rope_freq = (float*)dev_alloc(half_hd * sizeof(float));
 	c->rope_cs = (float2*)dev_alloc(half_hd * sizeof(float2));
 	c->rope_cs1 = (float2*)dev_alloc(half_hd * sizeof(float2));
-	HIP_CHECK(hipMemcpy(c->rope_freq, freq.data(), half_hd * sizeof(float), hipMemcpyHostToDevice));
-	HIP_CHECK(hipMemcpy(c->rope_cs1, cs1.data(), half_hd * sizeof(float2), hipMemcpyHostToDevice));
+	dev_copy_sync(c->rope_freq, freq.data(), half_hd * sizeof(float), hipMemcpyHostToDevice);
+	dev_copy_sync(c->rope_cs1, cs1.data(), half_hd * sizeof(float2), hipMemcpyHostToDevice);
 
 	// logits land in pinned host memory: the host sampler reads and overwrites them (src/sampler.c:55)
 	HIP_CHECK(hipHostMalloc((void**)&c->logits_h, (size_t)c->vocab * sizeof(float), hipHostMallocDefault));
@@ -1874,7 +1891,8 @@ void* upload_pending(const void* host, std::vector<void*>& owned) {
 			HIP_CHECK(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)host));
 			CALM_REQUIRE(base == host && size > DEV_PAD, "multi-device: a weight pointer into the middle of an allocation on another device");
 			void* d = dev_alloc(size - DEV_PAD);
-			HIP_CHECK(hipMemcpyPeer(d, cur, host, attr.device, size - DEV_PAD));
+			HIP_CHECK(hipMemcpyPeerAsync(d, cur, host, attr.device, size - DEV_PAD, g_stream)); // (the source is complete: uploads return synchronised)
+			HIP_CHECK(hipStreamSynchronize(g_stream));
 			owned.push_back(d);
 			return d;
 		}
@@ -2388,9 +2406,8 @@ extern "C" void perf_hip(void) {
 extern "C" double perf_stage_hip(struct Transformer* t, int stage, int iters, uint64_t* bytes_per_launch) {
 	Ctx* c = ctx_of(t);
 	CALM_REQUIRE(stage >= 0 && stage < CALM_STAGE_COUNT && iters > 0, "bad stage / iters");
-	HIP_CHECK(hipStreamSynchronize(g_stream));
 	TokState ts;
-	HIP_CHECK(hipMemcpy(&ts, c->ts, sizeof(ts), hipMemcpyDeviceToHost));
+	dev_copy_sync(&ts, c->ts, sizeof(ts), hipMemcpyDeviceToHost);
 	int kv_len = ts.kv_len > 0 ? ts.kv_len : 1;
 	if (bytes_per_launch) {
 		*bytes_per_launch = stage_bytes(c, stage, kv_len);
@@ -2462,15 +2479,16 @@ extern "C" void calm_tl_arm(int waves) {
 		HIP_CHECK(hipMalloc(&buf, need));
 		cap = need;
 	}
-	HIP_CHECK(hipMemset(buf, 0, need));
+	dev_zero(buf, need);
 	unsigned uw = (unsigned)waves;
-	HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(calm_tl_buf), &buf, sizeof(buf)));
-	HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(calm_tl_waves), &uw, sizeof(uw)));
+	HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(calm_tl_buf), &buf, sizeof(buf), 0, hipMemcpyHostToDevice, g_stream));
+	HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(calm_tl_waves), &uw, sizeof(uw), 0, hipMemcpyHostToDevice, g_stream));
+	HIP_CHECK(hipStreamSynchronize(g_stream)); // (stack sources)
 }
 extern "C" void calm_tl_read(unsigned long long* host, int waves) {
-	HIP_CHECK(hipStreamSynchronize(g_stream));
 	unsigned long long* buf = nullptr;
-	HIP_CHECK(hipMemcpyFromSymbol(&buf, HIP_SYMBOL(calm_tl_buf), sizeof(buf)));
-	HIP_CHECK(hipMemcpy(host, buf, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+	HIP_CHECK(hipMemcpyFromSymbolAsync(&buf, HIP_SYMBOL(calm_tl_buf), sizeof(buf), 0, hipMemcpyDeviceToHost, g_stream));
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	dev_copy_sync(host, buf, (size_t)waves * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
 }
 #endif

@@ -2070,7 +2070,7 @@ __device__ __forceinline__ float act_gelu(float x) {
 
 // task = one hidden unit j of one active expert slot k: rows (w1[e_k][j], w3[e_k][j]) [x2 for gf4]
 // MOE: 0 dense; 1 the gate computed here, by every workgroup, from the vector (below); 2 the gate folded from the partials
-// k_attn_out's epilogue left (`moegate` then points at gate_part, `n_experts` carries n_experts | k_attn_out's grid << 8).
+// k_attn_out's epilogue left (`moegate` then points at gate_part, `n_experts` carries n_experts | k_attn_out's grid << 8 | its expert rows ep << 24).
 template <int DB, int V, bool FULL, int MOE, bool XREG = false>
 __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const float* norm_w, const void* w1, const void* w3, const void* moegate, int dim, int hidden, int n_experts, int n_active,
                                                  FfnUpArgs a) {
@@ -2150,7 +2150,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 		// adds its float4s' live columns in index order, then the wave's DPP tree -- the same order in every workgroup, so all of
 		// them pick the same experts -- and every load of a wave is in flight at once (one round trip).  The vector's own
 		// loads go out first (the image needs them right after); nothing here waits for the image.
-		const int ne = n_experts & 0xff, cols = n_experts >> 8, nq = ne + 2;
+		// (k_attn_out<GATE> files the two statistics behind ITS expert rows, whose count ep is n_experts rounded up to a power of two:
+		// rows ep and ep + 1; quantity q of the fold lives in row q < ne ? q : ep + (q - ne))
+		const int ne = n_experts & 0xff, cols = (n_experts >> 8) & 0xffff, ep = (unsigned)n_experts >> 24, nq = ne + 2;
 		const float* part = (const float*)moegate;
 		stage_load<WG_THREADS>(sr, x, norm_w);
 		// quantities per wave and batch x float4s per lane and quantity: up to 20 loads in flight per lane whichever way -- few live
@@ -2166,7 +2168,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 					for (int i = 0; i < C4; ++i) {
 						v[j][i] = make_float4(0.f, 0.f, 0.f, 0.f);
 						if (q < nq && i * 256 < cols) { // wave-uniform
-							v[j][i] = *((const float4*)(part + (size_t)q * GATE_COLS) + i * 64 + lane);
+							v[j][i] = *((const float4*)(part + (size_t)(q < ne ? q : q - ne + ep) * GATE_COLS) + i * 64 + lane);
 						}
 					}
 				}
@@ -2200,7 +2202,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_ffn_up(const float* x, const flo
 			// every wave routes for itself (the same logits, the same picks, identical stores): no second barrier before the first tile
 			const float n = (float)dim;
 			const float mean = a.ln ? gate[ne + 1] / n : 0.f;                       // src/infer.c:183-207
-			const float scale = 1.0f / sqrtf(gate[ne] / n - mean * mean + a.eps);
+			// (one-pass variance from the partial sums; the reference's two-pass form cannot go negative, this one can by rounding)
+			const float scale = 1.0f / sqrtf(fmaxf(gate[ne] / n - mean * mean, 0.f) + a.eps);
 			const int le = lane < ne ? lane : 0;
 			const float c = a.ln ? a.gate_c[le] : 0.f;
 			moe_route((gate[le] - mean * c) * scale, ne, n_active, sel_e, sel_w, (blockIdx.x == 0 && wave == 0) ? a.moe_w : nullptr, a.moe_e);

@@ -38,7 +38,7 @@ extern "C" void calm_hip_test_matvec(int dbits, const void* w, const float* x, f
 	void* dw = upload_hip((void*)w, wbytes);
 	float* dx = (float*)upload_hip((void*)x, n * sizeof(float));
 	float* dout = (float*)dev_alloc(d * sizeof(float));
-	HIP_CHECK(hipMemset(dout, 0, d * sizeof(float)));
+	dev_zero(dout, d * sizeof(float)); // (k_attn_out adds into it) -- on the decode stream, like the launch behind it
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
 		by_bool(stage_v4(n, WG_THREADS), [&](auto V4) {
@@ -62,6 +62,7 @@ extern "C" void calm_hip_test_norm_matvec(int dbits, const void* w, const float*
 	float* dx = (float*)upload_hip((void*)x, n * sizeof(float));
 	float* dnw = (float*)upload_hip((void*)nw, n * sizeof(float));
 	float* dout = (float*)dev_alloc(d * sizeof(float));
+	dev_fill(dout, 0xff, d * sizeof(float)); // poison (NaN): a row the kernel skipped cannot look like an answer
 	by_dbits(dbits, [&](auto DBT) {
 		constexpr int DB = decltype(DBT)::value;
 		int ntasks = (d + KShape<DB, KS_OUTPUT>::NR - 1) / KShape<DB, KS_OUTPUT>::NR;
@@ -109,6 +110,7 @@ extern "C" void calm_hip_test_attn(const float* q, const uint16_t* kcache, const
 	}
 	c.q = (float*)upload_hip((void*)q, q_dim * sizeof(float));
 	c.att = (float*)dev_alloc(q_dim * sizeof(float));
+	dev_fill(c.att, 0xff, q_dim * sizeof(float)); // poison (NaN)
 	c.partial = (float*)dev_alloc((size_t)n_heads * MAX_SPLIT * (head_dim + 4) * sizeof(float));
 	TokState ts = {};
 	ts.kv_len = kv_len;
@@ -131,7 +133,7 @@ extern "C" int calm_hip_test_argmax(const float* logits, int n) {
 	init_hip();
 	float* dl = (float*)upload_hip((void*)logits, n * sizeof(float));
 	int* dn = (int*)dev_alloc(2 * sizeof(int));
-	HIP_CHECK(hipMemset(dn, 0, 2 * sizeof(int)));
+	dev_zero(dn, 2 * sizeof(int));
 	hipLaunchKernelGGL(k_argmax, dim3(1), dim3(1024), 0, g_stream, dl, n, dn, (int*)nullptr, dn + 1);
 	HIP_CHECK(hipGetLastError());
 	int r = -2;
@@ -241,7 +243,7 @@ extern "C" int calm_hip_test_sample(const float* logits, int n, float temperatur
 	init_hip();
 	float* dl = (float*)upload_hip((void*)logits, n * sizeof(float));
 	int* dn = (int*)dev_alloc(2 * sizeof(int));
-	HIP_CHECK(hipMemset(dn, 0, 2 * sizeof(int)));
+	dev_zero(dn, 2 * sizeof(int));
 	SampleState st;
 	st.rng = *rng_state, st.temperature = temperature, st.cutoff_offset = logf(minp) * temperature;
 	SampleState* ds = (SampleState*)upload_hip(&st, sizeof(st));
@@ -258,6 +260,15 @@ extern "C" int calm_hip_test_sample(const float* logits, int n, float temperatur
 namespace {
 
 // the backend's private cache layout, from what struct Transformer shows: [layer][kv_head][seq_len][head_dim], 2 or 1 bytes
+// These hooks look into a model prepared by ANOTHER instance of the backend (the product library: its decode stream is not this
+// library's g_stream), so the copy is fenced by whole-device synchronisations on both sides and itself runs on this library's stream.
+void foreign_copy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+	init_hip();
+	HIP_CHECK(hipDeviceSynchronize());
+	dev_copy_sync(dst, src, bytes, kind);
+	HIP_CHECK(hipDeviceSynchronize());
+}
+
 struct KvGeom {
 	int n_kv_heads, head_dim, seq_len, kv_dim, ebytes;
 	size_t layer_bytes;
@@ -280,8 +291,7 @@ extern "C" void calm_hip_read_kv(struct Transformer* t, int layer, int which, ui
 	const KvGeom g = kv_geom(t);
 	CALM_REQUIRE(layer >= 0 && layer < t->config.n_layers, "calm_hip_read_kv: no such layer");
 	std::vector<unsigned char> tmp(g.layer_bytes);
-	HIP_CHECK(hipDeviceSynchronize());
-	HIP_CHECK(hipMemcpy(tmp.data(), (char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, g.layer_bytes, hipMemcpyDeviceToHost));
+	foreign_copy(tmp.data(), (char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, g.layer_bytes, hipMemcpyDeviceToHost);
 	for (int h = 0; h < g.n_kv_heads; ++h) {
 		for (int p = 0; p < g.seq_len; ++p) {
 			uint16_t* dst = host + (size_t)p * g.kv_dim + h * g.head_dim;
@@ -317,8 +327,7 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 			}
 		}
 	}
-	HIP_CHECK(hipDeviceSynchronize());
-	HIP_CHECK(hipMemcpy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+	foreign_copy((char*)(which ? t->state.value_cache : t->state.key_cache) + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice);
 	// the transposed value cache, when the backend keeps one (prepare_ctx: head size 128, knob "attn_vt", a window beyond the unsplit
 	// kernel's contexts), sits behind the [position][dim] one in the same allocation -- seen here from the allocation's size (this
 	// library shares no state with the product library the model was prepared by): [layer][kv_head][block of positions][head_dim][position in block]
@@ -338,7 +347,7 @@ extern "C" void calm_hip_write_kv(struct Transformer* t, int layer, int which, c
 				}
 			}
 		}
-		HIP_CHECK(hipMemcpy((char*)t->state.value_cache + kv_bytes + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice));
+		foreign_copy((char*)t->state.value_cache + kv_bytes + (size_t)layer * g.layer_bytes, tmp.data(), g.layer_bytes, hipMemcpyHostToDevice);
 	}
 }
 
@@ -350,9 +359,8 @@ extern "C" void calm_hip_read_moe(struct Transformer* t, int layer, int* experts
 	const int n = t->config.n_experts_ac;
 	const float* w = t->state.exp + (size_t)layer * CALM_MAX_EXPERTS;
 	const int* e = (const int*)(t->state.exp + (size_t)t->config.n_layers * CALM_MAX_EXPERTS) + (size_t)layer * CALM_MAX_EXPERTS;
-	HIP_CHECK(hipDeviceSynchronize());
-	HIP_CHECK(hipMemcpy(experts, e, n * sizeof(int), hipMemcpyDeviceToHost));
-	HIP_CHECK(hipMemcpy(weights, w, n * sizeof(float), hipMemcpyDeviceToHost));
+	foreign_copy(experts, e, n * sizeof(int), hipMemcpyDeviceToHost);
+	foreign_copy(weights, w, n * sizeof(float), hipMemcpyDeviceToHost);
 }
 
 namespace {
@@ -387,7 +395,7 @@ extern "C" double calm_hip_membench(size_t bytes, int nt, int iters) {
 	size_t n16 = bytes / 16;
 	u32x4* buf = (u32x4*)dev_alloc(n16 * 16);
 	unsigned* sink = (unsigned*)dev_alloc(4);
-	HIP_CHECK(hipMemset(buf, 0x5a, n16 * 16));
+	dev_fill(buf, 0x5a, n16 * 16);
 	int blocks = g_ncu * 8;
 	auto go = [&]() {
 		if (nt) {

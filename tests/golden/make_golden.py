@@ -52,6 +52,10 @@ CASES = {
     "mqa_hd96_fp16": (dict(dim=192, hidden_dim=224, head_dim=96, n_heads=2, n_kv_heads=1, vocab_size=160), "fp16", 24),
     # mixture of experts over 4-bit weights, tied classifier
     "moe_gf4": (dict(n_experts=4, n_experts_active=2, tied=True), "gf4", 24),
+    # expert counts that are NOT powers of two (round 4's routing-ahead pads its expert rows to a power of two and once read the norm
+    # statistics from the padded rows: advisor finding): 6 experts top-2 under RMSNorm, 12 experts top-3 under LayerNorm
+    "moe6_fp8": (dict(n_experts=6, n_experts_active=2), "fp8", 24),
+    "moe12_ln_fp16": (dict(n_experts=12, n_experts_active=3, norm_type="layernorm"), "fp16", 24),
     # head_dim 256 (gemma-style), GELU, runs past a 12-row rolling buffer with fp8 weights
     "hd256_sink_fp8": (dict(dim=512, hidden_dim=544, head_dim=256, n_heads=2, n_kv_heads=1, n_layers=1, vocab_size=160, act_type="gelu", max_seq_len=12), "fp8", 30),
 }

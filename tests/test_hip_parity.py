@@ -223,6 +223,34 @@ def test_golden_logits_teacher_forced(hiplib, case, graph):
         hiplib.calm_hip_configure(b"graph", 1)
 
 
+@pytest.mark.parametrize("route", [1, 0])
+@pytest.mark.parametrize("case", ["moe6_fp8", "moe12_ln_fp16", "dbrx_like_fp8"])
+def test_expert_counts_that_are_not_powers_of_two_route_like_the_reference(hiplib, case, route):
+    """6 experts top-2 (RMSNorm) and 12 experts top-3 (LayerNorm): k_attn_out<GATE> pads its expert rows to a power of two and files the
+    norm statistics behind them; k_ffn_up<MOE = 2> must read them THERE (round 4 read rows n_experts, n_experts + 1: the padded experts'
+    zeros, so the picks were right and the mixture weights silently wrong).  Both routing forms -- "moe_route" 1: ahead, from the
+    partial sums; 0: the gate inside k_ffn_up -- against the reference's logits, and the routed experts of the last step against the
+    oracle's (src/infer.c:277-305)."""
+    model, z = load_golden(case)
+    old = hiplib.calm_hip_configure(b"moe_route", route)
+    b = HipBackend(model)
+    cpu = oracle.OracleBackend(model)
+    try:
+        L, k = model.config.n_layers, model.config.n_experts_ac
+        for pos, tok in enumerate(z["tokens"]):
+            lg = b.forward(int(tok), pos, 0)
+            _, eo, wo, _ = cpu.forward_traced(int(tok), pos)
+            assert rel_err(lg, z["logits"][pos]) < LOGIT_TOL, pos
+            for layer in range(L):
+                e, w = b.read_moe(layer)
+                assert list(e[:k]) == list(eo[layer][:k]), (pos, layer, e, eo[layer])
+                assert np.abs(np.asarray(w[:k]) - np.asarray(wo[layer][:k])).max() < 1e-4, (pos, layer, w, wo[layer])
+                assert abs(float(np.sum(w[:k])) - 1.0) < 1e-5
+    finally:
+        b.close()
+        hiplib.calm_hip_configure(b"moe_route", old)
+
+
 @pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4", "moe_gf4", "dbrx_like_fp8"])
 def test_alternative_tile_shapes_give_the_reference_logits(hiplib, case):
     """the tile shapes the launchers pick by matrix size (k_qkv half-depth tiles for small matrices, one row per task in k_attn_out /
