@@ -100,6 +100,7 @@ int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every
 int g_skew = 14;       // k_ffn_up: percent more tasks for the first-dispatched workgroup of each CU than an even split gives it (0: even) (k_ffn_up, k_output at two workgroups per CU; kernels.hip.h task_range)
 int g_qkv_wgs = 0;     // workgroups per CU of k_qkv's grid where the tasks exceed it (0: the rule in launch_qkv; A/B switch)
 int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
+int g_pf_score_mb = 256; // MiB of logits scratch the scoring GEMM may use (prefill_logprobs_hip scores a chunk in blocks of that many rows; read when the scratch is allocated)
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -257,13 +258,17 @@ struct Ctx {
 	unsigned* pf_tile_count = nullptr;
 	float2* pf_rope = nullptr;
 	int* pf_tok = nullptr;
-	unsigned* pf_flag = nullptr;     // pinned host word the prompt kernels raise when an activation leaves the binary16 range (prefill.hip.h)
-	unsigned* pf_flag_dev = nullptr; // ... as the device sees it
+	// pinned host words the prompt kernels raise when an activation leaves the binary16 range (prefill.hip.h): one per chunk of a
+	// prefill call (PF_FLAG_WORDS; chunks beyond share the last), so that the call redoes the prompt from the FIRST chunk that raised
+	// one, not from its start; pf_flag_ptr[k] = word k as the device sees it (the persistent sources of the per-chunk symbol copies)
+	unsigned* pf_flag = nullptr;
+	std::vector<unsigned*> pf_flag_ptr;
 	// ... of a mixture-of-experts model: gate logits, per-expert row lists, one expert's gathered rows
 	float *pf_gate = nullptr, *pf_wsel = nullptr, *pf_xe = nullptr, *pf_y = nullptr;
 	int *pf_rows = nullptr, *pf_colexp = nullptr, *pf_slot = nullptr;
 	int pf_max_cols = 0;
 	// ... when the caller wants the log-probability of every next token: logits of the chunk, targets, results
+	int pf_score_nt = 0; // tokens per block of the scoring GEMM (pf_logits holds that many rows)
 	float *pf_logits = nullptr, *pf_lp = nullptr;
 	int* pf_target = nullptr;
 	// graph cache: (n_split, kv_only, sink, chained, argmax)
@@ -805,13 +810,18 @@ void vt_sync(Ctx* c, int upto) {
 	if (!c->vt || c->vt_rows >= upto) {
 		return;
 	}
-	const int n = (upto - c->vt_rows) * c->kv_dim;
 	const size_t layer_elems = (size_t)c->kv_dim * c->seq_len;
-	const dim3 grid((n + 255) / 256, c->n_layers);
-	if (c->kvbits == 16) {
-		hipLaunchKernelGGL(k_vt_backfill<16>, grid, dim3(256), 0, g_stream, c->vc, c->vt, layer_elems, c->kv_dim, c->head_dim, c->seq_len, c->vt_rows, upto);
-	} else {
-		hipLaunchKernelGGL(k_vt_backfill<8>, grid, dim3(256), 0, g_stream, c->vc, c->vt, layer_elems, c->kv_dim, c->head_dim, c->seq_len, c->vt_rows, upto);
+	// in blocks of rows whose element count stays far inside an int (the kernel indexes one thread per element: a 1M-position window
+	// of 4096-wide rows would be 2^32 of them)
+	const int max_rows = (1 << 30) / c->kv_dim;
+	for (int r0 = c->vt_rows; r0 < upto; r0 += max_rows) {
+		const int r1 = upto - r0 < max_rows ? upto : r0 + max_rows;
+		const dim3 grid(((r1 - r0) * c->kv_dim + 255) / 256, c->n_layers);
+		if (c->kvbits == 16) {
+			hipLaunchKernelGGL(k_vt_backfill<16>, grid, dim3(256), 0, g_stream, c->vc, c->vt, layer_elems, c->kv_dim, c->head_dim, c->seq_len, r0, r1);
+		} else {
+			hipLaunchKernelGGL(k_vt_backfill<8>, grid, dim3(256), 0, g_stream, c->vc, c->vt, layer_elems, c->kv_dim, c->head_dim, c->seq_len, r0, r1);
+		}
 	}
 	c->vt_rows = upto;
 }
@@ -1071,6 +1081,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 
 constexpr size_t PF_SPLIT_SLOTS = 2560; // 64-KiB partial tiles of a split launch (tiles x ranges: about one per CU, x 2-3 for grid padding; the big form's are four each)
 constexpr int PF_SPLIT_TILES = 4096;
+constexpr int PF_FLAG_WORDS = 256; // range-flag words per model: one per chunk of a prefill call (a 500k-token prompt in 2048-token chunks)
 
 void pf_alloc(Ctx* c) {
 	if (c->pf_x) {
@@ -1096,9 +1107,14 @@ void pf_alloc(Ctx* c) {
 	c->pf_h = frag(c->hidden, erows);
 	c->pf_rope = (float2*)dev_alloc((size_t)NT * (c->head_dim / 2) * sizeof(float2));
 	c->pf_tok = (int*)dev_alloc(NT * sizeof(int));
-	HIP_CHECK(hipHostMalloc((void**)&c->pf_flag, sizeof(unsigned), hipHostMallocMapped));
-	*c->pf_flag = 0;
-	HIP_CHECK(hipHostGetDevicePointer((void**)&c->pf_flag_dev, c->pf_flag, 0));
+	HIP_CHECK(hipHostMalloc((void**)&c->pf_flag, PF_FLAG_WORDS * sizeof(unsigned), hipHostMallocMapped));
+	memset(c->pf_flag, 0, PF_FLAG_WORDS * sizeof(unsigned));
+	unsigned* flag_dev = nullptr;
+	HIP_CHECK(hipHostGetDevicePointer((void**)&flag_dev, c->pf_flag, 0));
+	c->pf_flag_ptr.resize(PF_FLAG_WORDS);
+	for (int k = 0; k < PF_FLAG_WORDS; ++k) {
+		c->pf_flag_ptr[k] = flag_dev + k;
+	}
 	// k_pf_gemm_wide with K cut into ranges: partial tiles (64 KiB each) and the tiles' arrival counters (left at zero by every launch)
 	c->pf_partial = (float*)dev_alloc(PF_SPLIT_SLOTS * 16384 * sizeof(float));
 	c->pf_tile_count = (unsigned*)dev_alloc(PF_SPLIT_TILES * sizeof(unsigned));
@@ -1381,9 +1397,16 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	if (score) {
 		// final norm + classifier for every token of the chunk (src/infer.c:465-469), then log softmax of the target
 		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_final_weight, c->dim, p->norm_eps, (int)p->norm_ln);
-		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->vocab, a.w0 = w->wcls, a.out = c->pf_logits;
-		gemm(a, std::integral_constant<int, PF_EPI_STORE>(), cols);
-		hipLaunchKernelGGL(k_pf_logprob, dim3(nb), block, 0, g_stream, c->pf_logits, c->vocab, c->pf_target, c->pf_lp);
+		// in blocks of pf_score_nt tokens (whole 128-token columns: a block of the fragment-major matrix starts at a 32-token group), so
+		// that the logits scratch stays bounded for 128k / 256k vocabularies
+		a.K = c->dim, a.M = c->vocab, a.w0 = w->wcls, a.out = c->pf_logits;
+		for (int t0 = 0; t0 < nb; t0 += c->pf_score_nt) {
+			const int n = nb - t0 < c->pf_score_nt ? nb - t0 : c->pf_score_nt;
+			a.xin = (const float4*)c->pf_xn + (size_t)(t0 >> 5) * pf_steps(c->dim) * 512;
+			a.nb = n;
+			gemm(a, std::integral_constant<int, PF_EPI_STORE>(), (n + 63) / 64);
+			hipLaunchKernelGGL(k_pf_logprob, dim3(n), block, 0, g_stream, c->pf_logits, c->vocab, c->pf_target + t0, c->pf_lp + t0);
+		}
 	}
 	HIP_CHECK(hipGetLastError());
 }
@@ -1503,6 +1526,9 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_pf_attn_mfma;
 	} else if (!strcmp(key, "pf_skinny")) {
 		slot = &g_pf_skinny;
+	} else if (!strcmp(key, "pf_score_mb")) {
+		CALM_REQUIRE(value < 0 || value >= 1, "calm_hip_configure(\"pf_score_mb\"): at least 1 MiB");
+		slot = &g_pf_score_mb;
 	} else if (!strcmp(key, "stage")) {
 		CALM_REQUIRE(value < (int)g_devs.size(), "calm_hip_configure(\"stage\"): no such stage");
 		int old_stage = g_alloc_stage;
@@ -1631,6 +1657,8 @@ extern "C" void init_hip(void) {
 	CALM_REQUIRE(g_pf_chunk >= PF_NT && g_pf_chunk <= PF_NT_DENSE && g_pf_chunk % 128 == 0, "CALM_HIP_PF_CHUNK: 1024 ... 2048 in steps of 128");
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
+	g_pf_score_mb = env_int("CALM_HIP_PF_SCORE_MB", g_pf_score_mb);
+	CALM_REQUIRE(g_pf_score_mb >= 1, "CALM_HIP_PF_SCORE_MB: at least 1 MiB");
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
 		printf("# HIP: %s (%s), %d CUs, %.1f GiB, device %d\n", prop.name, prop.gcnArchName, g_ncu, (double)prop.totalGlobalMem / (1024.0 * 1024 * 1024), dev);
 	}
@@ -2224,18 +2252,22 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 		}
 	};
 	int done = 0;
+	std::vector<int> chunk_start; // first token of every batched chunk of this call
 	if ((first->n_experts == 0 || first->n_active <= PF_MAX_ACTIVE) && first->t->weights.token_embedding_table) {
 		for (int s = 0; s < P; ++s) {
 			on_stage(s);
 			pf_alloc(st[s]);
 			// the K-range GEMMs leave their tile counters at zero; a launch that did not run to its end must not poison the next call
 			HIP_CHECK(hipMemsetAsync(st[s]->pf_tile_count, 0, PF_SPLIT_TILES * sizeof(unsigned), g_stream));
-			// this model's range flag is the one this device's prompt kernels raise from here on (ordered on the stream)
-			*st[s]->pf_flag = 0;
-			HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(calm_pf_range_ptr), &st[s]->pf_flag_dev, sizeof(unsigned*), 0, hipMemcpyHostToDevice, g_stream));
+			memset(st[s]->pf_flag, 0, PF_FLAG_WORDS * sizeof(unsigned)); // (the call before ended synchronised: nobody is writing them)
 		}
 		if (logprob && !last->pf_logits) { // (the last stage's device is current)
-			last->pf_logits = (float*)dev_alloc((size_t)last->pf_nt * last->vocab * sizeof(float));
+			// logits scratch of the scoring GEMM: at most "pf_score_mb" = 256 MiB (2048 tokens at a 32k vocabulary, 512 at 128k, 256 at 256k), whole
+			// 128-token columns; prefill_chunk scores a chunk in blocks of that many tokens
+			int snt = (int)(((size_t)g_pf_score_mb << 20) / ((size_t)last->vocab * sizeof(float))) / 128 * 128;
+			snt = snt < 128 ? 128 : snt > last->pf_nt ? last->pf_nt : snt;
+			last->pf_score_nt = snt;
+			last->pf_logits = (float*)dev_alloc((size_t)snt * last->vocab * sizeof(float));
 			last->pf_lp = (float*)dev_alloc(last->pf_nt * sizeof(float));
 			last->pf_target = (int*)dev_alloc(last->pf_nt * sizeof(int));
 		}
@@ -2252,9 +2284,13 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 				break; // a chunk costs about three decode steps whatever its size (it streams every weight once, less efficiently)
 			}
 			int target[PF_NT_DENSE];
+			const int k = (int)chunk_start.size() < PF_FLAG_WORDS ? (int)chunk_start.size() : PF_FLAG_WORDS - 1;
+			chunk_start.push_back(done);
 			for (int s = 0; s < P; ++s) {
 				on_stage(s);
 				Ctx* c = st[s];
+				// this chunk's range flag of this model is the one this device's prompt kernels raise from here on (ordered on the stream)
+				HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(calm_pf_range_ptr), &c->pf_flag_ptr[k], sizeof(unsigned*), 0, hipMemcpyHostToDevice, g_stream));
 				if (s == 0) {
 					HIP_CHECK(hipMemcpyAsync(c->pf_tok, tokens + done, (size_t)nb * sizeof(int), hipMemcpyHostToDevice, g_stream));
 				} else {
@@ -2294,19 +2330,25 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 	if (done > 0) {
 		// Did every activation of the batched chunks fit the hi + lo binary16 form (prefill.hip.h: pf_split2)?  The flags are host
 		// words the kernels raise: ONE synchronisation per call (of the last stage, which is behind every hand-off), not one
-		// per chunk and stage.  If a flag is up -- values beyond +-65504, NaN -- the batched part of the prompt (later chunks read
-		// the rows of the one that overflowed) is redone by the serial fp32 decode path, token by token, before anything is built on
-		// it: the batched path never decides a result it cannot represent.  (Its positions lie before the rolling buffer wraps: a
-		// serial step there is idempotent.)
+		// per chunk and stage.  If a flag is up -- values beyond +-65504, NaN -- the batched part of the prompt FROM THE FIRST CHUNK
+		// THAT RAISED ONE (later chunks read its rows; earlier ones are sound) is redone by the serial fp32 decode path, token by token,
+		// before anything is built on it: the batched path never decides a result it cannot represent.  (Its positions lie before the
+		// rolling buffer wraps: a serial step there is idempotent, and an unsplit serial step un-mirrors its row of the transposed
+		// value cache -- run_step -- so nothing stale of the chunk survives there either.)
 		on_stage(P - 1);
 		HIP_CHECK(hipStreamSynchronize(g_stream));
-		bool redo = false;
+		int first_bad = (int)chunk_start.size();
 		for (int s = 0; s < P; ++s) {
-			redo = redo || *st[s]->pf_flag != 0;
+			for (int k = 0; k < first_bad && k < PF_FLAG_WORDS; ++k) {
+				if (st[s]->pf_flag[k] != 0) {
+					first_bad = k;
+				}
+			}
 		}
-		if (redo) {
-			g_pf_redone += done;
-			for (int i = 0; i < done; ++i) {
+		if (first_bad < (int)chunk_start.size()) {
+			const int from = chunk_start[first_bad];
+			g_pf_redone += done - from;
+			for (int i = from; i < done; ++i) {
 				serial_token(i);
 			}
 		}

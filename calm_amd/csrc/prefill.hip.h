@@ -60,10 +60,11 @@ __device__ __forceinline__ size_t pf_unit(int t, int k, int nsteps) {
 	return ((((size_t)(t >> 5) * nsteps + (k >> 6)) * 4 + ((k & 31) >> 3)) << 7) + (((k >> 5) & 1) << 5) + (t & 31);
 }
 // Raised (never cleared by a kernel) when an activation did not fit the hi + lo form: beyond the binary16 range, or not a number.
-// The word lives in pinned host memory of the model being ingested (Ctx::pf_flag; prefill_impl points this device's copy of
-// calm_pf_range_ptr at it on the stream ahead of the call's kernels) and is read by the host at the call's own final
-// synchronisation -- no extra round trip per chunk, no flag shared between models: a prompt during which it was raised is redone
-// through the serial fp32 decode path, so the batched path either agrees with the serial one to fp32 rounding or is not used.
+// The word lives in pinned host memory of the model being ingested, one word per chunk of the call (Ctx::pf_flag; prefill_impl points
+// this device's copy of calm_pf_range_ptr at the chunk's word on the stream ahead of the chunk's kernels) and is read by the host at
+// the call's own final synchronisation -- no extra round trip per chunk, no flag shared between models: a prompt during which one was
+// raised is redone from that chunk on through the serial fp32 decode path, so the batched path either agrees with the serial one to
+// fp32 rounding or is not used.
 __device__ unsigned* calm_pf_range_ptr;
 
 // x = hi + lo, two binary16 numbers each.  Out-of-range values saturate HERE (NaN stays NaN: the compares are ordered) and

@@ -184,6 +184,8 @@ const char* calm_hip_device_name(void);
  *   "pf_rounds": 1 = a prompt GEMM whose last round of workgroups would be mostly empty runs in 2 / 4 ranges of K (0: never; A/B switch)
  *   "pf_chunk": tokens per prompt chunk of a dense model, 1024 ... 2048 in steps of 128 (default 2048; read when a model's prompt
  *       buffers are allocated, i.e. at its first prefill_hip call; mixture-of-experts models always take 1024)
+ *   "pf_score_mb": MiB of device scratch for the logits of prefill_logprobs_hip (default 256; read when that scratch is allocated, at a
+ *       model's first scoring call): a chunk is scored in blocks of as many tokens as fit (whole 128-token columns, at least 128)
  *   "stage"     multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip)
  * Queries (value ignored): "stages" (pipeline stages of this process), "stage_device" (value = stage -> its device), "pf_redone"
  * (prompt tokens prefill_hip sent back through the serial path), "handoffs" / "handoff_ns" (stage-to-stage copies timed under "prof"

@@ -27,6 +27,26 @@ GOLDEN_CASES = ["tiny_fp16", "tiny_fp8", "tiny_gf4", "moe_fp8", "ln_gelu_clip_fp
                 "partial_rope_fp16", "dbrx_like_fp8", "mqa_hd96_fp16", "moe_gf4", "hd256_sink_fp8", "moe6_fp8", "moe12_ln_fp16"]
 
 
+# ---- tolerances (max |delta| over a token's logits / max |logit|) ----------------------------------------------
+# LOGIT_TOL: whole decode steps with the fp16 KV cache -- the north star's 1e-3, for fp16 AND fp8 / gf4 weights (weights decode exactly,
+#   activations stay fp32).  Measured: <= 3.6e-4 at 32 layers (profiles/r05_fp8kv.txt, kvbits 16 rows).
+# FP8KV_TOL: the same comparison with an fp8 (e5m2) KV cache on both sides, models of AT MOST 2 LAYERS decoded from position 0.  e5m2
+#   codes are 12.5-25 % apart; where the two sides' fp32 sums (different summation orders) straddle a rounding boundary the cached
+#   element differs by a whole code.  Measured on the 2-layer attention-true model (tools/fp8kv_study.py, profiles/r05_fp8kv.txt): 3.6e-4
+#   .. 8.4e-4 of the cached elements differ, logits by median 1.2-2.0e-4, p99.9 2.7e-3, max 3.04e-3 over 4096 positions (largest at
+#   short contexts, < 1.1e-3 beyond 256 positions: more rows to average over).  It is NOT depth-independent: every layer's cache
+#   re-quantises a perturbed value (an fp32-rounding difference eps becomes ~0.18 sqrt(5.5 eps) behind one e5m2 row), and by 32 layers
+#   ANY two summation orders sit at the fixed point, ~2e-2 -- the CPU checker against ITSELF with one norm weight moved by one ulp:
+#   median 1.9e-2 (fp16 cache: 1.3e-4).  So full-depth fp8-KV comparisons run one step on identical caches (tests/test_long_context.py),
+#   never free-running from position 0, and this constant is only ever applied to shallow models.
+LOGIT_TOL = 1e-3
+FP8KV_TOL = 4e-3
+
+
+def logit_tol(kvbits: int) -> float:
+    return FP8KV_TOL if kvbits == 8 else LOGIT_TOL
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X GPU (run with -m gpu on the GPU box)")
 

@@ -95,3 +95,20 @@ def test_perplexity_matches_the_reference_cli_arithmetic():
     got, got_err = perplexity(oracle.OracleBackend(model), toks, steps)
     assert abs(got - want) < 1e-4 * want and abs(got_err - want_err) < 1e-3 * max(want_err, 1e-6)
     o.close()
+
+
+def test_profile_summary_names_kernels_in_anonymous_namespaces():
+    """tools/prof_summary.py: rocprofv3 prints `void (anonymous namespace)::k<...>(args)`; the summary's key is `k<...>` (round 4
+    cut at the first parenthesis and filed every such kernel -- 10 % of the traced time -- under an empty name)"""
+    import importlib.util
+    import os
+
+    from conftest import ROOT
+
+    spec = importlib.util.spec_from_file_location("prof_summary", os.path.join(ROOT, "tools", "prof_summary.py"))
+    ps = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ps)
+    assert ps.short("void (anonymous namespace)::k_pf_gemm_big<8, 0>(PfGemmArgs)") == "k_pf_gemm_big<8, 0>"
+    assert ps.short("void k_ffn_up<8, 4, true, 0, true>(float const*, float const*, int)") == "k_ffn_up<8, 4, true, 0, true>"
+    assert ps.short("void (anonymous namespace)::k_vt_backfill<16>(void const*, void*) [clone .kd]") == "k_vt_backfill<16>"
+    assert ps.short("__amd_rocclr_copyBuffer") == "__amd_rocclr_copyBuffer"

@@ -8,8 +8,10 @@
 * kvbits = 8 has no counterpart in the reference's CPU backend (src/infer.c:161); its CUDA backend stores K/V rows (and the
   re-rotated sink keys) as `__nv_fp8_e5m2(float)` (src/infer.cu:473-482,150-180).  The oracle's kvbits = 8 mode restates
   exactly that storage on top of the CPU arithmetic (oracle/calm_oracle.c: kv_store, oracle_float_to_e5m2 -- pinned against
-  torch.float8_e5m2 in tests/test_oracle.py), and the HIP backend answers to it: same logits tolerance as everywhere else,
-  cache bytes equal except where an fp32 sum that differs in its last bits straddles an e5m2 rounding boundary.
+  torch.float8_e5m2 in tests/test_oracle.py), and the HIP backend answers to it: cache bytes equal except where an fp32 sum that
+  differs in its last bits straddles an e5m2 rounding boundary, logits within conftest.FP8KV_TOL on shallow models decoded from
+  position 0 (the measured bound and why it cannot be depth-independent: conftest.py, profiles/r05_fp8kv.txt) and within the common
+  LOGIT_TOL for one step on identical caches at any depth and context.
 """
 import dataclasses
 import os
@@ -17,7 +19,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import FP8KV_TOL, LOGIT_TOL, load_golden, logit_tol, rel_err
 from calm_amd import abi
 from calm_amd import calmfile as cf
 from calm_amd.host import HipBackend, HostModel
@@ -25,14 +27,13 @@ from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 1e-3
 FF = abi.FF_UPDATE_KV_ONLY
 
 
 @pytest.mark.parametrize("case", ["tiny_fp16", "tiny_fp8", "bias_tied_gf4", "sink_fp16", "hd256_sink_fp8", "mqa_hd96_fp16", "moe_fp8"])
 def test_fp8_kv_cache_matches_the_oracle(hiplib, case):
     """golden models with an fp8 (e5m2) KV cache on both sides, teacher-forced along the golden token stream -- through the
-    rolling buffer and the sink re-rotation where the model has them: logits within LOGIT_TOL at every position, and the
+    rolling buffer and the sink re-rotation where the model has them: logits within FP8KV_TOL at every position, and the
     cached K / V rows byte-equal up to rare one-code differences"""
     model, z = load_golden(case)
     toks = [int(t) for t in z["tokens"]]
@@ -44,7 +45,7 @@ def test_fp8_kv_cache_matches_the_oracle(hiplib, case):
             lo = o.forward(tok, pos, 0)
             lg = b.forward(tok, pos, 0)
             worst = max(worst, rel_err(lg, lo))
-        assert worst < LOGIT_TOL, worst
+        assert worst < FP8KV_TOL, worst
         c = model.config
         n = min(len(toks), c.seq_len)
         for layer in range(c.n_layers):
@@ -202,10 +203,8 @@ def test_transposed_value_cache_catches_up_when_a_sequence_crosses_the_split_thr
                 else:
                     ref.forward(toks[pos], pos, FF)
                     hip.forward(toks[pos], pos, FF)
-            # an e5m2 cache: an fp32 sum that differs in its last bits now and then lands on the other side of a rounding boundary,
-            # one code of a 2-bit mantissa apart (test_fp8_kv_cache_matches_the_oracle) -- the logits then differ by ~1e-3 on this
-            # 2-layer model whichever attention kernel reads the row; what matters here is that nothing changes at the threshold
-            tol = LOGIT_TOL if kvbits == 16 else 2.5 * LOGIT_TOL
+            # (an e5m2 cache: conftest.FP8KV_TOL -- what matters here is that nothing changes at the threshold)
+            tol = logit_tol(kvbits)
             assert max(errs.values()) < tol, (rnd, errs)
             before = max(e for p_, e in errs.items() if p_ <= 383)
             after = max(e for p_, e in errs.items() if p_ > 383)

@@ -10,13 +10,12 @@ import os
 import numpy as np
 import pytest
 
-from conftest import rel_err
+from conftest import LOGIT_TOL, rel_err
 from calm_amd import calmfile as cf
 from calm_amd.host import STAGES, HipBackend, HostModel
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = 1e-3
 GATE_TIE = 2e-3  # (tests/test_full_depth_moe.py: a routing difference is acceptable only below this gate-logit margin, relative to max |gate logit|)
 
 CASES = [

@@ -6,12 +6,11 @@ import pytest
 
 from calm_amd import calmfile as cf
 from calm_amd.host import HipBackend, HostModel
-from conftest import rel_err
+from conftest import LOGIT_TOL, rel_err
 from oracle import oracle
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_TOL = 1e-3
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp8", "gf4"])

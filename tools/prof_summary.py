@@ -24,7 +24,18 @@ from collections import defaultdict
 
 
 def short(name):
-    return name.split("(")[0].replace("void ", "").replace("calm::", "")
+    """`void (anonymous namespace)::k_pf_gemm_big<8, 0>(PfGemmArgs)` -> `k_pf_gemm_big<8, 0>`: namespaces (the anonymous one carries a
+    parenthesis of its own -- round 4 cut the name there and filed 10 % of the trace under "") and the `void ` go, then the argument list"""
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("calm::", "")
+    depth = 0
+    for i, ch in enumerate(name):  # the argument list opens at the first "(" outside the template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i].strip()
+    return name.strip()
 
 
 def kernel_durations(d):
