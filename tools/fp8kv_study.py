@@ -2,6 +2,7 @@
 """What an fp8 (e5m2) KV cache does to logits parity, measured: the bound behind tests' FP8KV_TOL.
 
     python tools/fp8kv_study.py [POSITIONS] [DEEP_POSITIONS]        (GPU box; prints a table, writes gpurun_out/fp8kv/table.txt)
+    python tools/fp8kv_study.py --control [LAYERS] [POSITIONS]      (no GPU: the CPU checker against itself, one weight one ulp apart)
 
 kvbits = 8 stores every K / V element as `__nv_fp8_e5m2(float)` (src/infer.cu:473-482): a 2-bit mantissa, so neighbouring codes are
 12.5-25 % apart.  Both sides (HIP backend, oracle's kvbits = 8 mode = that storage on top of src/infer.c:238-267's arithmetic) round
@@ -87,7 +88,31 @@ def run(model, kvbits, n_pos, seed, out):
     return errs
 
 
+def control(layers, n_pos):
+    """no GPU: the CPU checker against ITSELF with ONE norm weight of layer 0 moved by one ulp -- how far does the smallest possible
+    difference between two correct implementations move the logits, with an e5m2 cache and with an fp16 one?"""
+    spec = cf.SPECS["mistral-7b"]
+    tensors, md = cf.synth_model_big(spec, "fp8", 1, layers)
+    t2 = dict(tensors)
+    w = tensors["model.layers.0.attn.norm.weight"].copy()
+    w[0] = np.nextafter(w[0], np.float32(2.0))
+    t2["model.layers.0.attn.norm.weight"] = w
+    ma, mb = HostModel(tensors, md, context=1024), HostModel(t2, md, context=1024)
+    toks = np.random.default_rng(33).integers(0, spec.vocab_size, size=n_pos)
+    for kvbits in (8, 16):
+        a, b = oracle.OracleBackend(ma, kvbits=kvbits), oracle.OracleBackend(mb, kvbits=kvbits)
+        errs = []
+        for pos, tok in enumerate(toks):
+            errs.append(rel_err(b.forward(int(tok), pos, 0), a.forward(int(tok), pos, 0)))
+        a.close(), b.close()
+        e = np.array(errs)
+        print(f"{layers:2d} layers, kvbits {kvbits:2d}: oracle vs oracle with one norm weight of layer 0 one ulp up, {n_pos} positions: "
+              f"median {np.median(e):.2e}  max {e.max():.2e}", flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--control":
+        return control(int(sys.argv[2]) if len(sys.argv) > 2 else 32, int(sys.argv[3]) if len(sys.argv) > 3 else 24)
     n_pos = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     n_deep = int(sys.argv[2]) if len(sys.argv) > 2 else 48
     out = []
