@@ -46,9 +46,24 @@ def test_perf_hip_breakdown_through_the_reference_cli(hiplib, tmp_path):
                 continue
             us, nbytes = b.stage_us(i, 8 if st != "output" else 2)
             seen[st] = (rows[names[st]][2], round(nbytes / us / 1e3, 1), rows[names[st]][1], round(us, 2))  # GB/s table, GB/s here, us table, us here
-        print("perf_hip table vs perf_stage_hip (GB/s, GB/s, us, us):", seen)
+            # the table's own arithmetic, which does not depend on how fast this box ran either measurement: GB/s x usec per run must
+            # be the bytes perf_stage_hip files under this stage, times its launches per run (L layers; the classifier once) -- the byte
+            # tagging is what the row is FOR (src/infer.cu:692-699: bw = bytes / time); printed with one decimal each
+            # (usec/run divides by ALL forward calls of the run, and the prompt's KV-only steps launch no classifier: its row may sit
+            # below by their share, three or four steps of 49)
+            per_run = nbytes * (1 if st == "output" else L)
+            got = rows[names[st]][2] * rows[names[st]][1] * 1e3
+            assert (0.88 if st == "output" else 0.98) * per_run <= got <= 1.02 * per_run, (st, rows[names[st]], per_run)
+        diag = os.environ.get("CALM_TEST_DIAG")  # the GPU sessions collect these across whole-suite runs (profiles/r05_gpu_tests.txt)
+        if diag:
+            with open(diag, "a") as f:
+                f.write("test_profiling table-vs-stage " + json.dumps({k: [v[0], v[1], round(v[0] / v[1], 3)] for k, v in seen.items()}) + "\n")
+        # ... and the two clocks agree grossly.  Round 5: whole-suite runs on fresh boxes went red in THIS test twice in four (and never
+        # in four runs of this file alone) while the band below was 20 %: the CLI child decodes 15 ms of GPU work after seconds of
+        # loading, perf_stage_hip times a few launches in a process that has been busy for minutes, and the clocks the two bursts meet are
+        # not the same.  The band now separates a wrong unit or byte count from that noise; the ratios of every run are on record.
         for st, (table, gbps, _, _) in seen.items():
-            assert abs(table - gbps) <= 0.2 * gbps, (st, seen, r.stdout[-1200:])
+            assert 0.6 * gbps <= table <= 1.5 * gbps, (st, seen, r.stdout[-1200:])
     finally:
         b.close()
     # the byte account: launches and bytes of every decode kernel of the run (warm-up step + n - 1 decode steps + prompt steps)
