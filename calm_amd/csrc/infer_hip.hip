@@ -105,6 +105,9 @@ int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
+int g_pf_chunk_moe = PF_NT_MOE; // ... of a mixture-of-experts model (PF_NT or PF_NT_MOE; read at the same moment)
+int g_pf_moe_big = 1;  // the grouped GEMMs of a mixture of experts in the big form, every expert's rows padded to whole 128-row columns: 1 = from 1024 packed
+                       // rows per chunk (the rule in prefill_chunk), 0 = never (64-row columns, the wide / K-split forms), 2 = always (tests)
 int g_pf_chunk = PF_NT_DENSE; // tokens per prompt chunk of a dense model (read when a model's prompt buffers are allocated; PF_NT ... PF_NT_DENSE)
 int g_pf_rounds = 1;   // ... the wide form in 2 / 4 ranges of K where its last round of workgroups would be mostly empty (0: whole rows only; A/B switch)
 int g_pf_big = 1;      // ... and the big form (512 units x 128 tokens per workgroup) for the FFN-up / classifier of long chunks (0: never; 2: always, for tests)
@@ -253,7 +256,7 @@ struct Ctx {
 	float* logits_h = nullptr; // pinned host
 	int trace_cap = 0;
 	// batched prompt ingestion (allocated on first use): token-major [pf_nt][...] activations of one chunk
-	int pf_nt = 0; // tokens per chunk, fixed when the buffers are allocated: PF_NT for mixtures of experts, else the knob "pf_chunk"
+	int pf_nt = 0; // tokens per chunk, fixed when the buffers are allocated: the knob "pf_chunk_moe" for mixtures of experts, else "pf_chunk"
 	float *pf_x = nullptr, *pf_xn = nullptr, *pf_q = nullptr, *pf_att = nullptr, *pf_h = nullptr, *pf_partial = nullptr;
 	unsigned* pf_tile_count = nullptr;
 	float2* pf_rope = nullptr;
@@ -1096,9 +1099,10 @@ void pf_alloc(Ctx* c) {
 		return p;
 	};
 	// a mixture-of-experts chunk packs (token, expert) pairs into 64-row columns, one group per expert
-	c->pf_nt = c->n_experts > 0 ? PF_NT : g_pf_chunk;
+	c->pf_nt = c->n_experts > 0 ? g_pf_chunk_moe : g_pf_chunk;
 	const int NT = c->pf_nt;
-	c->pf_max_cols = c->n_experts > 0 ? (NT * c->n_active + 63) / 64 + c->n_experts : 0;
+	// (worst case: every expert's group padded to a whole 128-row column pair -- k_pf_route gran 2 -- and the count even)
+	c->pf_max_cols = c->n_experts > 0 ? ((NT * c->n_active + 63) / 64 + 2 * c->n_experts + 1) / 2 * 2 : 0;
 	const int erows = c->n_experts > 0 ? c->pf_max_cols * 64 : NT;
 	c->pf_x = (float*)dev_alloc((size_t)NT * c->dim * sizeof(float));
 	c->pf_xn = frag(c->dim, NT);
@@ -1215,6 +1219,16 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	// Two forms of the GEMM (prefill.hip.h): k_pf_gemm_wide (256 units x 64 tokens per workgroup, no K split inside the workgroup)
 	// where its tiles cover enough of the chip, else the K-split form with S unit strips per wave (operands reused S times): the
 	// S whose grid costs the least (rounds of workgroups over the CUs x a workgroup's time); ties go to the larger S.
+	// Mixture of experts: the grouped GEMMs take the big form (128-token tiles: every expert's rows padded to whole 128-row columns by
+	// k_pf_route, gran 2) where the chunk packs enough rows for the larger tile to pay for the extra padding (on average 64 rows per
+	// expert) -- profiles/r05_prefill.txt; fp8 / gf4 weights.  Otherwise 64-row columns and the wide / K-split forms.
+	const int moe_gran = (c->n_experts > 0 && DB != 16 && g_pf_big && g_pf_moe_big && (g_pf_moe_big >= 2 || g_pf_big >= 2 || nb * c->n_active >= 1024)) ? 2 : 1;
+	// a grid of r rounds of workgroups over the CUs: whole rounds, and a last one that costs 0.6 of a round when it fills at most half
+	// the slots (measured: profiles/r04_prefill.txt), a full one otherwise
+	auto rounds_cost = [](double r) {
+		const double f = r - floor(r);
+		return floor(r) + (f < 1e-9 ? 0.0 : (f <= 0.5 ? 0.6 : 1.0));
+	};
 	auto gemm = [&](PfGemmArgs a, auto EPI, int ncols) {
 		constexpr int epi = decltype(EPI)::value;
 		constexpr int kvb = epi == PF_EPI_QKV ? KVB : 16; // only the QKV epilogue touches the cache
@@ -1252,7 +1266,26 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		if constexpr ((epi == PF_EPI_FFN_UP || epi == PF_EPI_STORE || epi == PF_EPI_RESID) && DB != 16) {
 			const int nxb = (a.M + PfBig<epi>::UNITS - 1) / PfBig<epi>::UNITS, ncb = (a.nb + PfBig<epi>::TOKENS - 1) / PfBig<epi>::TOKENS;
 			int kr = 1;
-			if (epi == PF_EPI_RESID && g_pf_big == 3) {
+			const bool grouped = a.col_expert != nullptr;
+			if (grouped && moe_gran != 2) {
+				kr = 0; // (64-row expert groups: the wide / K-split forms below)
+			} else if (grouped && epi == PF_EPI_STORE) {
+				// the experts' FFN-down (4096-6144 units: 8-12 tiles per token column): ranges of K by the rounds they leave, one workgroup
+				// per CU; the columns that will be live: the packed rows plus half a column of padding per expert
+				const int live = std::min(ncb, (nb * c->n_active + 127) / 128 + (c->n_experts + 1) / 2);
+				const double r1 = (double)nxb * live / g_ncu;
+				const size_t tiles_b = (size_t)8 * ((nxb + 7) / 8) * ncb;
+				double best = rounds_cost(r1);
+				for (int k = 2; k <= 4; k *= 2) {
+					if (pf_steps(a.K) / k < 48 || tiles_b * k * 4 > PF_SPLIT_SLOTS || tiles_b > (size_t)PF_SPLIT_TILES) {
+						break;
+					}
+					const double t = rounds_cost(r1 * k) / k * (1.0 + 0.03 * k);
+					if (t < 0.97 * best) {
+						best = t, kr = k;
+					}
+				}
+			} else if (epi == PF_EPI_RESID && g_pf_big == 3) {
 				kr = 0; // (A/B switch: the big form without the residual GEMM's ranges)
 			} else if (epi == PF_EPI_RESID) {
 				kr = g_ncu / (nxb * ncb);
@@ -1263,7 +1296,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 					kr = 0; // (the residual GEMM only in ranges: unsplit, its 4096 units are a quarter of the chip)
 				}
 			}
-			if (g_pf_big && kr >= 1 && !a.col_expert && (g_pf_big >= 2 || (long)nxb * ncb * kr * 8 >= (long)g_ncu * 5)) {
+			if (g_pf_big && kr >= 1 && (g_pf_big >= 2 || grouped || (long)nxb * ncb * kr * 8 >= (long)g_ncu * 5)) {
 				a.ncols = ncb, a.ksplit = kr, a.partial = c->pf_partial, a.tile_count = c->pf_tile_count;
 				auto kern = k_pf_gemm_big<DB, epi>;
 				allow_lds(kern, PfBigA<DB>::LDS_BYTES);
@@ -1295,17 +1328,13 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 			// at most half the slots leaves one workgroup per CU, which runs at ~0.6 of a full round's time, not 0.5 (hence nothing for the
 			// QKV GEMM's 1.5 rounds at 2048 tokens: measured 32.0 against 32.4 k tok/s with it split); a grid under one round gains nothing
 			// from ranges at all (TinyLlama's FFN-down: - 5 %).  profiles/r04_prefill.txt.
-			auto cost = [](double r) {
-				const double f = r - floor(r);
-				return floor(r) + (f < 1e-9 ? 0.0 : (f <= 0.5 ? 0.6 : 1.0));
-			};
 			const double r1 = (double)nx * ncols / (2.0 * g_ncu);
-			double best = cost(r1);
+			double best = rounds_cost(r1);
 			for (int k = 2; k <= 4 && r1 > 1.0; k *= 2) {
 				if (nsteps / k < 16 || (size_t)tiles * k > PF_SPLIT_SLOTS || tiles > PF_SPLIT_TILES) {
 					break;
 				}
-				const double t = cost(r1 * k) / k * (1.0 + 0.03 * k);
+				const double t = rounds_cost(r1 * k) / k * (1.0 + 0.03 * k);
 				if (t < 0.97 * best) {
 					best = t, ks = k;
 				}
@@ -1380,9 +1409,9 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		// residual in rank order
 		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->n_experts, a.w0 = w->moegate[l], a.out = c->pf_gate;
 		hipLaunchKernelGGL((k_pf_gemm<DB, 16, PF_EPI_STORE, 1>), dim3((a.M + 31) / 32, cols), block, 0, g_stream, a);
-		const int ecols = (nb * c->n_active + 63) / 64 + c->n_experts; // worst case for this chunk
-		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, ecols, c->pf_rows, c->pf_colexp, c->pf_slot,
-		                   c->pf_wsel);
+		const int ecols = ((nb * c->n_active + 63) / 64 + moe_gran * c->n_experts + moe_gran - 1) / moe_gran * moe_gran; // worst case for this chunk
+		hipLaunchKernelGGL(k_pf_route, dim3(1), dim3(PF_NT), 0, g_stream, c->pf_gate, nb, c->n_experts, c->n_active, ecols, moe_gran, c->pf_rows, c->pf_colexp,
+		                   c->pf_slot, c->pf_wsel);
 		hipLaunchKernelGGL(k_pf_gather, dim3(ecols * 2, (pf_steps(c->dim) + 7) / 8), block, 0, g_stream, (float4*)c->pf_xe, (const float4*)c->pf_xn, c->pf_rows, c->pf_colexp,
 		                   c->dim);
 		PfGemmArgs m = a;
@@ -1522,6 +1551,11 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 	} else if (!strcmp(key, "pf_chunk")) {
 		CALM_REQUIRE(value < 0 || (value >= PF_NT && value <= PF_NT_DENSE && value % 128 == 0), "calm_hip_configure(\"pf_chunk\"): 1024 ... 2048 in steps of 128");
 		slot = &g_pf_chunk;
+	} else if (!strcmp(key, "pf_chunk_moe")) {
+		CALM_REQUIRE(value < 0 || value == PF_NT || value == PF_NT_MOE, "calm_hip_configure(\"pf_chunk_moe\"): 1024 or 2048");
+		slot = &g_pf_chunk_moe;
+	} else if (!strcmp(key, "pf_moe_big")) {
+		slot = &g_pf_moe_big;
 	} else if (!strcmp(key, "pf_attn_mfma")) {
 		slot = &g_pf_attn_mfma;
 	} else if (!strcmp(key, "pf_skinny")) {
@@ -1655,6 +1689,9 @@ extern "C" void init_hip(void) {
 	g_pf_big = env_int("CALM_HIP_PF_BIG", g_pf_big);
 	g_pf_chunk = env_int("CALM_HIP_PF_CHUNK", g_pf_chunk);
 	CALM_REQUIRE(g_pf_chunk >= PF_NT && g_pf_chunk <= PF_NT_DENSE && g_pf_chunk % 128 == 0, "CALM_HIP_PF_CHUNK: 1024 ... 2048 in steps of 128");
+	g_pf_chunk_moe = env_int("CALM_HIP_PF_CHUNK_MOE", g_pf_chunk_moe);
+	CALM_REQUIRE(g_pf_chunk_moe == PF_NT || g_pf_chunk_moe == PF_NT_MOE, "CALM_HIP_PF_CHUNK_MOE: 1024 or 2048");
+	g_pf_moe_big = env_int("CALM_HIP_PF_MOE_BIG", g_pf_moe_big);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
 	g_pf_score_mb = env_int("CALM_HIP_PF_SCORE_MB", g_pf_score_mb);

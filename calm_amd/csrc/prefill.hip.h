@@ -41,7 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PF_NT = 1024; // tokens per chunk of a mixture-of-experts model (k_pf_route: one thread per token), and the least a dense model's is
+constexpr int PF_NT = 1024; // the least a dense model's prompt chunk is (and k_pf_route's workgroup; mixture-of-experts chunks: PF_NT_MOE)
 // Dense models take chunks of up to PF_NT_DENSE tokens (knob "pf_chunk"): at 1024 tokens the grids of the QKV / wo / w2 GEMMs cover 256-384
 // of the 512 workgroup slots, at 2048 all of them -- + 4...11 % per GEMM (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt)
 constexpr int PF_NT_DENSE = 2048;
@@ -166,88 +166,102 @@ __global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, cons
 
 // Mixture-of-experts routing of a chunk (src/infer.c:277-305 per token): top-k by logit, first maximum wins
 // ties, weights = softmax over the selected logits.  The (token, rank) pairs are then packed expert by expert
-// into rows of ONE matrix, every expert's group padded to whole 64-row workgroup columns, so that a single
-// grouped GEMM launch serves all experts:
-//   rows[r]      token of packed row r, or -1 for padding          col_expert[c]  expert of column c, -1 past the end
+// into rows of ONE matrix, every expert's group padded to whole workgroup columns -- `gran` 64-row columns at a time: 1 for the
+// K-split / wide GEMM forms, 2 where the grouped GEMMs take the big form's 128-token tiles -- so that a single grouped GEMM launch
+// serves all experts:
+//   rows[r]      token of packed row r, or -1 for padding          col_expert[c]  expert of 64-row column c, -1 past the end
 //   slot[t*k+j]  packed row of token t's rank-j expert             wsel[t*k+j]    its routing weight
-// One workgroup of PF_NT threads, thread t = token t; everything is in token order (deterministic): a token's place in its
-// expert's group is the number of earlier tokens routed to that expert -- a ballot per expert within the wave plus the waves'
-// counts (a token routes to an expert at most once).
-__global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int max_cols, int* rows, int* col_expert, int* slot,
+// One workgroup of PF_NT threads, thread t = tokens t and t + PF_NT (chunks of up to PF_NT_MOE = 2 PF_NT tokens); everything is in
+// token order (deterministic): a token's place in its expert's group is the number of earlier tokens routed to that expert -- a
+// ballot per expert within the wave plus the counts of the (pass, wave) pairs before it (a token routes to an expert at most once).
+constexpr int PF_ROUTE_TPT = 2;                 // tokens per thread of k_pf_route
+constexpr int PF_NT_MOE = PF_ROUTE_TPT * PF_NT; // tokens per chunk of a mixture-of-experts model
+__global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int max_cols, int gran, int* rows, int* col_expert, int* slot,
                                                     float* wsel) {
-	constexpr int NW = PF_NT / 64;
-	__shared__ int wave_cnt[CALM_MAX_EXPERTS][NW]; // tokens of wave w routed to expert e, then the exclusive prefix over w
+	constexpr int NW = PF_NT / 64, TPT = PF_ROUTE_TPT;
+	__shared__ int wave_cnt[CALM_MAX_EXPERTS][TPT * NW]; // tokens of (pass, wave) routed to expert e, then the exclusive prefix over them
 	__shared__ int first_col[CALM_MAX_EXPERTS + 1];
 	__shared__ int cnt[CALM_MAX_EXPERTS];
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	int mine[PF_MAX_ACTIVE], inwave[PF_MAX_ACTIVE];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	int mine[TPT][PF_MAX_ACTIVE], inwave[TPT][PF_MAX_ACTIVE];
 #pragma unroll
-	for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
-		mine[k] = -1, inwave[k] = 0;
+	for (int p = 0; p < TPT; ++p) {
+#pragma unroll
+		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+			mine[p][k] = -1, inwave[p][k] = 0;
+		}
 	}
-	if (t < nb) {
-		const float* g = gate + (size_t)t * n_experts;
-		float max_val = -3.402823466e+38f;
-		for (int j = 0; j < n_experts; ++j) {
-			max_val = max_val < g[j] ? g[j] : max_val;
-		}
-		unsigned long long mask = 0;
-		float wsum = 0.f;
 #pragma unroll
-		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
-			if (k < n_active) {
-				int best = -1;
-				for (int j = 0; j < n_experts; ++j) {
-					if ((mask & (1ull << j)) == 0 && (best == -1 || g[j] > g[best])) {
-						best = j;
-					}
-				}
-				mine[k] = best;
-				wsum += expf(g[best] - max_val);
-				mask |= 1ull << best;
+	for (int p = 0; p < TPT; ++p) {
+		const int t = p * PF_NT + threadIdx.x;
+		if (t < nb) {
+			const float* g = gate + (size_t)t * n_experts;
+			float max_val = -3.402823466e+38f;
+			for (int j = 0; j < n_experts; ++j) {
+				max_val = max_val < g[j] ? g[j] : max_val;
 			}
-		}
+			unsigned long long mask = 0;
+			float wsum = 0.f;
 #pragma unroll
-		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
-			if (k < n_active) {
-				wsel[t * n_active + k] = expf(g[mine[k]] - max_val) / wsum;
+			for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+				if (k < n_active) {
+					int best = -1;
+					for (int j = 0; j < n_experts; ++j) {
+						if ((mask & (1ull << j)) == 0 && (best == -1 || g[j] > g[best])) {
+							best = j;
+						}
+					}
+					mine[p][k] = best;
+					wsum += expf(g[best] - max_val);
+					mask |= 1ull << best;
+				}
+			}
+#pragma unroll
+			for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+				if (k < n_active) {
+					wsel[t * n_active + k] = expf(g[mine[p][k]] - max_val) / wsum;
+				}
 			}
 		}
 	}
 	const unsigned long long below = (1ull << lane) - 1;
 	for (int e = 0; e < n_experts; ++e) {
-		bool to_e = false;
 #pragma unroll
-		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
-			to_e |= mine[k] == e;
-		}
-		const unsigned long long m = __ballot(to_e);
-		if (lane == 0) {
-			wave_cnt[e][wave] = __popcll(m);
-		}
+		for (int p = 0; p < TPT; ++p) {
+			bool to_e = false;
 #pragma unroll
-		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
-			if (mine[k] == e) {
-				inwave[k] = __popcll(m & below);
+			for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+				to_e |= mine[p][k] == e;
+			}
+			const unsigned long long m = __ballot(to_e);
+			if (lane == 0) {
+				wave_cnt[e][p * NW + wave] = __popcll(m);
+			}
+#pragma unroll
+			for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+				if (mine[p][k] == e) {
+					inwave[p][k] = __popcll(m & below);
+				}
 			}
 		}
 	}
 	__syncthreads();
-	if (t < n_experts) {
+	if ((int)threadIdx.x < n_experts) {
 		int c = 0;
-		for (int w = 0; w < NW; ++w) {
-			const int n = wave_cnt[t][w];
-			wave_cnt[t][w] = c;
+		for (int w = 0; w < TPT * NW; ++w) { // (pass-major: tokens 0 .. PF_NT - 1 come before PF_NT ..)
+			const int n = wave_cnt[threadIdx.x][w];
+			wave_cnt[threadIdx.x][w] = c;
 			c += n;
 		}
-		cnt[t] = c;
+		cnt[threadIdx.x] = c;
 	}
 	__syncthreads();
-	if (t == 0) {
+	if (threadIdx.x == 0) {
 		int col = 0;
 		for (int e = 0; e < n_experts; ++e) {
 			first_col[e] = col;
-			for (int c = 0; c < (cnt[e] + 63) / 64; ++c) {
+			const int ncols = (cnt[e] + 64 * gran - 1) / (64 * gran) * gran;
+			for (int c = 0; c < ncols; ++c) {
 				col_expert[col++] = e;
 			}
 		}
@@ -258,16 +272,20 @@ __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, i
 	}
 	__syncthreads();
 #pragma unroll
-	for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
-		if (mine[k] >= 0) {
-			const int r = first_col[mine[k]] * 64 + wave_cnt[mine[k]][wave] + inwave[k];
-			rows[r] = t;
-			slot[t * n_active + k] = r;
+	for (int p = 0; p < TPT; ++p) {
+		const int t = p * PF_NT + threadIdx.x;
+#pragma unroll
+		for (int k = 0; k < PF_MAX_ACTIVE; ++k) {
+			if (mine[p][k] >= 0) {
+				const int r = first_col[mine[p][k]] * 64 + wave_cnt[mine[p][k]][p * NW + wave] + inwave[p][k];
+				rows[r] = t;
+				slot[t * n_active + k] = r;
+			}
 		}
 	}
-	// the padding of every expert's last column
+	// the padding of every expert's last column(s)
 	for (int e = 0; e < n_experts; ++e) {
-		for (int r = first_col[e] * 64 + cnt[e] + t; r < first_col[e + 1] * 64; r += PF_NT) {
+		for (int r = first_col[e] * 64 + cnt[e] + threadIdx.x; r < first_col[e + 1] * 64; r += PF_NT) {
 			rows[r] = -1;
 		}
 	}
@@ -1680,6 +1698,14 @@ __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 		return;
 	}
 	const int unit_wg = bx * PfBig<EPI>::UNITS, tok_wg = by * 128;
+	size_t expert_off = 0;
+	if (a.col_expert) { // a grouped GEMM (mixture of experts): k_pf_route padded every expert's rows to whole 128-row columns (gran 2)
+		const int e = a.col_expert[2 * by];
+		if (e < 0) {
+			return;
+		}
+		expert_off = (size_t)e * a.expert_stride;
+	}
 	const size_t row_bytes = (size_t)a.K * DB / 8;
 	const int row_pieces = (int)(row_bytes / 16);
 	const int nsteps = pf_steps(a.K);
@@ -1692,9 +1718,9 @@ __global__ __launch_bounds__(512, 1) void k_pf_gemm_big(PfGemmArgs a) {
 	for (int q = 0; q < NQ; ++q) {
 		const int r = half * 64 + q * RPL + lane / PR;
 		if constexpr (EPI == PF_EPI_FFN_UP) {
-			rowq[q] = (const unsigned char*)(half ? a.w1 : a.w0) + (size_t)min(unit_wg + strip * 64 + (r & 63), a.M - 1) * row_bytes;
+			rowq[q] = (const unsigned char*)(half ? a.w1 : a.w0) + expert_off + (size_t)min(unit_wg + strip * 64 + (r & 63), a.M - 1) * row_bytes;
 		} else {
-			rowq[q] = (const unsigned char*)a.w0 + (size_t)min(unit_wg + strip * 128 + r, a.M - 1) * row_bytes;
+			rowq[q] = (const unsigned char*)a.w0 + expert_off + (size_t)min(unit_wg + strip * 128 + r, a.M - 1) * row_bytes;
 		}
 	}
 	const float4* xg = a.xin + (size_t)(tok_wg >> 5) * nsteps * 512 + lane;

@@ -999,6 +999,51 @@ def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
         ksplit.close()
 
 
+@pytest.mark.parametrize("dtype,experts,active", [("fp8", 6, 2), ("gf4", 4, 3), ("fp16", 5, 2)])
+def test_prefill_mixture_chunks_of_2048_tokens_and_128_row_expert_groups(hiplib, dtype, experts, active):
+    """Round 5: a mixture-of-experts chunk holds up to 2048 tokens (k_pf_route: two tokens per thread, packed in token order) and, for
+    fp8 / gf4 weights, pads every expert's rows to whole 128-row columns so that the grouped GEMMs run in the big form (k_pf_gemm_big,
+    FFN-down in ranges of K).  A 1500-token prompt as ONE chunk in that form, against the same prompt (a) in 64-row groups through the
+    wide / K-split forms ("pf_moe_big" 0), (b) in chunks of 1024 + 476 ("pf_chunk_moe" 1024): fp32-rounding apart; the scored
+    log-probabilities likewise; and the logits behind the prompt against the oracle.  (fp16 weights keep 64-row groups: same checks.)"""
+    spec = cf.tiny_spec("pfmoe", max_seq_len=1536, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=400, n_layers=2,
+                        n_experts=experts, n_experts_active=active)
+    tensors, md = cf.synth_model(spec, dtype, seed=41)
+    model = HostModel(tensors, md)
+    rng = np.random.default_rng(14)
+    n = 1500
+    toks = [int(t) for t in rng.integers(0, 400, size=n + 1)]
+
+    def run(knobs):
+        old = {k: hiplib.calm_hip_configure(k, v) for k, v in knobs.items()}
+        b = HipBackend(model)
+        try:
+            lp = b.prefill_logprobs(toks, 0).copy()  # (also fills the cache over positions 0 .. n)
+            b.prefill(toks[:n], 0)
+            return b.forward(toks[n], n, 0).copy(), lp
+        finally:
+            b.close()
+            for k, v in old.items():
+                hiplib.calm_hip_configure(k, v)
+
+    l_big, lp_big = run({})
+    l_small, lp_small = run({b"pf_moe_big": 0})
+    l_two, lp_two = run({b"pf_chunk_moe": 1024})
+    assert np.isfinite(l_big).all() and np.isfinite(lp_big).all()
+    assert rel_err(l_big, l_small) < 2e-4, rel_err(l_big, l_small)
+    assert rel_err(l_big, l_two) < 2e-4, rel_err(l_big, l_two)
+    assert np.abs(lp_big - lp_small).max() < 2e-3 * max(1.0, float(np.abs(lp_small).max()))
+    assert np.abs(lp_big - lp_two).max() < 2e-3 * max(1.0, float(np.abs(lp_two).max()))
+    o = oracle.OracleBackend(model)
+    try:
+        for pos, tok in enumerate(toks[:n]):
+            o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
+        lo = o.forward(toks[n], n, 0).copy()
+    finally:
+        o.close()
+    assert rel_err(l_big, lo) < LOGIT_TOL, rel_err(l_big, lo)
+
+
 @pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 2), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1), ("dbrx-132b", "fp8", 1)])
 def test_prefill_full_width_matches_serial(hiplib, name, dtype, layers):
     """BASELINE shapes at full width (1-2 layers): 100-token prompt, batched vs serial ingestion on the GPU, and
