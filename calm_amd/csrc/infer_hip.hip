@@ -105,9 +105,9 @@ int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one
 int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
 int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
-int g_pf_chunk_moe = PF_NT_MOE; // ... of a mixture-of-experts model (PF_NT or PF_NT_MOE; read at the same moment)
-int g_pf_moe_big = 1;  // the grouped GEMMs of a mixture of experts in the big form, every expert's rows padded to whole 128-row columns: 1 = from 1024 packed
-                       // rows per chunk (the rule in prefill_chunk), 0 = never (64-row columns, the wide / K-split forms), 2 = always (tests)
+int g_pf_chunk_moe = PF_NT_MOE; // ... of a mixture-of-experts model (1024, 2048 or 4096 = PF_NT_MOE; read at the same moment)
+int g_pf_moe_big = 1;  // the grouped GEMMs of a mixture of experts in the big form, every expert's rows padded to whole 128-row columns: 1 = from 64 packed
+                       // rows per expert on average (the rule in prefill_chunk), 0 = never (64-row columns, the wide / K-split forms), 2 = always (tests)
 int g_pf_chunk = PF_NT_DENSE; // tokens per prompt chunk of a dense model (read when a model's prompt buffers are allocated; PF_NT ... PF_NT_DENSE)
 int g_pf_rounds = 1;   // ... the wide form in 2 / 4 ranges of K where its last round of workgroups would be mostly empty (0: whole rows only; A/B switch)
 int g_pf_big = 1;      // ... and the big form (512 units x 128 tokens per workgroup) for the FFN-up / classifier of long chunks (0: never; 2: always, for tests)
@@ -1221,8 +1221,9 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	// S whose grid costs the least (rounds of workgroups over the CUs x a workgroup's time); ties go to the larger S.
 	// Mixture of experts: the grouped GEMMs take the big form (128-token tiles: every expert's rows padded to whole 128-row columns by
 	// k_pf_route, gran 2) where the chunk packs enough rows for the larger tile to pay for the extra padding (on average 64 rows per
-	// expert) -- profiles/r05_prefill.txt; fp8 / gf4 weights.  Otherwise 64-row columns and the wide / K-split forms.
-	const int moe_gran = (c->n_experts > 0 && DB != 16 && g_pf_big && g_pf_moe_big && (g_pf_moe_big >= 2 || g_pf_big >= 2 || nb * c->n_active >= 1024)) ? 2 : 1;
+	// expert): from an average of 64 packed rows per expert -- Mixtral-8x7B from 256 tokens (+ 6 %; + 17 % at 1536), DBRX-132B from 256
+	// (+ 18 %), both behind at half that (profiles/r05_prefill.txt); fp8 / gf4 weights.  Otherwise 64-row columns and the wide / K-split forms.
+	const int moe_gran = (c->n_experts > 0 && DB != 16 && g_pf_big && g_pf_moe_big && (g_pf_moe_big >= 2 || g_pf_big >= 2 || nb * c->n_active >= 64 * c->n_experts)) ? 2 : 1;
 	// a grid of r rounds of workgroups over the CUs: whole rounds, and a last one that costs 0.6 of a round when it fills at most half
 	// the slots (measured: profiles/r04_prefill.txt), a full one otherwise
 	auto rounds_cost = [](double r) {
@@ -1552,7 +1553,7 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		CALM_REQUIRE(value < 0 || (value >= PF_NT && value <= PF_NT_DENSE && value % 128 == 0), "calm_hip_configure(\"pf_chunk\"): 1024 ... 2048 in steps of 128");
 		slot = &g_pf_chunk;
 	} else if (!strcmp(key, "pf_chunk_moe")) {
-		CALM_REQUIRE(value < 0 || value == PF_NT || value == PF_NT_MOE, "calm_hip_configure(\"pf_chunk_moe\"): 1024 or 2048");
+		CALM_REQUIRE(value < 0 || value == 1024 || value == 2048 || value == PF_NT_MOE, "calm_hip_configure(\"pf_chunk_moe\"): 1024, 2048 or 4096");
 		slot = &g_pf_chunk_moe;
 	} else if (!strcmp(key, "pf_moe_big")) {
 		slot = &g_pf_moe_big;
@@ -1690,7 +1691,7 @@ extern "C" void init_hip(void) {
 	g_pf_chunk = env_int("CALM_HIP_PF_CHUNK", g_pf_chunk);
 	CALM_REQUIRE(g_pf_chunk >= PF_NT && g_pf_chunk <= PF_NT_DENSE && g_pf_chunk % 128 == 0, "CALM_HIP_PF_CHUNK: 1024 ... 2048 in steps of 128");
 	g_pf_chunk_moe = env_int("CALM_HIP_PF_CHUNK_MOE", g_pf_chunk_moe);
-	CALM_REQUIRE(g_pf_chunk_moe == PF_NT || g_pf_chunk_moe == PF_NT_MOE, "CALM_HIP_PF_CHUNK_MOE: 1024 or 2048");
+	CALM_REQUIRE(g_pf_chunk_moe == 1024 || g_pf_chunk_moe == 2048 || g_pf_chunk_moe == PF_NT_MOE, "CALM_HIP_PF_CHUNK_MOE: 1024, 2048 or 4096");
 	g_pf_moe_big = env_int("CALM_HIP_PF_MOE_BIG", g_pf_moe_big);
 	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
 	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
@@ -2320,7 +2321,7 @@ void prefill_impl(struct Transformer* t, const int* tokens, int n, int pos, floa
 			if (nb <= 2) {
 				break; // a chunk costs about three decode steps whatever its size (it streams every weight once, less efficiently)
 			}
-			int target[PF_NT_DENSE];
+			int target[PF_NT_MOE > PF_NT_DENSE ? PF_NT_MOE : PF_NT_DENSE];
 			const int k = (int)chunk_start.size() < PF_FLAG_WORDS ? (int)chunk_start.size() : PF_FLAG_WORDS - 1;
 			chunk_start.push_back(done);
 			for (int s = 0; s < P; ++s) {

@@ -171,11 +171,11 @@ __global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, cons
 // serves all experts:
 //   rows[r]      token of packed row r, or -1 for padding          col_expert[c]  expert of 64-row column c, -1 past the end
 //   slot[t*k+j]  packed row of token t's rank-j expert             wsel[t*k+j]    its routing weight
-// One workgroup of PF_NT threads, thread t = tokens t and t + PF_NT (chunks of up to PF_NT_MOE = 2 PF_NT tokens); everything is in
+// One workgroup of PF_NT threads, thread t = tokens t, t + PF_NT, ... (chunks of up to PF_NT_MOE = 4 PF_NT tokens); everything is in
 // token order (deterministic): a token's place in its expert's group is the number of earlier tokens routed to that expert -- a
 // ballot per expert within the wave plus the counts of the (pass, wave) pairs before it (a token routes to an expert at most once).
-constexpr int PF_ROUTE_TPT = 2;                 // tokens per thread of k_pf_route
-constexpr int PF_NT_MOE = PF_ROUTE_TPT * PF_NT; // tokens per chunk of a mixture-of-experts model
+constexpr int PF_ROUTE_TPT = 4;                 // tokens per thread of k_pf_route
+constexpr int PF_NT_MOE = PF_ROUTE_TPT * PF_NT; // the most a mixture-of-experts model's chunk is (knob "pf_chunk_moe"; default 2048)
 __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int max_cols, int gran, int* rows, int* col_expert, int* slot,
                                                     float* wsel) {
 	constexpr int NW = PF_NT / 64, TPT = PF_ROUTE_TPT;

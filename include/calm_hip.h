@@ -106,7 +106,7 @@ float* decode_sample_hip(struct Transformer* transformer, int token, int pos, in
 /* Batched prompt ingestion: the KV-cache effect of
  *     for (i = 0; i < n; ++i) forward_hip(transformer, tokens[i], pos + i, FF_UPDATE_KV_ONLY);
  * i.e. of the reference's serial prompt loop (src/run.c:208,216-218; README.md:80 "prompt processing is
- * serial"), computed up to 2048 tokens at a time (mixture-of-experts models: 1024): weights are streamed once per chunk and the multiply-adds run on
+ * serial"), computed up to 2048 tokens at a time (mixture-of-experts models: 4096): weights are streamed once per chunk and the multiply-adds run on
  * the f16 matrix cores with the fp32 activations carried as hi + lo binary16 (every product exact, fp32 accumulation:
  * 3-7e-7 per GEMM), so the cache rows agree with the serial path to fp32 rounding.  A chunk in which an activation leaves the binary16 range (beyond +-65504, or NaN)
  * is redone token by token through the serial fp32 decode path inside the call (knob "pf_redone" counts such tokens).
@@ -183,7 +183,10 @@ const char* calm_hip_device_name(void);
  *       512-unit x 128-token GEMM form for every dense fp8 / gf4 FFN-up and classifier whatever its grid -- a test switch)
  *   "pf_rounds": 1 = a prompt GEMM whose last round of workgroups would be mostly empty runs in 2 / 4 ranges of K (0: never; A/B switch)
  *   "pf_chunk": tokens per prompt chunk of a dense model, 1024 ... 2048 in steps of 128 (default 2048; read when a model's prompt
- *       buffers are allocated, i.e. at its first prefill_hip call; mixture-of-experts models always take 1024)
+ *       buffers are allocated, i.e. at its first prefill_hip call)
+ *   "pf_chunk_moe": ... of a mixture-of-experts model: 1024, 2048 or 4096 (default 4096; read at the same moment)
+ *   "pf_moe_big": the grouped GEMMs of a mixture-of-experts chunk in the 512-unit x 128-token form, every expert's rows padded to whole
+ *       128-row columns: 1 = where a chunk packs at least 64 rows per expert on average (fp8 / gf4 weights), 0 = never, 2 = always (tests)
  *   "pf_score_mb": MiB of device scratch for the logits of prefill_logprobs_hip (default 256; read when that scratch is allocated, at a
  *       model's first scoring call): a chunk is scored in blocks of as many tokens as fit (whole 128-token columns, at least 128)
  *   "stage"     multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip)

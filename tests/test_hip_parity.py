@@ -956,7 +956,7 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
 
 @pytest.mark.parametrize("name,dtype", [("mistral-7b", "fp8"), ("llama-3-8b", "gf4"), ("tinyllama-1.1b", "fp16"), ("mixtral-8x7b", "fp8")])
 def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
-    """BASELINE widths, one layer, a 1100-token prompt (one chunk for a dense model, 1024 + 76 for the mixture of experts): every GEMM
+    """BASELINE widths, one layer, a 1100-token prompt (one chunk; the mixture of experts' grouped GEMMs in the big form too): every GEMM
     of the long chunk runs in the wide form (k_pf_gemm_wide: B staged through LDS, no K split) -- the FFN-up and the classifier of the dense fp8 / gf4 models in
     the big form (k_pf_gemm_big: 512 units x 128 tokens per workgroup), as is the FFN-down with K cut into ranges -- a short chunk in the
     K-split form.  Against serial
@@ -1001,17 +1001,17 @@ def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
 
 @pytest.mark.parametrize("dtype,experts,active", [("fp8", 6, 2), ("gf4", 4, 3), ("fp16", 5, 2)])
 def test_prefill_mixture_chunks_of_2048_tokens_and_128_row_expert_groups(hiplib, dtype, experts, active):
-    """Round 5: a mixture-of-experts chunk holds up to 2048 tokens (k_pf_route: two tokens per thread, packed in token order) and, for
+    """Round 5: a mixture-of-experts chunk holds up to 4096 tokens (k_pf_route: four tokens per thread, packed in token order) and, for
     fp8 / gf4 weights, pads every expert's rows to whole 128-row columns so that the grouped GEMMs run in the big form (k_pf_gemm_big,
-    FFN-down in ranges of K).  A 1500-token prompt as ONE chunk in that form, against the same prompt (a) in 64-row groups through the
-    wide / K-split forms ("pf_moe_big" 0), (b) in chunks of 1024 + 476 ("pf_chunk_moe" 1024): fp32-rounding apart; the scored
+    FFN-down in ranges of K).  A 3000-token prompt as ONE chunk in that form, against the same prompt (a) in 64-row groups through the
+    wide / K-split forms ("pf_moe_big" 0), (b) in chunks of 1024 + 1024 + 952 ("pf_chunk_moe" 1024): fp32-rounding apart; the scored
     log-probabilities likewise; and the logits behind the prompt against the oracle.  (fp16 weights keep 64-row groups: same checks.)"""
-    spec = cf.tiny_spec("pfmoe", max_seq_len=1536, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=400, n_layers=2,
+    spec = cf.tiny_spec("pfmoe", max_seq_len=3072, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=400, n_layers=2,
                         n_experts=experts, n_experts_active=active)
     tensors, md = cf.synth_model(spec, dtype, seed=41)
     model = HostModel(tensors, md)
     rng = np.random.default_rng(14)
-    n = 1500
+    n = 3000
     toks = [int(t) for t in rng.integers(0, 400, size=n + 1)]
 
     def run(knobs):
