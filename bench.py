@@ -355,7 +355,7 @@ def main():
     # activation as hi + lo binary16), so the peak in algorithmic FLOPs is half the 2.5 PF dense f16 peak (MI355X_MICROARCH.md)
     prefill = None
     if not args.no_device_greedy:
-        n_pf = min(2048, model.config.seq_len - 1)
+        n_pf = min(4095 if spec.n_experts else 2048, model.config.seq_len - 1)  # one chunk: 2048 tokens for a dense model, up to 4096 for a mixture of experts
         prompt = [int(t) for t in np.random.default_rng(args.seed).integers(0, spec.vocab_size, size=n_pf)]
         be.prefill(prompt[:64], 0)
         be.prefill(prompt, 0)

@@ -6,15 +6,13 @@ Loads a test-hook library (tools/experiments/libcalm_hip_test_r04.so = round 4's
 output with a NULL-stream hipMemset ahead of a launch on the non-blocking decode stream; calm_amd/libcalm_hip_test.so = this
 round's, every fill ordered on the decode stream) and hammers the failing shape -- a 256 x 14336 fp8 matvec (k_attn_out:
 x += W.v on a zeroed x) -- alternating the input between x and 8 x, the test's own property.  Counts calls whose output is
-all zeros / differs from the first answer, once with the host idle between calls and once with a second thread keeping the
-NULL stream busy with device-to-device copies (what a neighbouring test's hipMemcpy does to the ordering).
-Output: one JSON line per mode.  Test infrastructure, not product code.
+all zeros / differs from the first answer.  Output: one JSON line.  Test infrastructure, not product code.
+(Round 5, one MI355X: 0 of 3000 calls with either library -- the driver's red run did not reproduce in isolation; profiles/r05_gpu_tests.txt.)
 """
 import ctypes as C
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -48,35 +46,16 @@ def main():
     assert np.abs(ref).max() > 0, "the very first call returned zeros"
     ref8 = ref * np.float32(8)
 
-    for mode in ("idle", "null_stream_busy"):
-        stop = threading.Event()
-        th = None
-        if mode == "null_stream_busy":
-            import torch  # device-to-device copies on the NULL stream from a second host thread
-
-            a = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
-            b = torch.empty_like(a)
-
-            def spin():
-                while not stop.is_set():
-                    b.copy_(a)
-                    torch.cuda.synchronize()
-
-            th = threading.Thread(target=spin, daemon=True)
-            th.start()
-        zeros = wrong = 0
-        t0 = time.time()
-        for i in range(iters):
-            v, r = (x8, ref8) if i & 1 else (x, ref)
-            o = call(v)
-            if not o.any():
-                zeros += 1
-            elif not np.array_equal(o, r):
-                wrong += 1
-        stop.set()
-        if th:
-            th.join()
-        print(json.dumps({"lib": os.path.relpath(path, ROOT), "mode": mode, "calls": iters, "all_zero": zeros, "other_mismatch": wrong, "seconds": round(time.time() - t0, 1)}), flush=True)
+    zeros = wrong = 0
+    t0 = time.time()
+    for i in range(iters):
+        v, r = (x8, ref8) if i & 1 else (x, ref)
+        o = call(v)
+        if not o.any():
+            zeros += 1
+        elif not np.array_equal(o, r):
+            wrong += 1
+    print(json.dumps({"lib": os.path.relpath(path, ROOT), "calls": iters, "all_zero": zeros, "other_mismatch": wrong, "seconds": round(time.time() - t0, 1)}), flush=True)
 
 
 if __name__ == "__main__":
