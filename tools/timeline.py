@@ -41,12 +41,15 @@ b = HipBackend(model, device_synth=(spec, dtype, 1, L))
 lib = b.lib._product
 lib.calm_tl_arm.argtypes = [C.c_int]
 lib.calm_tl_read.argtypes = [C.c_void_p, C.c_int]
-for pos in range(64):
+for pos in range(int(os.environ.get("TL_POS", "64"))):  # the cache length the attention stage then meets
     b.forward(5 + pos, pos, 0)
+ONLY = os.environ.get("TL_ONLY", "").split()  # e.g. TL_ONLY=attn
 waves = 8192
 print(f"{name} {dtype} L={L}; us after the launch's first wave started; stage time = perf_stage_hip of the INSTRUMENTED build")
 print(f"{'kernel':9s} {'us/launch':>9s} {'waves':>6s} | last wave start | image built p50 / max | first tile done p50 / max | exits p1 / p10 / p50 / p90 / p99 / last")
 for i, st in enumerate(STAGES):
+    if ONLY and st not in ONLY:
+        continue
     if st == "attn":
         # k_attn (contexts up to 384 positions): entry / cache length known / positions folded in / lane groups merged / barrier / exit
         lib.calm_tl_arm(waves)
