@@ -14,18 +14,24 @@ P = os.path.join(ROOT, "profiles")
 for f in (f"{tag}_kernel_stats.md", f"{tag}_kernel_stats.json", f"{tag}_pmc.json"):
     if os.path.exists(os.path.join(F, f)):
         shutil.copy(os.path.join(F, f), os.path.join(P, f))
-shutil.copy(os.path.join(F, "kernel_bytes.json"), os.path.join(P, f"{tag}_kernel_bytes.json"))
-line = [l for l in open(os.path.join(F, "bench.json")) if l.startswith("{")][-1]
-open(os.path.join(P, f"{tag}_bench.json"), "w").write(line)
-shutil.copy(os.path.join(F, "other_configs.jsonl"), os.path.join(P, f"{tag}_other_configs_full_size.jsonl"))
-with open(os.path.join(P, f"{tag}_reference_cli_on_hip.txt"), "w") as o:
+if os.path.exists(os.path.join(F, "kernel_bytes.json")):
+    shutil.copy(os.path.join(F, "kernel_bytes.json"), os.path.join(P, f"{tag}_kernel_bytes.json"))
+for src, dst in (("bench.json", f"{tag}_bench.json"), ("bench_steps20.json", f"{tag}_bench_steps20.json")):
+    if os.path.exists(os.path.join(F, src)):
+        line = [l for l in open(os.path.join(F, src)) if l.startswith("{")][-1]
+        open(os.path.join(P, dst), "w").write(line)
+if os.path.exists(os.path.join(F, "other_configs.jsonl")):
+    shutil.copy(os.path.join(F, "other_configs.jsonl"), os.path.join(P, f"{tag}_other_configs_full_size.jsonl"))
+if os.path.exists(os.path.join(F, "cli_poso_0.out")):
+  with open(os.path.join(P, f"{tag}_reference_cli_on_hip.txt"), "w") as o:
     o.write(f"Round {int(tag[1:])}: the reference's own CLI (src/run.c, built as oracle/_ref/run_hip against libcalm_hip.so) on the HIP backend, Mistral-7B fp8 shape at full depth\n"
             "(tools/gpu_final.sh section 4; CALM_POSO shifts the positions: the first and the last 32 positions of a 4096-token context)\n")
     for p in (0, 4064):
         o.write(f"-- CALM_POSO={p}\n")
         o.write(open(os.path.join(F, f"cli_poso_{p}.out")).read()[:400] + "\n")
         o.write("".join(open(os.path.join(F, f"cli_poso_{p}.err")).readlines()[-3:]))
-with open(os.path.join(P, f"{tag}_gpu_tests.txt"), "w") as o:
+if os.path.exists(os.path.join(F, "pytest_gpu.log")):  # (round 5: the suite's record is profiles/r05_gpu_tests.txt, from tools/gpu_suite_repeat.sh)
+  with open(os.path.join(P, f"{tag}_gpu_tests.txt"), "w") as o:
     o.write(f"Round {int(tag[1:])}: pytest -m gpu on the MI355X box (tools/gpu_final.sh section 0)\n")
     o.write("".join(open(os.path.join(F, "pytest_gpu.log")).readlines()[-8:]))
     o.write("".join(l for l in open(os.path.join(F, "summary.txt")) if "smoke ok" in l))

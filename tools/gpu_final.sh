@@ -11,7 +11,7 @@
 #  6. the long-context table (tools/longctx.py: Mistral geometry at 4k fp16 / 32k e5m2, DBRX geometry at 4k)
 #  7. the real-architecture shape sweep with per-stage timings (tests/test_shape_sweep.py, CALM_SHAPE_SWEEP_OUT)
 #  SECTIONS="1 2 3" selects (default: all)
-TAG=${1:-r04}
+TAG=${1:-r05}
 SECTIONS=${SECTIONS:-"0 2 1 3 4 5 6 7"}
 want() { case " $SECTIONS " in *" $1 "*) return 0;; esac; return 1; }
 OUT=gpurun_out/final_$TAG
@@ -35,6 +35,13 @@ if want 1; then
 echo "== 1. bench" | tee -a $OUT/summary.txt
 ( time timeout 600 python bench.py ) > $OUT/bench.json 2> $OUT/bench.err; echo "exit $?" >> $OUT/summary.txt
 tail -c 3800 $OUT/bench.json >> $OUT/summary.txt; tail -4 $OUT/bench.err >> $OUT/summary.txt
+echo "== 1b. bench as the driver runs it (--steps 20): value for 20 steps + baseline_metric = the 256-step decode of the same run" | tee -a $OUT/summary.txt
+( time timeout 600 python bench.py --steps 20 --warmup 3 ) > $OUT/bench_steps20.json 2> $OUT/bench20.err; echo "exit $?" >> $OUT/summary.txt
+python - >> $OUT/summary.txt <<PY
+import json
+d = json.loads([l for l in open("$OUT/bench_steps20.json") if l.startswith("{")][-1])
+print("value", d["value"], "tok/s at", d["steps"], "steps | baseline_metric", d["baseline_metric"], "| rocprof", (d["roofline"] or {}).get("rocprof"), "| traffic", d["roofline"]["traffic"])
+PY
 fi
 if want 3; then
 echo "== 3. other shapes at full size, CPU leg and parity included" | tee -a $OUT/summary.txt
