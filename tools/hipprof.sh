@@ -8,6 +8,9 @@
 # Three runs of <command>: kernel trace (+ the byte account), FETCH_SIZE counters, nothing else; summaries land in
 # profiles/TAG_kernel_stats.md and profiles/TAG_pmc.json (the latter stamped with the kernel sources' hash, which is what lets
 # bench.py quote roofline.traffic from it).  The counter pass never shares a run with a trace domain other than the kernel trace.
+# rocprofv3 7.2 has crashed on this library's hipGraph replays (SIGSEGV under hipGraphLaunch / "AQL packet is malformed": round 4 in
+# decode_greedy_hip, round 5 in both passes over bench.py; not deterministic): trace with eager launches -- CALM_HIP_GRAPH=0 tools/hipprof.sh ...
+# (the same kernels, grids and arguments) -- and note it in the summary JSON ("_launch_mode"; prof_summary.py does when the variable is set).
 TAG=hipprof; WORKLOAD="mistral-7b fp8"; PMC=1
 while [ $# -gt 0 ]; do
   case "$1" in

@@ -110,6 +110,8 @@ def main():
 
     js = {k: {"calls": len(v), "avg_us": sum(v) / len(v), "median_us": statistics.median(v), "min_us": min(v)} for k, v in durs.items() if k}
     js["_csrc_sha"] = _sha()
+    if os.environ.get("CALM_HIP_GRAPH") == "0":  # (tools/hipprof.sh: traced with eager launches)
+        js["_launch_mode"] = "eager launches (CALM_HIP_GRAPH=0): the same kernels, grids and arguments as the graph replays"
     js["_workload"] = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "mistral-7b fp8"
     json.dump(js, open(os.path.join(root, "profiles", f"{tag}_kernel_stats.json"), "w"), indent=1)
     if fetch:
