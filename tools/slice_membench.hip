@@ -32,6 +32,48 @@ __global__ __launch_bounds__(256) void k_read(const u32x4* src, size_t n16, unsi
 	}
 }
 
+// The same bytes in k_ffn_up's ACCESS PATTERN, still without any arithmetic or activation vector: 512 workgroups x 4 waves; a wave's tasks
+// are hidden units j = wave, wave + 2048, ...; a task is row j of w1 and row j of w3 (ROW bytes each, the two matrices `half` bytes apart)
+// walked in steps of TILE_KB KiB per row; a tile = that step of both rows; DEPTH tiles in flight per wave (the engine: 2 rows x 2 KiB, 2
+// in flight).  Every load unconditional (clamped), like the engine's.
+template <int TILE_KB, int DEPTH>
+__global__ __launch_bounds__(256) void k_read_rows(const unsigned char* base, size_t half, int n_units, int row_bytes, unsigned* sink) {
+	constexpr int LPT = 2 * TILE_KB; // wave-loads per tile (two rows)
+	const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
+	const int steps = row_bytes / (TILE_KB * 1024);
+	const int my_units = (n_units - wave + nwaves - 1) / nwaves;
+	const int ntiles = my_units * steps;
+	auto load = [&](int t, u32x4(&v)[LPT]) {
+		const int tc = t < ntiles ? t : ntiles - 1; // (clamped, never branched on)
+		const int unit = wave + (tc / steps) * nwaves, st = tc % steps;
+		const unsigned char* r0 = base + (size_t)unit * row_bytes + (size_t)st * TILE_KB * 1024 + lane * 16;
+#pragma unroll
+		for (int k = 0; k < TILE_KB; ++k) {
+			v[2 * k] = __builtin_nontemporal_load((const u32x4*)(r0 + k * 1024));
+			v[2 * k + 1] = __builtin_nontemporal_load((const u32x4*)(r0 + half + k * 1024));
+		}
+	};
+	u32x4 ring[DEPTH][LPT];
+	unsigned acc = 0;
+#pragma unroll
+	for (int d = 0; d < DEPTH; ++d) {
+		load(d, ring[d]);
+	}
+	for (int t = 0; t < ntiles; t += DEPTH) {
+#pragma unroll
+		for (int d = 0; d < DEPTH; ++d) {
+#pragma unroll
+			for (int k = 0; k < LPT; ++k) {
+				acc += ring[d][k][0] ^ ring[d][k][1] ^ ring[d][k][2] ^ ring[d][k][3];
+			}
+			load(t + d + DEPTH, ring[d]);
+		}
+	}
+	if (acc == 0x9e3779b9u) {
+		*sink = acc;
+	}
+}
+
 int main() {
 	hipDeviceProp_t prop;
 	CK(hipGetDeviceProperties(&prop, 0));
@@ -70,5 +112,30 @@ int main() {
 			}
 		}
 	}
+	// k_ffn_up's access pattern on its own: Mistral-7B's 14336 hidden units x (4096 B of w1 + 4096 B of w3) = 117.44 MB per launch
+	printf("\n  k_ffn_up's 117.44 MB in the row engine's access pattern (wave = hidden unit: its w1 row and its w3 row; no arithmetic, no vector):\n");
+	const int n_units = 14336, row_bytes = 4096;
+	const size_t half = (size_t)n_units * row_bytes, lslice = 2 * half, nls = total / lslice;
+	auto pat = [&](const char* what, auto kern) {
+		for (int rep = 0; rep < 2; ++rep) {
+			CK(hipEventRecord(e0, st));
+			for (int i = 0; i < 200; ++i) {
+				hipLaunchKernelGGL(kern, dim3(ncu * 2), dim3(256), 0, st, (const unsigned char*)buf + (size_t)(i % nls) * lslice, half, n_units, row_bytes, sink);
+			}
+			CK(hipEventRecord(e1, st));
+			CK(hipEventSynchronize(e1));
+			float ms = 0;
+			CK(hipEventElapsedTime(&ms, e0, e1));
+			if (rep == 1) {
+				const double us = (double)ms * 1e3 / 200;
+				printf("  %s  %8.2f us / launch   %7.0f GB/s\n", what, us, 2.0 * half / us / 1e3);
+			}
+		}
+	};
+	pat("tiles of 2 rows x 1 KiB, 2 in flight", k_read_rows<1, 2>);
+	pat("tiles of 2 rows x 2 KiB, 2 in flight", k_read_rows<2, 2>); // the product's shape
+	pat("tiles of 2 rows x 4 KiB, 2 in flight", k_read_rows<4, 2>);
+	pat("tiles of 2 rows x 2 KiB, 4 in flight", k_read_rows<2, 4>);
+	pat("tiles of 2 rows x 1 KiB, 4 in flight", k_read_rows<1, 4>);
 	return 0;
 }
