@@ -89,7 +89,7 @@ def pipeline_leg(args, n_gpus):
         cmd += ["--layers", str(args.layers)]
     t0 = time.perf_counter()
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("CALM_BENCH_PIPELINE_TIMEOUT", "900")))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("CALM_BENCH_PIPELINE_TIMEOUT", "420")))
     except subprocess.TimeoutExpired:
         return {"error": "timeout", "command": " ".join(cmd[1:])}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
