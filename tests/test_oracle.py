@@ -158,3 +158,4 @@ def test_oracle_fp8_kv_mode_stays_close_to_the_fp16_cache_and_stores_e5m2():
     assert 0 < worst < 0.2  # 2-bit mantissas in K and V: percent-level drift
     assert (o8.kv(0, 0).view(np.uint16) & 0xFF).max() == 0 and (o16.kv(0, 0).view(np.uint16) & 0xFF).max() > 0
     o16.close(), o8.close()
+
