@@ -259,7 +259,9 @@ def test_fp8_cache_to_the_end_of_an_8192_context_and_past_it(hiplib, more_cpu_th
             prefill_caches_with_noise(hip, ref, 8, seed=6)
             worst, where, n = finish_context(hip, ref, seq_len, 40, 32, seed=6)
         print(f"fp8 cache, seq_len {seq_len}: worst max|d|/max|logit| = {worst:.3e} at position {where} over {n} compared positions")
-        assert worst < LOGIT_TOL, (worst, where)
+        # identical pre-filled caches: the step's own new row is one of thousands and the common bound holds; decoded from position 0
+        # (CALM_TEST_SLOW) the two e5m2 caches differ by their one-code flips and the 2-layer bound applies (conftest.FP8KV_TOL)
+        assert worst < (FP8KV_TOL if SLOW else LOGIT_TOL), (worst, where)
     finally:
         hip.close()
         ref.close()
