@@ -48,7 +48,10 @@ struct TokState {
 	int kv_sink; // 0, or CALM_KV_SINKS once pos >= seq_len   (src/infer.c:330)
 	int kv_pos;  // cache slot the new K/V row goes to          (src/infer.c:331)
 	int kv_len;  // number of valid cache rows                   (src/infer.c:332)
-	int pad[3];
+	// decode steps this model has begun: only ever incremented (k_begin_token), never reset -- the tag of the in-launch hand-off
+	// granules of k_qkv_attn, which must never match what an earlier step left in the buffer
+	unsigned epoch;
+	int pad[2];
 };
 
 // head size for which prepare_hip keeps the transposed value cache (behind the [position][dim] one, same size)
@@ -144,6 +147,55 @@ __device__ __forceinline__ float wave_max(float v) {
 		v = fmaxf(v, __shfl_xor(v, o));
 	}
 	return v;
+}
+
+// group_sum of N independent values, stage by stage: every DPP add of a stage reads a register written N - 1 instructions earlier
+// (one chain per value gets two wait states in front of each of its four steps)
+template <int LPR, int N>
+__device__ __forceinline__ void group_sum_multi(float (&v)[N]) {
+	auto dpp = [](float x, auto ctrl) {
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+	};
+	static_assert(LPR <= 16, "group_sum_multi: groups within one DPP row");
+	if constexpr (LPR >= 2) {
+#pragma unroll
+		for (int i = 0; i < N; ++i) {
+			v[i] += dpp(v[i], std::integral_constant<int, 0xb1>());
+		}
+	}
+	if constexpr (LPR >= 4) {
+#pragma unroll
+		for (int i = 0; i < N; ++i) {
+			v[i] += dpp(v[i], std::integral_constant<int, 0x4e>());
+		}
+	}
+	if constexpr (LPR >= 8) {
+#pragma unroll
+		for (int i = 0; i < N; ++i) {
+			v[i] += dpp(v[i], std::integral_constant<int, 0x141>());
+		}
+	}
+	if constexpr (LPR >= 16) {
+#pragma unroll
+		for (int i = 0; i < N; ++i) {
+			v[i] += dpp(v[i], std::integral_constant<int, 0x140>());
+		}
+	}
+}
+// maximum over the 64 lanes, in every lane (VALU + one v_readlane; wave_max above goes through the LDS crossbar six times)
+__device__ __forceinline__ float wave_max_dpp(float v) {
+	auto dpp = [](float x, auto ctrl, auto row_mask) { // lanes the control leaves without a source keep x
+		const int xi = __builtin_bit_cast(int, x);
+		return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(xi, xi, decltype(ctrl)::value, decltype(row_mask)::value, 0xf, false));
+	};
+	using F = std::integral_constant<int, 0xf>;
+	v = fmaxf(v, dpp(v, std::integral_constant<int, 0xb1>(), F()));
+	v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4e>(), F()));
+	v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>(), F()));
+	v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>(), F()));
+	v = fmaxf(v, dpp(v, std::integral_constant<int, 0x142>(), std::integral_constant<int, 0xa>())); // row_bcast:15 into rows 1, 3
+	v = fmaxf(v, dpp(v, std::integral_constant<int, 0x143>(), std::integral_constant<int, 0xc>())); // row_bcast:31 into rows 2, 3
+	return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), RED_LANE));
 }
 
 // ---------------------------------------------------------------- weight decode ---------------
@@ -403,7 +455,7 @@ template <int DB, int BLOCK, int V, bool NORM>
 // matvec, so the image does not wait for the block-wide sum of squares (two barriers and an LDS round trip on the path to the first
 // multiply-add); the sum rides on the image's own barrier instead.
 __device__ __forceinline__ float stage_finish(const StageRegs<V, NORM>& sr, float4* xs4, float* red, const float* __restrict__ src, const float* __restrict__ normw,
-                                              int n, float eps, bool ln, float* dump) {
+                                              int n, float eps, bool ln, float* dump, int dump_block = 0) {
 	constexpr int MAXV = V;
 	constexpr int NWAVES = BLOCK / 64;
 	const int tid = threadIdx.x;
@@ -479,7 +531,7 @@ __device__ __forceinline__ float stage_finish(const StageRegs<V, NORM>& sr, floa
 			t.z = (t.z - mean) * scale * gw.z;
 			t.w = (t.w - mean) * scale * gw.w;
 		}
-		if (dump && blockIdx.x == 0) {
+		if (dump && (int)blockIdx.x == dump_block) {
 			((float4*)dump)[p] = t;
 		}
 		if constexpr (DB == 4) {
@@ -939,6 +991,7 @@ __global__ void k_begin_token(TokState* ts, int token, const int* tok_src, int p
 		ts->kv_sink = kv_sink;
 		ts->kv_pos = kv_pos;
 		ts->kv_len = kv_len;
+		ts->epoch = ts->epoch + 1;
 	}
 	if (embed && i < dim) { // embed == nullptr: a later pipeline stage; x already holds the residual stream
 		x[i] = decode_elem<DB>(embed, (size_t)token * dim + i);
@@ -1022,9 +1075,32 @@ struct QkvArgs {
 // struct argument is copied to scratch memory, +4 us per launch when that was tried).
 // HALF: tiles half as deep -- for matrices so small that a wave's share is less than one full tile (TinyLlama's 10.5 MB at fp16: 6.3 ->
 // 5.45 us; the host decides, launch_qkv)
-template <int DB, int KVB, int V, bool FULL, bool HALF, bool XREG = false>
-__global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// In-launch hand-off words of k_qkv_attn (below): this token's q and its k / v rows AS CACHED, one 8-byte {value, tag} granule per
+// element, indexed like the rows of [wq; wk; wv].  One buffer serves every layer: the tag names (decode step, layer).
+struct FuseArgs {
+	unsigned long long* gran;
+	float* out;      // (q_dim) attention output
+	unsigned* err;   // raised when a wait ran into its bound (never, unless a producer died)
+	int n_heads, kv_mul;
+	unsigned layer;  // < 256
+	unsigned salt;   // added to the step count: 0 in a decode step; perf_stage_hip, which repeats one launch without a begin-token kernel, counts it up
+};
+__device__ __forceinline__ unsigned fuse_tag(const TokState* ts, const FuseArgs& f) {
+	return ((ts->epoch + f.salt) << 8) | f.layer;
+}
+// written by ONE relaxed agent-scope (write-through, sc1) 8-byte store: the data is its own flag -- no drain of the writing wave's
+// memory queue (its next weight tiles are in flight), no counter, no fence
+__device__ __forceinline__ void gran_store(unsigned long long* g, float v, unsigned tag) {
+	__hip_atomic_store(g, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void k_add_epoch(TokState* ts, unsigned n) {
+	ts->epoch += n;
+}
+
+template <int DB, int KVB, int V, bool FULL, bool HALF, bool XREG, bool FUSED>
+__device__ __forceinline__ void qkv_rows(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, const QkvArgs& a, const FuseArgs* f, int bid, int nblocks,
+                                         unsigned char* smem) {
 	constexpr int NR = KShape<DB, KS_QKV>::NR, U = (HALF && KShape<DB, KS_QKV>::U > 1) ? KShape<DB, KS_QKV>::U / 2 : KShape<DB, KS_QKV>::U;
 	float4* xs4 = (float4*)smem;
 	float* red = (float*)(xs4 + xs_slots<DB>(dim));
@@ -1051,8 +1127,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 	StageRegs<V, true> sr;
 	auto pre = [&]() { stage_load<WG_THREADS>(sr, x, norm_w); stage_first_barrier(); };
 	float nscale = 1.f; // what the norm leaves to the epilogue (stage_finish)
-	auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump); };
+	auto stage = [&]() { nscale = stage_finish<DB, WG_THREADS>(sr, xs4, red, x, norm_w, dim, a.eps, a.ln != 0, a.xb_dump, (int)blockIdx.x - bid); };
 	const int kv_pos = a.ts->kv_pos; // scalar load issued at kernel start, long before any epilogue
+	unsigned tag = 0;
+	if constexpr (FUSED) {
+		tag = fuse_tag(a.ts, *f);
+	}
 	// aux = (cos, sin) of each row pair's RoPE angle, fetched before the task's last multiply-add
 	auto aux_of = [&](int t, float(&aux)[NR]) {
 #pragma unroll
@@ -1085,7 +1165,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 				v1 = r1;
 			}
 			if (j < q_dim) {
-				*(float2*)(a.q + j) = make_float2(v0, v1);
+				if constexpr (FUSED) { // the attention workgroups of this launch are the only readers
+					gran_store(f->gran + j, v0, tag);
+					gran_store(f->gran + j + 1, v1, tag);
+				} else {
+					*(float2*)(a.q + j) = make_float2(v0, v1);
+				}
 			} else {
 				int jl = j - q_dim;
 				void* cache = a.kc;
@@ -1104,6 +1189,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 						((__half*)a.vt)[offt] = __low2half(h);
 						((__half*)a.vt)[offt + next_d] = __high2half(h);
 					}
+					if constexpr (FUSED) { // this step's attention reads the row as later steps will find it in the cache
+						gran_store(f->gran + j, __low2float(h), tag);
+						gran_store(f->gran + j + 1, __high2float(h), tag);
+					}
 				} else {
 					const unsigned short b2 = e5m2x2_sat(v0, v1);
 					*(unsigned short*)((unsigned char*)cache + off) = b2;
@@ -1111,11 +1200,21 @@ __global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float*
 						((unsigned char*)a.vt)[offt] = (unsigned char)(b2 & 0xff);
 						((unsigned char*)a.vt)[offt + next_d] = (unsigned char)(b2 >> 8);
 					}
+					if constexpr (FUSED) {
+						gran_store(f->gran + j, bf8_byte0(b2 & 0xffu), tag);
+						gran_store(f->gran + j + 1, bf8_byte0((unsigned)b2 >> 8), tag);
+					}
 				}
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, blockIdx.x * WG_WAVES + wave_id(), gridDim.x * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
+	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, bid * WG_WAVES + wave_id(), nblocks * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
+}
+
+template <int DB, int KVB, int V, bool FULL, bool HALF, bool XREG = false>
+__global__ __launch_bounds__(WG_THREADS) void k_qkv(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, QkvArgs a) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	qkv_rows<DB, KVB, V, FULL, HALF, XREG, false>(x, norm_w, dim, q_dim, kv_dim, a, nullptr, (int)blockIdx.x, (int)gridDim.x, smem);
 }
 
 // ---- attention --------------------------------------------------------------------------------
@@ -1341,6 +1440,293 @@ __global__ __launch_bounds__(NW * 64) void k_attn(const TokState* ts, const floa
 		}
 	}
 #endif
+}
+
+// ---- k_qkv_attn: short-context attention INSIDE k_qkv's launch ---------------------------------
+//
+// The reference runs the whole layer in one cooperative kernel (src/infer.cu:441-556); here a kernel boundary is cheaper than a grid
+// barrier, but the boundary between k_qkv and k_attn bought nothing except its cost: k_attn's K / V rows were
+// written by EARLIER tokens, and the one round trip to memory they cost (~1.9 us behind a boundary whose L2s come up empty,
+// profiles/r05_attn_floor.txt) could have been under way since k_qkv started.  So: the first n_heads workgroups of this launch take a
+// query head each, ask for every cached row of their kv head at once (registers: 16 wave-tiles of K and of V per wave), and only
+// then wait -- for the 128 q values of THEIR head, never for the grid: the row engine's epilogue publishes every q / k / v value as an
+// 8-byte {value, tag} granule by one write-through store (the data is its own flag: the producing wave drains nothing -- its next
+// weight tiles are in flight -- and counts nothing), the attention wave re-reads its head's granules past the caches until every tag
+// names this (decode step, layer).  q rows come first in the task order and this token's k / v rows last, so a head has folded the
+// old positions in long before the launch ends and the tail behind the last producer is ONE position: a dot product, an exp, 128
+// multiply-adds.  Producers never wait for anything, consumers only for producers: nothing can hang whatever the dispatch order
+// (the wait is bounded all the same).  Matches src/infer.c:238-267,397-406 like k_attn.
+constexpr int FUSE_UA = 64 / WG_WAVES; // wave-tiles of 64 / LPR cached rows a wave holds of K and of V (16 at 4 waves: 128 VGPRs at binary16)
+__host__ __device__ constexpr int fuse_max_kv(int lpr) {
+	return WG_WAVES * (64 / lpr) * FUSE_UA; // cached rows (the new one included) one workgroup covers: 256 at head size 128, 512 at 64
+}
+
+// 16 bytes past the L1 (agent scope), waited for in the same statement (the compiler does not count it)
+__device__ __forceinline__ u32x4 load16_agent(const void* p) {
+	u32x4 v;
+	asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+	return v;
+}
+constexpr unsigned long long FUSE_WAIT_TICKS = 5000000ull; // 50 ms of the 100 MHz wall clock
+
+template <int KVB>
+using KvRaw = std::conditional_t<KVB == 16, u32x4, u32x2>; // 8 cached elements
+template <int KVB>
+__device__ __forceinline__ float dot8_raw(const KvRaw<KVB>& k, const float (&q)[8]) {
+	float d = 0.f;
+	if constexpr (KVB == 16) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			d = fma_mix_lo(k[i], q[2 * i], d);
+			d = fma_mix_hi(k[i], q[2 * i + 1], d);
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const f32x2 lo = bf8x2_lo(k[i]), hi = bf8x2_hi(k[i]);
+			d = fmaf(q[4 * i], lo[0], d), d = fmaf(q[4 * i + 1], lo[1], d), d = fmaf(q[4 * i + 2], hi[0], d), d = fmaf(q[4 * i + 3], hi[1], d);
+		}
+	}
+	return d;
+}
+// exp2 for a value that asm statements go on to read.  gfx940+ wants one wait state between a transcendental instruction and a
+// dependent ordinary VALU instruction; hipcc's hazard pass inserts it between ITS instructions and does not look inside an asm string
+// (round 6: NaNs whenever the scheduler put an asm v_fma_mix_f32 right behind the v_exp_f32 that made its factor).  The copy below is
+// the one reader of the exponential's register and carries the wait state itself.
+__device__ __forceinline__ float exp2_for_asm(float x) {
+	const float e = __builtin_amdgcn_exp2f(x);
+	float r;
+	asm("s_nop 0\n\tv_mov_b32 %0, %1" : "=v"(r) : "v"(e));
+	return r;
+}
+template <int KVB>
+__device__ __forceinline__ void axpy8_raw(float p, const KvRaw<KVB>& v, float (&o)[8]) {
+	if constexpr (KVB == 16) {
+#pragma unroll
+		for (int i = 0; i < 4; ++i) {
+			o[2 * i] = fma_mix_lo(v[i], p, o[2 * i]);
+			o[2 * i + 1] = fma_mix_hi(v[i], p, o[2 * i + 1]);
+		}
+	} else {
+#pragma unroll
+		for (int i = 0; i < 2; ++i) {
+			const f32x2 lo = bf8x2_lo(v[i]), hi = bf8x2_hi(v[i]);
+			o[4 * i] = fmaf(p, lo[0], o[4 * i]), o[4 * i + 1] = fmaf(p, lo[1], o[4 * i + 1]), o[4 * i + 2] = fmaf(p, hi[0], o[4 * i + 2]), o[4 * i + 3] = fmaf(p, hi[1], o[4 * i + 3]);
+		}
+	}
+}
+
+// LDS the attention role needs (it shares the launch's dynamic allocation with the row engine's image)
+__host__ __device__ constexpr size_t fuse_lds_bytes(int lpr) {
+	return (size_t)(WG_WAVES + WG_WAVES * (64 / lpr) + WG_WAVES * 64 * 8 + WG_WAVES * lpr * 8) * sizeof(float);
+}
+
+template <int KVB, int LPR>
+__device__ __forceinline__ void attn_fused_role(const QkvArgs& a, const FuseArgs& f, int q_dim, int kv_dim, unsigned char* smem) {
+	constexpr int RPW = 64 / LPR, NW = WG_WAVES, UA = FUSE_UA;
+	constexpr int EB = KVB / 8;
+	using Raw = KvRaw<KVB>;
+	float* sm_m = (float*)smem;         // [NW]            every wave's maximum (base-2 scores)
+	float* sm_l = sm_m + NW;            // [NW][RPW]       ... and each of its lane groups' sum of weights
+	float* sm_o = sm_l + NW * RPW;      // [NW][RPW][LPR * 8]  ... and weighted value sum
+	float* sm_q = sm_o + NW * 64 * 8;   // [NW][LPR * 8]: every wave's copy of q
+
+	const int lane = lane_id(), wave = wave_id();
+	const int head_dim = a.head_dim;
+	// workgroup b sits on XCD b % 8: the query heads of one kv head on the same one where the head counts allow (their rows then come
+	// from memory once per XCD); any placement is correct
+	const int n_kv = f.n_heads / f.kv_mul;
+	const int b = blockIdx.x;
+	const int kvh = b % n_kv, h = kvh * f.kv_mul + b / n_kv;
+	const int r = lane % LPR, g = lane / LPR;
+	const bool dvalid = r * 8 < head_dim;
+	const int d0 = dvalid ? r * 8 : 0;
+	const unsigned char* kbase = (const unsigned char*)a.kc + ((size_t)kvh * a.seq_len * head_dim + d0) * EB;
+	const unsigned char* vbase = (const unsigned char*)a.vc + ((size_t)kvh * a.seq_len * head_dim + d0) * EB;
+	const size_t rstride = (size_t)head_dim * EB;
+
+	const int kv_len = a.ts->kv_len, kv_pos = a.ts->kv_pos;
+	const unsigned tag = fuse_tag(a.ts, f);
+#ifdef CALM_TIMELINE
+	unsigned long long tl[8];
+	tl[0] = wall_clock64();
+#endif
+	// every cached row of the kv head, at once; rows past the live range are clamped into it and masked below, and so is the slot
+	// this token's row is being written to (read from its granules instead)
+	Raw kw[UA], vw[UA];
+#pragma unroll
+	for (int u = 0; u < UA; ++u) {
+		const int t = min((u * NW + wave) * RPW + g, kv_len - 1);
+		kw[u] = *(const Raw*)(kbase + (size_t)t * rstride);
+		vw[u] = *(const Raw*)(vbase + (size_t)t * rstride);
+	}
+
+	const unsigned long long t_start = wall_clock64();
+	bool bad = false;
+	auto expired = [&]() {
+		if (wall_clock64() - t_start > FUSE_WAIT_TICKS) {
+			bad = true;
+			if (lane == 0) {
+				atomicOr(f.err, 1u);
+			}
+			return true;
+		}
+		return false;
+	};
+	const int npairs = head_dim >> 1; // <= 64
+	const int pi = lane < npairs ? lane : npairs - 1;
+	const unsigned long long* gq = f.gran + (size_t)h * head_dim + 2 * pi;
+	const unsigned long long* gk = f.gran + (size_t)q_dim + (size_t)kvh * head_dim + 2 * pi;
+	const int d = min((int)threadIdx.x, head_dim - 1); // the output dim of this thread in the last step
+	unsigned long long* gv = f.gran + (size_t)q_dim + kv_dim + (size_t)kvh * head_dim + d;
+	// scores are kept in base 2, scaled once through q: exp(s / sqrt(head_dim) - max) = exp2(s' - max'), s' = (q log2(e) / sqrt(head_dim)) . k
+	// (src/infer.c:247-257; two operations per lane instead of a division and a multiplication per cached row)
+	const float qscale = 1.44269504088896341f / sqrtf((float)head_dim);
+	float* qs = sm_q + wave * (LPR * 8);
+
+	// q: one 16-byte load per lane = the pair (2 lane, 2 lane + 1) of the head, re-read until both tags match
+	u32x4 qg;
+	for (;;) {
+		qg = load16_agent(gq);
+		if (__all(qg[1] == tag && qg[3] == tag) || expired()) {
+			break;
+		}
+		__builtin_amdgcn_s_sleep(2);
+	}
+#ifdef CALM_TIMELINE
+	tl[1] = wall_clock64(); // q is here (and, before it, the cached rows: the queue returns in order)
+#endif
+	const float qa = __uint_as_float(qg[0]) * qscale, qb = __uint_as_float(qg[2]) * qscale;
+	if (lane < npairs) {
+		*(float2*)(qs + 2 * lane) = make_float2(qa, qb);
+	}
+	__builtin_amdgcn_wave_barrier(); // same wave, LDS returns in order: no workgroup barrier
+	float qv[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		const float qi = qs[d0 + i];
+		qv[i] = dvalid ? qi : 0.f;
+	}
+
+	// ~420 vector instructions per wave from here to the barrier (they ARE this launch's critical path once q is late: 4 waves x 16
+	// tiles on one CU; profiles/r06_qkv_attn.txt): every tile's dot product first, their lane-group sums stage by stage, ONE maximum
+	// for the whole wave (so that the lane groups' partial sums simply add), no masking of the value rows (a masked row's weight is 0
+	// and the cache holds numbers: zero-filled at prepare_hip, finite rows since)
+	float s[UA];
+#pragma unroll
+	for (int u = 0; u < UA; ++u) {
+		s[u] = dot8_raw<KVB>(kw[u], qv);
+	}
+	group_sum_multi<LPR>(s);
+	float m = -INFINITY;
+#pragma unroll
+	for (int u = 0; u < UA; ++u) {
+		const int t = (u * NW + wave) * RPW + g;
+		s[u] = (t < kv_len && t != kv_pos) ? s[u] : -INFINITY;
+		m = fmaxf(m, s[u]);
+	}
+	m = wave_max_dpp(m); // wave-uniform
+	float l = 0.f, o[8];
+#pragma unroll
+	for (int i = 0; i < 8; ++i) {
+		o[i] = 0.f;
+	}
+	if (m != -INFINITY) {
+#pragma unroll
+		for (int u = 0; u < UA; ++u) {
+			const float p = exp2_for_asm(s[u] - m); // exp2(-inf) = 0: the masked rows
+			l += p;
+			axpy8_raw<KVB>(p, vw[u], o);
+		}
+	}
+	if (lane == 0) {
+		sm_m[wave] = m;
+	}
+	if (r == 0) {
+		sm_l[wave * RPW + g] = l;
+	}
+	{
+		float4* so = (float4*)(sm_o + (wave * RPW + g) * (LPR * 8) + r * 8); // (lanes past head_dim hold zeros)
+		so[0] = make_float4(o[0], o[1], o[2], o[3]);
+		so[1] = make_float4(o[4], o[5], o[6], o[7]);
+	}
+#ifdef CALM_TIMELINE
+	asm volatile("" ::"v"(o[0]), "v"(l));
+	tl[5] = wall_clock64(); // this wave's old positions are folded in
+#endif
+	__syncthreads();
+#ifdef CALM_TIMELINE
+	tl[2] = wall_clock64(); // ... every wave's
+	tl[3] = tl[4] = tl[2];
+#endif
+	if (wave * 64 < head_dim) { // one thread per output dim from here on
+		float M = sm_m[0];
+#pragma unroll
+		for (int w = 1; w < NW; ++w) {
+			M = fmaxf(M, sm_m[w]);
+		}
+		float L = 0.f, O = 0.f;
+#pragma unroll
+		for (int w = 0; w < NW; ++w) {
+			const float e = (sm_m[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(sm_m[w] - M); // a wave without positions
+			float lw = 0.f, ow = 0.f;
+#pragma unroll
+			for (int gg = 0; gg < RPW; ++gg) {
+				lw += sm_l[w * RPW + gg];
+				ow += sm_o[(w * RPW + gg) * (LPR * 8) + d];
+			}
+			L = fmaf(lw, e, L);
+			O = fmaf(ow, e, O);
+		}
+		// this token's own row: k as pairs against the q pair of the poll above (a wave-wide dot product), v one granule per thread
+		u32x4 kg;
+		unsigned long long vg;
+		for (;;) {
+			vg = __hip_atomic_load(gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			kg = load16_agent(gk);
+			if (__all(kg[1] == tag && kg[3] == tag && (unsigned)(vg >> 32) == tag) || expired()) {
+				break;
+			}
+			__builtin_amdgcn_s_sleep(1);
+		}
+#ifdef CALM_TIMELINE
+		tl[3] = wall_clock64(); // this token's k / v rows are here
+#endif
+		const float s_new = wave_sum(lane < npairs ? fmaf(qa, __uint_as_float(kg[0]), qb * __uint_as_float(kg[2])) : 0.f);
+		const float v_new = __uint_as_float((unsigned)vg);
+		const float M2 = fmaxf(M, s_new);
+		const float e1 = (M == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(M - M2), pn = __builtin_amdgcn_exp2f(s_new - M2);
+		float res = fmaf(pn, v_new, O * e1) / fmaf(L, e1, pn);
+		if (bad) {
+			res = __builtin_nanf("");
+		}
+		if ((int)threadIdx.x < head_dim) {
+			f.out[h * head_dim + threadIdx.x] = res;
+		}
+#ifdef CALM_TIMELINE
+		tl[4] = wall_clock64();
+#endif
+	}
+#ifdef CALM_TIMELINE
+	{
+		const unsigned wv = blockIdx.x * NW + wave;
+		if (lane == 0 && calm_tl_buf && wv < calm_tl_waves) {
+			unsigned long long* ob = calm_tl_buf + (size_t)wv * 8;
+			ob[0] = tl[0], ob[1] = tl[1], ob[2] = tl[2], ob[3] = tl[4], ob[4] = tl[3], ob[5] = tl[5];
+		}
+	}
+#endif
+}
+
+// n_attn (= n_heads) rides in front as a preloaded scalar: a wave knows its role before it has fetched anything
+template <int DB, int KVB, bool HALF, int LPR>
+__global__ __launch_bounds__(WG_THREADS) void k_qkv_attn(const float* x, const float* norm_w, int dim, int q_dim, int kv_dim, int n_attn, QkvArgs a, FuseArgs f) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	if ((int)blockIdx.x < n_attn) {
+		attn_fused_role<KVB, LPR>(a, f, q_dim, kv_dim, smem);
+		return;
+	}
+	qkv_rows<DB, KVB, 4, true, HALF, false, true>(x, norm_w, dim, q_dim, kv_dim, a, &f, (int)blockIdx.x - n_attn, (int)gridDim.x - n_attn, smem);
 }
 
 // Long-context attention: one workgroup (4 waves) per (kv head, group of QH query heads, kv split).

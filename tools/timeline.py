@@ -39,6 +39,9 @@ spec = cf.SPECS.get(name) or cf.ARCH_SPECS[name]
 model = HostModel(cf.stub_tensors(spec, dtype, L), cf.dataclasses.replace(spec, n_layers=L).metadata(dtype))
 b = HipBackend(model, device_synth=(spec, dtype, 1, L))
 lib = b.lib._product
+for kv in os.environ.get("TL_KNOBS", "").split():  # e.g. TL_KNOBS="qkv_attn=0 fuse_dbg=1"
+    k, v = kv.split("=")
+    lib.calm_hip_configure(k.encode(), int(v))
 lib.calm_tl_arm.argtypes = [C.c_int]
 lib.calm_tl_read.argtypes = [C.c_void_p, C.c_int]
 for pos in range(int(os.environ.get("TL_POS", "64"))):  # the cache length the attention stage then meets
@@ -69,6 +72,21 @@ for i, st in enumerate(STAGES):
     buf = np.zeros((waves, 8), dtype=np.uint64)
     lib.calm_tl_read(buf.ctypes.data, waves)
     t = buf.astype(np.int64) * 10
+    if st == "qkv" and lib.calm_hip_configure(b"qkv_attn", -1) == 1:
+        # k_qkv_attn: the first n_heads workgroups are the attention role -- entry / q here / old positions folded in, past the barrier /
+        # this token's k, v rows here / exit; the row engine's stamps follow below
+        na = spec.n_heads * 4
+        at = t[:na][t[:na, 3] > 0]
+        t0 = t[t[:, 3] > 0][:, 0].min()
+        if len(at):
+            c = lambda k: (at[:, k] - t0) / 1e3
+            f = lambda k: f"{float(np.median(c(k))):5.2f} / {c(k).max():5.2f}"
+            print(f"{'qkv:attn':9s} {'':9s} {len(at):6d} | entry {f(0)} | q here {f(1)} | own rows folded in {f(5)} | past the barrier {f(2)} | k, v here {f(4)} | exit {f(3)}   (p50 / max)")
+            if os.environ.get("TL_HEADS"):
+                for h in range(0, spec.n_heads):
+                    w = (t[4 * h:4 * h + 4] - t0) / 1e3
+                    print(f"   wg {h:2d}: q here " + " ".join(f"{x:5.2f}" for x in w[:, 1]) + " | folded " + " ".join(f"{x:5.2f}" for x in w[:, 5]) + f" | barrier {w[0, 2]:5.2f} | kv {w[0, 4]:5.2f} | exit {w[0, 3]:5.2f}")
+        t[:na] = 0
     a = t[t[:, 3] > 0]
     t0 = a[:, 0].min()
     ex = (a[:, 3] - t0) / 1e3
