@@ -100,7 +100,6 @@ int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every
 int g_skew = 14;       // k_ffn_up: percent more tasks for the first-dispatched workgroup of each CU than an even split gives it (0: even) (k_ffn_up, k_output at two workgroups per CU; kernels.hip.h task_range)
 int g_qkv_wgs = 0;     // workgroups per CU of k_qkv's grid where the tasks exceed it (0: the rule in launch_qkv; A/B switch)
 int g_qkv_attn = 1;    // short-context attention inside k_qkv's launch (kernels.hip.h k_qkv_attn) where the shape allows (fused_ok); 0: k_qkv, then k_attn
-int g_fuse_dbg = 0;    // EXPERIMENT (k_qkv_attn): 1 = one workgroup per CU (LDS padded past half a CU's) and the row engine on ncu - n_heads of them
 int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
 int g_pf_score_mb = 256; // MiB of logits scratch the scoring GEMM may use (prefill_logprobs_hip scores a chunk in blocks of that many rows; read when the scratch is allocated)
 int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
@@ -443,15 +442,23 @@ void launch_qkv(Ctx* c, int l) {
 	});
 }
 
-// Short-context attention rides in k_qkv's launch (kernels.hip.h k_qkv_attn) when: the knob is on; the step's attention is unsplit and
-// its cached rows fit one workgroup's registers (256 at head size 128, 512 at 64); heads of 64 or 128 (8 / 16 lanes per row; LPR 4 is not
-// instantiated, larger heads would need two loads per granule poll); the input vector takes the 4-registers-per-thread staging and
-// whole-KiB rows (every BASELINE shape; the other forms stay with the two launches rather than doubling the instantiations).
+// Short-context attention rides in k_qkv's launch (kernels.hip.h k_qkv_attn) when: the knob is on (1: by this rule; 2: also for gf4
+// weights); the step's attention is unsplit and its cached rows fit one workgroup's registers (256 at head size 128, 512 at 64); heads
+// of 64 or 128 (8 / 16 lanes per row; LPR 4 is not instantiated, larger heads would need two loads per granule poll); the input vector
+// takes the 4-registers-per-thread staging and whole-KiB rows (every BASELINE shape; the other forms stay with the two launches rather
+// than doubling the instantiations); the heads leave at least half of the CUs to the row engine (FUSE_LDS: one workgroup per CU).
+// gf4 weights stay with the two launches by default: their k_qkv wants eight waves per CU (launch_qkv), the fused launch's row engine
+// has four on ncu - n_heads CUs, and the two cancel (Llama-3-8B gf4, 8 layers: 2408-2439 tok/s against 2428-2432; profiles/r06_qkv_attn.txt).
 template <int DB>
 bool fused_ok(const Ctx* c, int kv_len, int n_split) {
-	return g_qkv_attn && c->gran && n_split == 1 && (c->lpr == 8 || c->lpr == 16) && kv_len <= fuse_max_kv(c->lpr) && stage_v4(c->dim, WG_THREADS) && rows_full<DB>(c->dim) &&
-	       c->n_layers <= 256 && c->head_dim <= 4 * 64;
+	return (DB == 4 ? g_qkv_attn == 2 : g_qkv_attn != 0) && c->gran && n_split == 1 && (c->lpr == 8 || c->lpr == 16) && kv_len <= fuse_max_kv(c->lpr) && stage_v4(c->dim, WG_THREADS) &&
+	       rows_full<DB>(c->dim) && c->n_layers <= 256 && c->head_dim <= 4 * 64 && 2 * c->n_heads <= g_ncu;
 }
+// Every workgroup of the fused launch asks for more than half a CU's LDS, so a CU holds ONE: the attention workgroups get CUs of their
+// own.  Beside a row-engine workgroup they put their 128 wave-loads of K / V rows into the CU's queue ahead of its weight tiles, that
+// CU's rows came in 2 us after everybody else's, and every head waits for some of them (Mistral-7B fp8, 32 layers: 623-625 tok/s with
+// shared CUs, 634-635 with this; 606-608 for the two launches).
+constexpr size_t FUSE_LDS = 82 * 1024;
 
 template <int DB, int KVB>
 void launch_qkv_attn(Ctx* c, int l) {
@@ -476,22 +483,14 @@ void launch_qkv_attn(Ctx* c, int l) {
 	f.n_heads = c->n_heads, f.kv_mul = c->kv_mul;
 	f.layer = (unsigned)l, f.salt = c->fuse_salt;
 	const int ntasks = (c->q_dim + 2 * c->kv_dim) / KShape<DB, KS_QKV>::NR;
-	int rows_grid = pick_blocks_wg(ntasks, KShape<DB, KS_QKV>::BPC);
-	{
-		const int wgs = g_qkv_wgs > 0 ? g_qkv_wgs : (DB == 4 ? 2 : 0); // (launch_qkv)
-		if (wgs > 0 && (ntasks + WG_WAVES - 1) / WG_WAVES > g_ncu * wgs) {
-			rows_grid = g_ncu * wgs;
-		}
-	}
-	if (g_fuse_dbg & 1) {
-		rows_grid = g_ncu - c->n_heads;
+	int rows_grid = g_ncu - c->n_heads; // one workgroup per CU (FUSE_LDS), the row engine on every CU the heads leave
+	if ((ntasks + WG_WAVES - 1) / WG_WAVES < rows_grid) {
+		rows_grid = (ntasks + WG_WAVES - 1) / WG_WAVES;
 	}
 	const dim3 grid(c->n_heads + rows_grid), block(WG_THREADS);
-	size_t lds = lds_bytes<DB>(c->dim);
-	lds = lds > fuse_lds_bytes(c->lpr) ? lds : fuse_lds_bytes(c->lpr);
-	if (g_fuse_dbg & 1) {
-		lds = 82 * 1024;
-	}
+	const size_t lds = FUSE_LDS;
+	static_assert(FUSE_LDS >= fuse_lds_bytes(8) && FUSE_LDS >= fuse_lds_bytes(16), "FUSE_LDS: the attention role's scratch");
+	CALM_REQUIRE(lds_bytes<DB>(c->dim) <= FUSE_LDS, "k_qkv_attn: the activation image of a 4096-column vector fits FUSE_LDS");
 	constexpr int U = KShape<DB, KS_QKV>::U;
 	const size_t per_wave = (size_t)(c->q_dim + 2 * c->kv_dim) * c->dim * DB / 8 / ((size_t)g_ncu * 2 * WG_WAVES);
 	const int chunks = (c->dim / (128 / DB) + 63) / 64;
@@ -1559,7 +1558,7 @@ void set_lds_attrs(Ctx* c) {
 			seg_all(std::integral_constant<int, 9>()), seg_all(std::integral_constant<int, 10>()), seg_all(std::integral_constant<int, 12>());
 		}
 		{
-			const size_t fd = 82 * 1024; // (fuse_dbg)
+			const size_t fd = FUSE_LDS;
 			allow_lds(k_qkv_attn<DB, 16, false, 16>, fd), allow_lds(k_qkv_attn<DB, 16, true, 16>, fd), allow_lds(k_qkv_attn<DB, 16, false, 8>, fd), allow_lds(k_qkv_attn<DB, 16, true, 8>, fd);
 			allow_lds(k_qkv_attn<DB, 8, false, 16>, fd), allow_lds(k_qkv_attn<DB, 8, true, 16>, fd), allow_lds(k_qkv_attn<DB, 8, false, 8>, fd), allow_lds(k_qkv_attn<DB, 8, true, 8>, fd);
 		}
@@ -1624,8 +1623,7 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_moe_route;
 	} else if (!strcmp(key, "qkv_attn")) {
 		slot = &g_qkv_attn;
-	} else if (!strcmp(key, "fuse_dbg")) {
-		slot = &g_fuse_dbg;
+
 	} else if (!strcmp(key, "fuse_timeouts")) { // bounded waits of k_qkv_attn that expired, over every prepared model (0 unless a launch lost a producer)
 		unsigned total = 0;
 		for (auto& kv : g_ctx) {

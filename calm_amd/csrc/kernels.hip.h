@@ -1208,7 +1208,11 @@ __device__ __forceinline__ void qkv_rows(const float* x, const float* norm_w, in
 			}
 		}
 	};
-	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, bid * WG_WAVES + wave_id(), nblocks * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
+	// k_qkv deals tasks wave by wave (wave w of block b starts at task 4 b + w); the fused launch, whose ncu - n_heads workgroups leave the
+	// last round of tasks partly empty (3072 tasks over 896 waves: 3.4 each), deals them block by block -- task t to block t % nblocks --
+	// so that every CU gets the same 13 or 14 of them instead of 16 on some and 12 on others
+	const int first = FUSED ? wave_id() * nblocks + bid : bid * WG_WAVES + wave_id();
+	run_rows<DB, NR, U, FULL, xreg_chunks<DB, XREG>()>(ntasks, first, nblocks * WG_WAVES, dim, xs4, x, rows_of, pre, stage, aux_of, epi);
 }
 
 template <int DB, int KVB, int V, bool FULL, bool HALF, bool XREG = false>
@@ -1679,6 +1683,9 @@ __device__ __forceinline__ void attn_fused_role(const QkvArgs& a, const FuseArgs
 			O = fmaf(ow, e, O);
 		}
 		// this token's own row: k as pairs against the q pair of the poll above (a wave-wide dot product), v one granule per thread
+		// (Round 6 also tried leaving the value row to k_attn_out -- out = part without v_new + weight * v_new, the second term added
+		// from the cache while that kernel stages the vector -- so that no head waits for the v rows, the row engine's last tasks:
+		// k_qkv_attn - 0.1 us, k_attn_out + 0.4 us, the token slower; profiles/r06_qkv_attn.txt.)
 		u32x4 kg;
 		unsigned long long vg;
 		for (;;) {
