@@ -89,7 +89,7 @@ def pipeline_leg(args, n_gpus):
         cmd += ["--layers", str(args.layers)]
     t0 = time.perf_counter()
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("CALM_BENCH_PIPELINE_TIMEOUT", "420")))
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=float(os.environ.get("CALM_BENCH_PIPELINE_TIMEOUT", "900")))
     except subprocess.TimeoutExpired:
         return {"error": "timeout", "command": " ".join(cmd[1:])}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -103,6 +103,61 @@ def pipeline_leg(args, n_gpus):
     rec["command"] = "bench.py " + " ".join(cmd[2:])
     rec["wall_seconds"] = round(time.perf_counter() - t0, 1)
     return rec
+
+
+# BASELINE.json's other GPU configurations (3, 4, 5; config 1 = TinyLlama is the reference's CPU plumbing case, measured here on the GPU
+# as well): what the default N = 1 run measures after the headline workload, each in a child process of its own
+OTHER_CONFIGS = [("llama-3-8b", "gf4", 0), ("tinyllama-1.1b", "fp16", 0), ("mixtral-8x7b", "fp8", 0), ("dbrx-132b", "fp8", 0), ("dbrx-132b", "fp8", 4)]
+
+
+def other_configs_leg(args):
+    """The reference publishes a table, not one number (README.md:88-107).  After the headline workload has released the GPU, every other
+    BASELINE configuration runs as `bench.py --gpus 1 --model M --dtype D --steps 64 --no-cpu --no-extras` in a child process (weights
+    synthesised on the device: 1-4 s per model), DBRX-132B also as 4 in-library pipeline stages on this one GPU; -> one record per
+    workload.  The whole leg is bounded (CALM_BENCH_OTHER_BUDGET seconds, default 150): what did not fit is listed as dropped."""
+    import subprocess
+
+    budget = float(os.environ.get("CALM_BENCH_OTHER_BUDGET", "150"))
+    t_leg = time.perf_counter()
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "CALM_HIP_DEVICES", "OMP_NUM_THREADS")
+           and not k.startswith("TORCHELASTIC")}
+    out = []
+    for model, dtype, stages in OTHER_CONFIGS:
+        name = f"{model} {dtype}" + (f", {stages} in-library pipeline stages on one GPU" if stages else "")
+        left = budget - (time.perf_counter() - t_leg)
+        if left < 20:
+            out.append({"workload": name, "dropped": f"the leg's {budget:.0f} s budget was spent"})
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--model", model, "--dtype", dtype, "--steps", "64", "--warmup", "8", "--no-cpu", "--no-extras",
+               "--no-other-configs"]
+        if stages:
+            cmd += ["--pipeline", str(stages)]
+        if args.layers:
+            cmd += ["--layers", str(args.layers)]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=left)
+        except subprocess.TimeoutExpired:
+            out.append({"workload": name, "dropped": f"timeout after {left:.0f} s (what was left of the leg's budget)"})
+            continue
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            out.append({"workload": name, "error": f"exit {r.returncode}", "stderr_tail": r.stderr[-400:]})
+            continue
+        d = json.loads(lines[-1])
+        rec = {"workload": name, "tok_s": d["value"], "steps": d["steps"], "ms_per_step": d["ms_per_step"], "achieved_GBps": d["achieved_GBps"],
+               "hbm_frac_of_spec": d["hbm_frac_of_spec"], "bytes_per_step": d["bytes_per_step"],
+               "dominant_kernel": {"kernel": d["roofline"]["kernel"], "us_per_launch": d["roofline"]["us_per_launch"], "achieved_GBps": d["roofline"]["achieved"],
+                                   "frac": d["roofline"]["frac"]},
+               "load_seconds": d["load_seconds"], "wall_seconds": round(time.perf_counter() - t0, 1)}
+        if d.get("baseline_metric"):
+            rec["tok_s_256"] = d["baseline_metric"]["tok_s"]
+            rec["hbm_frac_of_spec_256"] = d["baseline_metric"]["hbm_frac_of_spec"]
+        if stages:
+            rec["stage_devices"], rec["handoff_us"] = d.get("stage_devices"), d.get("handoff_us")
+        out.append(rec)
+    return out
 
 
 def steps_note(steps, with_256=False):
@@ -132,9 +187,15 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: the launch / rendezvous / timing protocol only (gloo), for the CPU tests")
     ap.add_argument("--host-synth", action="store_true", help="without a CPU leg: synthesise the weights on the host and upload them (default: on the device)")
     ap.add_argument("--no-pipeline-leg", action="store_true", help="--gpus N > 1 without --pipeline: do not run BASELINE config 5 (the N-stage layer pipeline) afterwards")
+    ap.add_argument("--no-other-configs", action="store_true", help="the default N = 1 run: do not measure the other BASELINE configurations afterwards (other_configs_leg)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the legs beside the timed region: device-side greedy decode, prompt ingestion")
     args = ap.parse_args()
     if args.pipeline == -1:
         args.pipeline = args.gpus
+    # the other BASELINE configurations ride behind the HEADLINE run only: no --model / --layers / --pipeline given, one GPU
+    want_others = not args.no_other_configs and args.model is None and not args.layers and args.pipeline <= 1 and args.gpus == 1 and not args.dry_run
+    if args.no_extras:
+        args.no_device_greedy = True
     if args.model is None:
         args.model = "dbrx-132b" if args.pipeline > 1 else "mistral-7b"
 
@@ -450,6 +511,8 @@ def main():
     if world > 1 and args.pipeline <= 1 and not args.no_pipeline_leg:
         # BASELINE config 5, which the replica run above is not: DBRX-132B fp8 over N in-library stages
         out["pipeline"] = pipeline_leg(args, world)
+    if want_others and world == 1:
+        out["other_configs"] = other_configs_leg(args)
     print(json.dumps(out), flush=True)
 
 

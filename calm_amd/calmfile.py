@@ -438,6 +438,24 @@ def spec_accounting(spec: ModelSpec, dtype: str) -> Dict[str, int]:
 _ICDF: Optional[np.ndarray] = None
 
 
+_ICDF_T4 = None
+
+
+def _icdf_table(tail: str = "normal") -> np.ndarray:
+    """unit-variance quantiles at the 2^16 mid-points of (0, 1): "normal", or "t4" = Student-t with 4 degrees of freedom (variance 2)
+    divided by sqrt(2) -- the heavy-tailed weights of synth_model_big(outliers=True): 1 in 10^4 entries beyond 5 sigma (normal: 1 in 10^6)"""
+    global _ICDF_T4
+    if tail == "normal":
+        return _normal_icdf_table()
+    assert tail == "t4", tail
+    if _ICDF_T4 is None:
+        from scipy.stats import t as student
+
+        u = (np.arange(1 << 16) + 0.5) / (1 << 16)
+        _ICDF_T4 = student.ppf(u, 4) / math.sqrt(2.0)
+    return _ICDF_T4
+
+
 def _normal_icdf_table(bits: int = 16) -> np.ndarray:
     """standard-normal quantiles at the 2^bits mid-points of (0, 1): u -> z, as float64"""
     global _ICDF
@@ -452,14 +470,14 @@ def _normal_icdf_table(bits: int = 16) -> np.ndarray:
     return _ICDF
 
 
-_LUT_CACHE: Dict[Tuple[str, float], np.ndarray] = {}
+_LUT_CACHE: Dict[Tuple, np.ndarray] = {}
 
 
-def _code_lut(dtype: str, sigma: float) -> np.ndarray:
-    """65536-entry table: uniform u16 -> storage code of a N(0, sigma^2) sample (fp16 bits or e5m2 byte)"""
-    key = (dtype, float(sigma))
+def _code_lut(dtype: str, sigma: float, tail: str = "normal") -> np.ndarray:
+    """65536-entry table: uniform u16 -> storage code of a N(0, sigma^2) sample (fp16 bits or e5m2 byte); tail: _icdf_table"""
+    key = (dtype, float(sigma), tail)
     if key not in _LUT_CACHE:
-        z = (_normal_icdf_table() * sigma).astype(np.float32).astype(np.float16)
+        z = (_icdf_table(tail) * sigma).astype(np.float32).astype(np.float16)
         if dtype == "fp16":
             _LUT_CACHE[key] = z.view(np.uint16).copy()
         else:
@@ -467,12 +485,12 @@ def _code_lut(dtype: str, sigma: float) -> np.ndarray:
     return _LUT_CACHE[key]
 
 
-def _gf4_scale_lut(sigma: float) -> np.ndarray:
-    """u16 -> e5m2 code of the signed max-magnitude element of 8 N(0, sigma^2) samples"""
-    key = ("gf4scale", float(sigma))
+def _gf4_scale_lut(sigma: float, tail: str = "normal") -> np.ndarray:
+    """u16 -> e5m2 code of the signed max-magnitude element of 8 N(0, sigma^2) samples (tail: _icdf_table)"""
+    key = ("gf4scale", float(sigma), tail)
     if key not in _LUT_CACHE:
         rng = np.random.default_rng(12345)
-        g = rng.standard_normal((1 << 16, 8)).astype(np.float32) * np.float32(sigma)
+        g = (rng.standard_normal((1 << 16, 8)) if tail == "normal" else rng.standard_t(4, size=(1 << 16, 8)) / math.sqrt(2.0)).astype(np.float32) * np.float32(sigma)
         idx = np.abs(g).argmax(-1)
         m = np.take_along_axis(g, idx[:, None], -1)[:, 0]
         _LUT_CACHE[key] = f32_to_fp8_e5m2(m.astype(np.float16).astype(np.float32))
@@ -523,10 +541,10 @@ def big_zeros(shape, dtype) -> np.ndarray:
     return np.frombuffer(m, dtype=dtype, count=int(np.prod(shape))).reshape(shape)  # (the array keeps the mapping alive)
 
 
-def _fill_codes(out: np.ndarray, dtype: str, sigma: float, seed: int) -> None:
+def _fill_codes(out: np.ndarray, dtype: str, sigma: float, seed: int, tail: str = "normal") -> None:
     """fill the storage array `out` (uint16 / uint8 / uint32) with random weight codes"""
     flat = out.reshape(-1)
-    lut = _gf4_scale_lut(sigma) if dtype == "gf4" else _code_lut(dtype, sigma)
+    lut = _gf4_scale_lut(sigma, tail) if dtype == "gf4" else _code_lut(dtype, sigma, tail)
     lib = _synth_lib()
     if lib is not None:
         kind = {"fp8": 0, "fp16": 1, "gf4": 2}[dtype]
@@ -545,7 +563,7 @@ def _fill_codes(out: np.ndarray, dtype: str, sigma: float, seed: int) -> None:
             flat[a:b] = lut[u]
 
 
-def _synth_walk(spec: "ModelSpec", dtype: str, seed: int, n_layers: Optional[int], W, F, with_tokenizer: bool = True):
+def _synth_walk(spec: "ModelSpec", dtype: str, seed: int, n_layers: Optional[int], W, F, with_tokenizer: bool = True, lognormal_norms: bool = False):
     """the tensor sequence of a synthetic model in file order: W(shape, sigma, fill_seed) makes a weight tensor, F(array) passes
     a small fp32 one on.  One walk serves the host filler (synth_stream_big) and the device filler (synth_device): same names,
     same order, same per-tensor seeds -- the two produce the same bytes."""
@@ -560,6 +578,8 @@ def _synth_walk(spec: "ModelSpec", dtype: str, seed: int, n_layers: Optional[int
         return W(shape, scale / math.sqrt(fan_in), seed * 100003 + counter[0])
 
     def norm_w():
+        if lognormal_norms:  # (synth_model_big(outliers=True): norm weights of trained models spread over an order of magnitude)
+            return F(np.exp(0.4 * rng.standard_normal(s.dim)).astype(np.float32))
         return F((1 + 0.1 * rng.standard_normal(s.dim)).astype(np.float32))
 
     yield "model.embed.weight", WW((s.vocab_size, s.dim), 1.0)
@@ -586,7 +606,7 @@ def _synth_walk(spec: "ModelSpec", dtype: str, seed: int, n_layers: Optional[int
         yield "tokenizer.scores", scores
 
 
-def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None, reuse: bool = True):
+def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None, reuse: bool = True, tail: str = "normal"):
     """Yield (name, array) for every tensor of a full-size synthetic model, in file order, in seconds.
 
     Weight CODES are sampled directly -- fp16 / fp8: the quantised value of a N(0, 1/fan_in) draw
@@ -610,10 +630,10 @@ def synth_stream_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optio
         if a is None:
             a = big_zeros(sshape, store)
             pool[key] = a
-        _fill_codes(a, dtype, sigma, fill_seed)
+        _fill_codes(a, dtype, sigma, fill_seed, tail)
         return a.view(np.float16) if dtype == "fp16" else (as_fp8(a) if dtype == "fp8" else a.view(np.int32))
 
-    return _synth_walk(spec, dtype, seed, n_layers, W, lambda a: a)
+    return _synth_walk(spec, dtype, seed, n_layers, W, lambda a: a, lognormal_norms=tail != "normal")
 
 
 _DEV_SYNTH_LIB = None
@@ -715,11 +735,53 @@ def stub_tensors(spec: ModelSpec, dtype: str, n_layers: Optional[int] = None) ->
     return t
 
 
-def synth_model_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None):
+OUTLIER_CHANNELS = 6
+
+
+def outlier_channels(spec: ModelSpec, seed: int) -> np.ndarray:
+    """the residual channels synth_model_big(outliers=True) inflates (sorted)"""
+    return np.sort(np.random.default_rng(seed * 7919 + 13).choice(spec.dim, OUTLIER_CHANNELS, replace=False))
+
+
+def _rescale(a: np.ndarray, dtype: str, rows, cols, factor: float) -> None:
+    """multiply the weights a[rows, cols] (storage array of `dtype`; rows / cols: index arrays or None = all) by `factor`, in place,
+    through a decode / re-quantise of the touched rows (gf4: of the touched 8-weight groups -- their other members keep their values
+    up to the coarser code grid of the group's new scale)"""
+    if dtype == "gf4":
+        if cols is None:
+            a[rows] = quantize_gf4(gf4_to_f32(a[rows]) * np.float32(factor))
+            return
+        for c in cols:  # one group column at a time (vocab x 8 floats)
+            g = gf4_to_f32(a[:, c // 8:c // 8 + 1])
+            g[:, c % 8] *= np.float32(factor)
+            a[:, c // 8:c // 8 + 1] = quantize_gf4(g)
+        return
+    view = a.view(np.float16) if dtype == "fp16" else a.view(np.uint8)
+    sel = (slice(None) if rows is None else rows, slice(None) if cols is None else cols)
+    w = dequantize(view[sel], dtype) * np.float32(factor)
+    view[sel] = quantize(w, dtype).view(view.dtype)
+
+
+def synth_model_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None, outliers: bool = False):
     """(tensors, metadata) of a full-shape synthetic model held entirely on the host (every tensor its
-    own array) -- use for layer-reduced models; for 7 GB+ models stream with synth_stream_big"""
+    own array) -- use for layer-reduced models; for 7 GB+ models stream with synth_stream_big.
+
+    outliers=True (round 6): the statistics the default fixture lacks and trained checkpoints have.  N(0, 1 / fan_in) weights with norm
+    weights 1 +- 0.1 keep every activation O(1) at any depth; a trained model's residual stream carries a handful of channels of
+    10^2 - 10^3 ("massive activations"), its weights are heavy-tailed and its norm weights spread over an order of magnitude.  Here:
+    Student-t (4 degrees of freedom, unit variance) weight entries, log-normal norm weights, and OUTLIER_CHANNELS residual channels
+    whose embedding columns are scaled by 24 and whose wo / w2 output rows by 16 in every layer, so the channel random-walks to a few
+    hundred by mid-depth while the others stay O(1) (dense models; tests/test_calmfile.py measures it with the oracle)."""
     s = dataclasses.replace(spec, n_layers=n_layers if n_layers is not None else spec.n_layers)
-    return dict(synth_stream_big(spec, dtype, seed, n_layers, reuse=False)), s.metadata(dtype)
+    tensors = dict(synth_stream_big(spec, dtype, seed, n_layers, reuse=False, tail="t4" if outliers else "normal"))
+    if outliers:
+        assert not s.n_experts, "outliers: dense models"
+        ch = outlier_channels(spec, seed)
+        _rescale(tensors["model.embed.weight"], dtype, None, ch, 24.0)
+        for l in range(s.n_layers):
+            _rescale(tensors[f"model.layers.{l}.attn.wo.weight"], dtype, ch, None, 16.0)
+            _rescale(tensors[f"model.layers.{l}.mlp.w2.weight"], dtype, ch, None, 16.0)
+    return tensors, s.metadata(dtype)
 
 
 def write_synth_big(path: str, spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Optional[int] = None) -> int:

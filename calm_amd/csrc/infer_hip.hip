@@ -99,6 +99,7 @@ int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every
                        // stream (kernels.hip.h k_ffn_down SEG) where all images together stay under 96 KiB; 0: one pass per expert
 int g_skew = 14;       // k_ffn_up: percent more tasks for the first-dispatched workgroup of each CU than an even split gives it (0: even) (k_ffn_up, k_output at two workgroups per CU; kernels.hip.h task_range)
 int g_qkv_wgs = 0;     // workgroups per CU of k_qkv's grid where the tasks exceed it (0: the rule in launch_qkv; A/B switch)
+long g_fused_steps = 0; // decode steps enqueued with the attention inside k_qkv's launch (calm_hip_configure("fused_steps"): tests check the path they mean to test ran)
 int g_qkv_attn = 1;    // short-context attention inside k_qkv's launch (kernels.hip.h k_qkv_attn) where the shape allows (fused_ok); 0: k_qkv, then k_attn
 int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
 int g_pf_score_mb = 256; // MiB of logits scratch the scoring GEMM may use (prefill_logprobs_hip scores a chunk in blocks of that many rows; read when the scratch is allocated)
@@ -929,9 +930,8 @@ void enqueue_step(Ctx* c, const StepPlan& sp, bool timed) {
 	}
 	for (int l = 0; l < c->n_layers; ++l) {
 		mark();
-		if (sp.fused) {
+		if (sp.fused) { // one launch, one span: a profiled step files it (and both stages' bytes) under the QKV stage
 			launch_qkv_attn<DB, KVB>(c, l);
-			mark(); // (the attention stage's span of a profiled step is empty)
 		} else {
 			launch_qkv<DB, KVB>(c, l);
 			mark();
@@ -1045,6 +1045,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 	sp.sink = kv_sink > 0;
 	sp.n_split = attn_splits(c, kv_len);
 	sp.fused = fused_step(c, kv_len, sp.n_split);
+	g_fused_steps += sp.fused;
 	c->attn_chunk = (kv_len + sp.n_split - 1) / sp.n_split;
 	const int attn_two = c->attn_chunk <= 2 * 4 * (64 / c->lpr) * 4; // the split kernel's two-round form (launch_attn_lpr): a different graph
 	sp.chained = tok_src != nullptr;
@@ -1126,7 +1127,7 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 		}
 		dispatch_step(c, sp, true);
 		HIP_CHECK(hipStreamSynchronize(g_stream));
-		const size_t nspans = (size_t)c->n_layers * 5 + (sp.kv_only ? 0 : 1);
+		const size_t nspans = (size_t)c->n_layers * (sp.fused ? 4 : 5) + (sp.kv_only ? 0 : 1);
 		double marker_us = c->marker_us;
 		if (calibrate) {
 			float marked_ms = 0;
@@ -1146,7 +1147,13 @@ void run_step(Ctx* c, int token, const int* tok_src, int pos, StepPlan sp, bool 
 			c->prof[stage].runs++;
 		};
 		for (int l = 0; l < c->n_layers; ++l) {
-			span(CALM_STAGE_QKV), span(CALM_STAGE_ATTN), span(CALM_STAGE_ATTN_OUT), span(CALM_STAGE_FFN_UP), span(CALM_STAGE_FFN_DOWN);
+			span(CALM_STAGE_QKV);
+			if (sp.fused) { // k_qkv_attn: the cached rows it read count under the launch that read them; no attention row of its own
+				c->prof[CALM_STAGE_QKV].bytes += stage_bytes(c, CALM_STAGE_ATTN, kv_len);
+			} else {
+				span(CALM_STAGE_ATTN);
+			}
+			span(CALM_STAGE_ATTN_OUT), span(CALM_STAGE_FFN_UP), span(CALM_STAGE_FFN_DOWN);
 		}
 		if (!sp.kv_only) {
 			span(CALM_STAGE_OUTPUT);
@@ -1624,6 +1631,8 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 	} else if (!strcmp(key, "qkv_attn")) {
 		slot = &g_qkv_attn;
 
+	} else if (!strcmp(key, "fused_steps")) {
+		return (int)(g_fused_steps & 0x7fffffff);
 	} else if (!strcmp(key, "fuse_timeouts")) { // bounded waits of k_qkv_attn that expired, over every prepared model (0 unless a launch lost a producer)
 		unsigned total = 0;
 		for (auto& kv : g_ctx) {
@@ -1783,6 +1792,7 @@ extern "C" void init_hip(void) {
 	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
+	g_qkv_attn = env_int("CALM_HIP_QKV_ATTN", g_qkv_attn);
 	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
 	g_pf_big = env_int("CALM_HIP_PF_BIG", g_pf_big);
 	g_pf_chunk = env_int("CALM_HIP_PF_CHUNK", g_pf_chunk);

@@ -24,7 +24,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 REFERENCE = "/root/reference"
 
 GOLDEN_CASES = ["tiny_fp16", "tiny_fp8", "tiny_gf4", "moe_fp8", "ln_gelu_clip_fp16", "par_fp8", "bias_tied_gf4", "sink_fp16", "ragged_fp8",
-                "partial_rope_fp16", "dbrx_like_fp8", "mqa_hd96_fp16", "moe_gf4", "hd256_sink_fp8", "moe6_fp8", "moe12_ln_fp16"]
+                "partial_rope_fp16", "dbrx_like_fp8", "mqa_hd96_fp16", "moe_gf4", "hd256_sink_fp8", "moe6_fp8", "moe12_ln_fp16",
+                "fuse_hd64_bias_fp16", "fuse_hd128_sink_fp16"]
 
 
 # ---- tolerances (max |delta| over a token's logits / max |logit|) ----------------------------------------------

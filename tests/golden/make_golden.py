@@ -58,6 +58,11 @@ CASES = {
     "moe12_ln_fp16": (dict(n_experts=12, n_experts_active=3, norm_type="layernorm"), "fp16", 24),
     # head_dim 256 (gemma-style), GELU, runs past a 12-row rolling buffer with fp8 weights
     "hd256_sink_fp8": (dict(dim=512, hidden_dim=544, head_dim=256, n_heads=2, n_kv_heads=1, n_layers=1, vocab_size=160, act_type="gelu", max_seq_len=12), "fp8", 30),
+    # Shapes the fused k_qkv_attn launch takes (round 6: heads of 64 / 128, a 512-column input vector = whole-KiB fp16 rows; the tiny
+    # cases above have heads of 16 and ragged rows and stay with k_qkv + k_attn): head 64 with q/k/v biases and two layers (the
+    # hand-off granules' tags name the layer), head 128 past a 16-row rolling buffer (the masked slot is NOT the last row, sink keys)
+    "fuse_hd64_bias_fp16": (dict(dim=512, hidden_dim=512, head_dim=64, n_heads=4, n_kv_heads=2, vocab_size=160, qkv_bias=True), "fp16", 24),
+    "fuse_hd128_sink_fp16": (dict(dim=512, hidden_dim=512, head_dim=128, n_heads=4, n_kv_heads=2, n_layers=1, vocab_size=160, max_seq_len=16), "fp16", 40),
 }
 FIRST_TOKEN = 5
 

@@ -306,6 +306,62 @@ def test_launch_forms_that_only_reorder_work_are_bit_identical(hiplib, name, dty
             hiplib.calm_hip_configure(b"moe_route", old)
 
 
+@pytest.mark.parametrize("knob", [1, 0])
+@pytest.mark.parametrize("case", ["fuse_hd64_bias_fp16", "fuse_hd128_sink_fp16"])
+def test_attention_inside_the_qkv_launch_gives_the_reference_logits(hiplib, case, knob):
+    """k_qkv_attn (round 6): short-context attention as the first n_heads workgroups of k_qkv's launch -- cached rows prefetched into
+    registers, q / k / v of the token handed over as tagged granules -- against the reference's own logits, and the two-launch form on
+    the same fixtures.  The fixtures are the shapes the fused launch takes (heads of 64 / 128, whole-KiB rows); two layers exercise
+    the tag's layer field, the rolling 16-row buffer a masked slot in the middle of the cached range and the re-rotated sink keys."""
+    model, z = load_golden(case)
+    old = hiplib.calm_hip_configure(b"qkv_attn", knob)
+    before = hiplib.calm_hip_configure(b"fused_steps", -1)
+    b = HipBackend(model)
+    try:
+        for pos, tok in enumerate(z["tokens"]):
+            assert rel_err(b.forward(int(tok), pos, 0), z["logits"][pos]) < LOGIT_TOL, pos
+        ran = hiplib.calm_hip_configure(b"fused_steps", -1) - before
+        assert ran == (len(z["tokens"]) if knob else 0), "the step did not take the launch form this test is about"
+        assert hiplib.calm_hip_configure(b"fuse_timeouts", -1) == 0
+        k = b.read_kv(0, 0).astype(np.float32)
+        kg = z["k_last"].view(np.float16).astype(np.float32)
+        assert np.abs(k - kg).max() <= 2e-3 * max(np.abs(kg).max(), 1.0)
+    finally:
+        b.close()
+        hiplib.calm_hip_configure(b"qkv_attn", old)
+
+
+@pytest.mark.parametrize("name,dtype,layers,kvbits,knob", [("mistral-7b", "fp8", 2, 16, 1), ("mistral-7b", "fp8", 2, 8, 1), ("tinyllama-1.1b", "fp16", 3, 16, 1),
+                                                      ("llama-3-8b", "gf4", 1, 16, 2)])
+def test_attention_inside_the_qkv_launch_agrees_with_two_launches_at_full_width(hiplib, name, dtype, layers, kvbits, knob):
+    """the same decode, 300 positions from 0, with the knob on and off at the BASELINE widths: the fused launch serves positions up to
+    its register capacity (256 cached rows at head size 128) and hands over to k_qkv + k_attn beyond it in the same sequence.  Logits
+    agree to summation order (fp16 cache) / to the e5m2 cache's code flips (FP8KV_TOL, tests/conftest.py); gf4 takes the fused launch
+    only when told to (knob 2: its k_qkv prefers the grid the fused launch cannot give it)."""
+    spec = cf.SPECS[name]
+    tensors, md = cf.synth_model_big(spec, dtype, seed=23, n_layers=layers)
+    model = HostModel(tensors, md, context=512)
+    n = 300
+
+    def run(v):
+        old = hiplib.calm_hip_configure(b"qkv_attn", v)
+        before = hiplib.calm_hip_configure(b"fused_steps", -1)
+        b = HipBackend(model, kvbits=kvbits)
+        try:
+            out = np.stack([b.forward((7 * pos + 3) % spec.vocab_size, pos, 0).copy() for pos in range(n)])
+            return out, hiplib.calm_hip_configure(b"fused_steps", -1) - before
+        finally:
+            b.close()
+            hiplib.calm_hip_configure(b"qkv_attn", old)
+
+    two, ran0 = run(0)
+    one, ran1 = run(knob)
+    assert ran0 == 0 and ran1 == (256 if spec.head_dim == 128 else n), (ran0, ran1)
+    assert np.isfinite(one).all() and hiplib.calm_hip_configure(b"fuse_timeouts", -1) == 0
+    worst = max(rel_err(one[p], two[p]) for p in range(n))
+    assert worst < (2e-5 if kvbits == 16 else FP8KV_TOL), worst
+
+
 @pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4"])
 def test_greedy_stream_identical_and_device_decode_agrees(hiplib, case):
     """free-running greedy decode: forward_hip + host argmax, generate(), and the device-side

@@ -19,22 +19,26 @@ pytestmark = pytest.mark.gpu
 ROW = re.compile(r"\[(\d+)\]\s+(\w+):\s+([\d.]+)%;\s+([\d.]+) usec/run,\s+([\d.]+) GB/s")
 
 
+@pytest.mark.parametrize("fused", [1, 0])
 @pytest.mark.skipif(not os.path.exists(oracle.RUN_HIP), reason="oracle/_ref/run_hip (reference CLI linked to libcalm_hip.so) not built")
-def test_perf_hip_breakdown_through_the_reference_cli(hiplib, tmp_path):
+def test_perf_hip_breakdown_through_the_reference_cli(hiplib, tmp_path, fused):
+    """fused = 1: the step's short-context attention rides in k_qkv's launch (k_qkv_attn, round 6) -- ONE launch, so the table has no
+    attention row and the QKV row carries both stages' bytes; fused = 0 (CALM_HIP_QKV_ATTN=0): the reference's six rows."""
     path = str(tmp_path / "mistral_l4_fp8.calm")
     spec, L, n = cf.SPECS["mistral-7b"], 4, 48
     cf.write_synth_big(path, spec, "fp8", seed=1, n_layers=L)
     acct = str(tmp_path / "kernel_bytes.json")
-    env = dict(os.environ, CALM_HIP_PROF="1", CUDA_INJECTION64_PATH="1", CALM_HIP_PROF_JSON=acct)  # run.c:630 gates perf_*() on the injection variable
+    env = dict(os.environ, CALM_HIP_PROF="1", CUDA_INJECTION64_PATH="1", CALM_HIP_PROF_JSON=acct, CALM_HIP_QKV_ATTN=str(fused))  # run.c:630 gates perf_*() on the injection variable
     env.pop("CALM_CPU", None)
     r = subprocess.run([oracle.RUN_HIP, path, "-i", "abc", "-t", "0", "-n", str(n)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "forward_hip breakdown" in r.stdout
     rows = {m.group(2): (float(m.group(3)), float(m.group(4)), float(m.group(5))) for m in ROW.finditer(r.stdout)}
-    assert set(rows) == {"matmul_qkv", "attn", "matmul_attn", "matmul_ffn_up", "matmul_ffn_down", "output"}, r.stdout[-1500:]
+    assert set(rows) == {"matmul_qkv", "matmul_attn", "matmul_ffn_up", "matmul_ffn_down", "output"} | (set() if fused else {"attn"}), r.stdout[-1500:]
     assert abs(sum(v[0] for v in rows.values()) - 100.0) < 0.5
     # the same stages timed back to back by perf_stage_hip on the same file
     model = HostModel.from_file(path)
+    old = hiplib.calm_hip_configure(b"qkv_attn", fused)
     b = HipBackend(model)
     try:
         for pos in range(8):
@@ -53,6 +57,12 @@ def test_perf_hip_breakdown_through_the_reference_cli(hiplib, tmp_path):
             # below by their share, three or four steps of 49)
             per_run = nbytes * (1 if st == "output" else L)
             got = rows[names[st]][2] * rows[names[st]][1] * 1e3
+            if fused and st == "qkv":
+                # (the fused launch's bytes include the cached rows it read, which grow with the position: perf_stage_hip quotes them at
+                # the 8th position, the table averages over the run's 48)
+                kv_row = 2 * spec.kv_dim * 2
+                assert 0.98 * per_run <= got <= 1.02 * (per_run + L * 48 * kv_row), (st, rows[names[st]], per_run)
+                continue
             assert (0.88 if st == "output" else 0.98) * per_run <= got <= 1.02 * per_run, (st, rows[names[st]], per_run)
         diag = os.environ.get("CALM_TEST_DIAG")  # the GPU sessions collect these across whole-suite runs (profiles/r05_gpu_tests.txt)
         if diag:
@@ -66,16 +76,23 @@ def test_perf_hip_breakdown_through_the_reference_cli(hiplib, tmp_path):
             assert 0.6 * gbps <= table <= 1.5 * gbps, (st, seen, r.stdout[-1200:])
     finally:
         b.close()
+        hiplib.calm_hip_configure(b"qkv_attn", old)
     # the byte account: launches and bytes of every decode kernel of the run (warm-up step + n - 1 decode steps + prompt steps)
     a = json.load(open(acct))
-    assert set(a) >= {"k_qkv", "k_attn", "k_attn_out", "k_ffn_up", "k_ffn_down", "k_output"}
+    qkv = "k_qkv_attn" if fused else "k_qkv"
+    assert set(a) >= {qkv, "k_attn_out", "k_ffn_up", "k_ffn_down", "k_output"} | (set() if fused else {"k_attn"})
     per = lambda k: a[k]["algorithmic_bytes"] / a[k]["launches"]
     assert per("k_ffn_up") == 2 * spec.hidden_dim * spec.dim and per("k_ffn_down") == spec.hidden_dim * spec.dim
-    assert per("k_qkv") == (spec.q_dim + 2 * spec.kv_dim) * spec.dim and per("k_attn_out") == spec.q_dim * spec.dim
+    assert per("k_attn_out") == spec.q_dim * spec.dim
     assert per("k_output") == spec.vocab_size * spec.dim
-    assert a["k_qkv"]["launches"] == a["k_ffn_up"]["launches"] and a["k_qkv"]["launches"] % L == 0
-    steps = a["k_qkv"]["launches"] // L
+    assert a[qkv]["launches"] == a["k_ffn_up"]["launches"] and a[qkv]["launches"] % L == 0
+    steps = a[qkv]["launches"] // L
+    qkv_w = (spec.q_dim + 2 * spec.kv_dim) * spec.dim
+    if fused:  # the fused launch's account = the weights + the cached rows every step read (positions 0 .. steps - 1, binary16 K and V)
+        assert qkv_w < per(qkv) <= qkv_w + steps * 2 * spec.kv_dim * 2
+    else:
+        assert per(qkv) == qkv_w
     # n_bandwidth of the reference's accounting (src/run.c:523-532) is what one step's weight kernels add up to
-    weights = sum(per(k) for k in ("k_qkv", "k_attn_out", "k_ffn_up", "k_ffn_down")) * L + per("k_output")
+    weights = (qkv_w + sum(per(k) for k in ("k_attn_out", "k_ffn_up", "k_ffn_down"))) * L + per("k_output")
     assert weights == model.accounting()[2] - sum(model.tensors[nm].nbytes for nm in model.tensors if nm.endswith("norm.weight"))
     assert steps >= n - 1
