@@ -771,7 +771,12 @@ def synth_model_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Option
     10^2 - 10^3 ("massive activations"), its weights are heavy-tailed and its norm weights spread over an order of magnitude.  Here:
     Student-t (4 degrees of freedom, unit variance) weight entries, log-normal norm weights, and OUTLIER_CHANNELS residual channels
     whose embedding columns are scaled by 24 and whose wo / w2 output rows by 16 in every layer, so the channel random-walks to a few
-    hundred by mid-depth while the others stay O(1) (dense models; tests/test_calmfile.py measures it with the oracle)."""
+    hundred by mid-depth while the others stay O(1) (dense models; tests/test_calmfile.py measures it with the oracle).
+    outliers=2: in addition the w1 / w3 columns those channels feed are scaled by 4 / 4096, so that gated hidden activations pass 65504 --
+    beyond binary16, where prefill_hip's hi + lo split gives up and sends the chunk back through the serial path (calm_hip.h:
+    "pf_redone").  (The gate's argument has to stay below 88: the reference is built with -ffast-math and its SiLU, x / (1 + expf(-x)),
+    turns a whole step into NaNs once expf overflows -- 128 on both columns did that at position 0; our restatement, built without
+    fast-math, did not.)"""
     s = dataclasses.replace(spec, n_layers=n_layers if n_layers is not None else spec.n_layers)
     tensors = dict(synth_stream_big(spec, dtype, seed, n_layers, reuse=False, tail="t4" if outliers else "normal"))
     if outliers:
@@ -781,6 +786,9 @@ def synth_model_big(spec: ModelSpec, dtype: str, seed: int = 0, n_layers: Option
         for l in range(s.n_layers):
             _rescale(tensors[f"model.layers.{l}.attn.wo.weight"], dtype, ch, None, 16.0)
             _rescale(tensors[f"model.layers.{l}.mlp.w2.weight"], dtype, ch, None, 16.0)
+            if int(outliers) >= 2:
+                _rescale(tensors[f"model.layers.{l}.mlp.w1.weight"], dtype, None, ch, 4.0)
+                _rescale(tensors[f"model.layers.{l}.mlp.w3.weight"], dtype, None, ch, 4096.0)
     return tensors, s.metadata(dtype)
 
 

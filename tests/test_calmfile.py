@@ -180,3 +180,33 @@ def test_quantize_gf4_is_the_reference_converters_gf4():
     assert got.shape == want.shape
     bad = np.nonzero(got != want)
     assert bad[0].size == 0, (bad[0][:5], bad[1][:5])
+
+
+def test_outlier_fixture_has_the_statistics_it_claims():
+    """synth_model_big(outliers=True): a handful of residual channels 1-2 orders of magnitude above the rest by mid-depth, heavy-tailed
+    weights, log-normal norm weights -- measured with the CPU oracle on the TinyLlama shape at half depth (the GPU tests run the
+    BASELINE shapes at full depth on it, tests/test_full_depth_parity.py)"""
+    from calm_amd.host import HostModel
+    from oracle import oracle
+
+    spec = cf.SPECS["tinyllama-1.1b"]
+    tensors, md = cf.synth_model_big(spec, "fp8", seed=5, n_layers=11, outliers=True)
+    plain, _ = cf.synth_model_big(spec, "fp8", seed=5, n_layers=1)
+    w = cf.dequantize(tensors["model.layers.3.mlp.w1.weight"], "fp8").ravel()
+    w0 = cf.dequantize(plain["model.layers.0.mlp.w1.weight"], "fp8").ravel()
+    sd = 1.0 / np.sqrt(spec.dim)
+    assert (np.abs(w) > 5 * sd).mean() > 20 * max((np.abs(w0) > 5 * sd).mean(), 1e-6)  # Student-t tails
+    g = tensors["model.layers.3.attn.norm.weight"]
+    assert g.min() > 0 and g.max() / g.min() > 5  # log-normal: an order of magnitude between channels
+    ch = cf.outlier_channels(spec, 5)
+    be = oracle.OracleBackend(HostModel(tensors, md, context=32))
+    try:
+        big, rest = [], []
+        for pos in range(4):
+            be.forward_stage(11 + 37 * pos, pos, 0, 1)  # first stage, not the last: state.x = the residual stream after 11 layers
+            x = be.state("x", spec.dim).copy()
+            big.append(np.abs(x[ch]).max())
+            rest.append(np.sqrt((np.delete(x, ch) ** 2).mean()))
+        assert min(big) > 60 and max(rest) < min(big) / 4, (big, rest)
+    finally:
+        be.close()

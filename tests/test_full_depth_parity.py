@@ -41,10 +41,17 @@ def more_cpu_threads():
         yield
 
 
-def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
+# the outlier fixture (calmfile.synth_model_big(outliers=True)): what two correct fp32 evaluations of a step may differ by.  Measured against
+# a float64 evaluation of position 0 (oracle/f64_step.py; profiles/r06_outliers.txt): the CPU reference itself sits 2.2e-4 ... 9.4e-4 from it,
+# our restatement 1.2e-4 ... 1.1e-3, the HIP backend 0.9e-4 ... 8.7e-4 -- so a pair of them is up to 1.4e-3 apart (benign fixture: all three
+# 2.3e-4 ... 4.1e-4, pairs <= 3.6e-4).  The bound below is that, with headroom; the float64 anchor is asserted separately.
+OUTLIER_TOL = 2.5e-3
+
+
+def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11, outliers=False, tol=TOL):
     """-> dict(worst relative error, positions where argmax differed, reference tokens, hip tokens)"""
     spec = cf.SPECS[name]
-    tensors, md = cf.synth_model_big(spec, dtype, seed)  # the real depth: n_layers is not overridden
+    tensors, md = cf.synth_model_big(spec, dtype, seed, outliers=outliers)  # the real depth: n_layers is not overridden
     model = HostModel(tensors, md)
     assert model.config.n_layers == spec.n_layers
     ref = oracle.RefBackend(model) if oracle.have_ref() else oracle.OracleBackend(model)
@@ -65,7 +72,7 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
             assert np.isfinite(lg).all(), pos
             e = rel_err(lg, lr)
             worst = max(worst, e)
-            assert e <= TOL, f"{name} {dtype}: position {pos}: max|delta|/max|logit| = {e:.3e} > {TOL}"
+            assert e <= tol, f"{name} {dtype}: position {pos}: max|delta|/max|logit| = {e:.3e} > {tol}"
             h = int(lg.argmax())
             hip_tokens.append(h)
             if h != ref_tokens[pos]:
@@ -77,6 +84,7 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
         # then the decode step at position m against the reference's logits there; and the scored log-probabilities of the stream
         m = n_tokens - 1
         prompt = [first_token] + ref_tokens[: m - 1]
+        redone0 = hip.lib.calm_hip_configure(b"pf_redone", -1)
         hip.prefill(prompt, 0)
         pf_err = rel_err(hip.forward(ref_tokens[m - 1], m, 0), ref_logits[m])
         lp = hip.prefill_logprobs(prompt + [ref_tokens[m - 1]], 0)
@@ -85,7 +93,15 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11):
             lr = ref_logits[pos].astype(np.float64)
             want.append((lr[ref_tokens[pos]] - lr.max()) - np.log(np.exp(lr - lr.max()).sum()))
         lp_err = float(np.abs(lp[:m] - np.array(want)).max())
-        return {"worst": worst, "diverged": diverged, "ref_tokens": ref_tokens, "hip_tokens": hip_tokens, "prefill": pf_err, "logprob": lp_err}
+        out = {"worst": worst, "diverged": diverged, "ref_tokens": ref_tokens, "hip_tokens": hip_tokens, "prefill": pf_err, "logprob": lp_err,
+               "pf_redone": hip.lib.calm_hip_configure(b"pf_redone", -1) - redone0, "logit_max": float(max(np.abs(l).max() for l in ref_logits))}
+        if outliers:  # position 0 against exact arithmetic: who is further from it, the reference or the HIP backend?
+            from oracle.f64_step import position0_logits_f64
+
+            l64 = position0_logits_f64(tensors, md, spec, dtype, [first_token])[0]
+            f = lambda a: float(np.abs(a.astype(np.float64) - l64).max() / np.abs(l64).max())
+            out["f64"] = (f(hip.forward(first_token, 0, 0)), f(ref_logits[0]))
+        return out
     finally:
         hip.close()
         ref.close()
@@ -103,6 +119,27 @@ def test_full_depth_logits_and_greedy_stream_match_the_reference(hiplib, name, d
         assert margin < 4 * TOL * lmax, f"{name} {dtype}: greedy streams part at position {pos} (hip {h}, reference {t}) with a reference top-2 margin of {margin:.3e}"
     if not r["diverged"]:
         assert r["hip_tokens"] == r["ref_tokens"]
+
+
+@pytest.mark.parametrize("name,dtype,n_tokens,outliers", [("mistral-7b", "fp8", 48, 1), ("llama-3-8b", "gf4", 48, 1), ("mistral-7b", "fp8", 24, 2)])
+def test_full_depth_parity_under_outlier_statistics(hiplib, name, dtype, n_tokens, outliers):
+    """The same comparison on the fixture with a trained model's statistics (calmfile.synth_model_big(outliers=True), round 6): residual
+    channels of 10^2 - 10^3, Student-t weights, log-normal norm weights -- what the reference's own quality gate (perplexity on real
+    checkpoints, src/run.c:258-316) meets and N(0, 1 / fan_in) weights never produce.  It exercises the 1e-3 bound where a few channels
+    carry the norm, gf4's 2^-a image scaling on large activations, and the prompt path's hi + lo binary16 split.  outliers = 2 pushes
+    gated hidden activations past 65504: a chunk whose activations leave the binary16 range must be sent back through the serial path
+    (pf_redone counts its tokens) -- at full size, with no loss of parity."""
+    r = full_depth_check(name, dtype, n_tokens, seed=5, outliers=outliers, tol=OUTLIER_TOL)
+    assert (r["pf_redone"] > 0) == (outliers == 2), r["pf_redone"]
+    print(f"{name} {dtype} full depth, outlier fixture, {n_tokens} positions: worst max|d|/max|logit| = {r['worst']:.3e} (max |logit| {r['logit_max']:.1f}); argmax differences: "
+          f"{r['diverged']}; after prefill_hip of the stream {r['prefill']:.3e} ({r['pf_redone']} prompt tokens redone serially); scored log-probabilities off by at most {r['logprob']:.3e}; "
+          f"position 0 against float64: HIP {r['f64'][0]:.2e}, CPU reference {r['f64'][1]:.2e}")
+    # the anchor: the HIP backend is about as close to exact arithmetic as the reference is
+    assert r["f64"][0] <= max(2 * r["f64"][1], 1e-3), r["f64"]
+    assert r["prefill"] <= OUTLIER_TOL, r["prefill"]
+    assert r["logprob"] <= 5e-3 * max(1.0, r["logit_max"] / 5), r["logprob"]
+    for pos, h, t, margin, lmax in r["diverged"]:
+        assert margin < 4 * OUTLIER_TOL * lmax, f"{name} {dtype}: greedy streams part at position {pos} (hip {h}, reference {t}) with a reference top-2 margin of {margin:.3e}"
 
 
 def test_full_depth_free_running_stream_mistral7b(hiplib):
