@@ -80,39 +80,34 @@ std::map<const void*, size_t> g_pending_uploads;
 int g_alloc_stage = -1;
 double g_hop_us = 0; // time inside the stage-to-stage copies of profiled steps, and their number (perf_hip; knobs "handoff_ns" / "handoffs")
 uint64_t g_hop_n = 0;
-int g_bpc = 0;       // cap on resident 256-thread workgroups per CU when sizing grids; 0: each kernel's default (2 -- measured: 2 beats 3 and 4 --
-                     // except where kernels.hip.h KShape names another)
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
-int g_down_u4 = 0;     // gf4 rows of 7 chunks: 7 = one 2 x 7 tile per task (12.8 us on the Llama-3-8B shape), else the kernel's shape (2 x 2: 9.7)
-int g_qkv_half = 0;    // k_qkv tiles half as deep: 0 = when a wave's share of the matrix is less than one tile (launch_qkv), 1 = always, 2 = never
-int g_out_one = 0;     // k_attn_out one row per task: 0 = by the same rule (rows_balance_one), 1 = always, 2 = never
-int g_down_one = 0;    // k_ffn_down one row per task: 0 = when row pairs would leave a full grid's last round markedly emptier (rows_balance_one), 1 = always, 2 = never
-int g_down_u = 2;      // k_ffn_down walks fp8 / fp16 rows of 4 n + 2 chunks in exact steps of 2 chunks (0: the format's 4-chunk steps; profiles/r03_startup_experiments.txt)
 int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the matrix cores over the transposed value cache where the head size is 128 (k_attn_vt); 0: k_attn_gqa
-int g_attn_waves = 16; // waves per workgroup of that kernel (16 / 8 / 4: the same positions per round, 4 / 8 / 16 tiles in flight per wave)
 int g_moe_route = 1;   // mixture-of-experts models: the router's logits from partial sums k_attn_out's epilogue leaves (k_ffn_up MOE == 2); 0: every
                        // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
-int g_down_seg = 1;    // mixtures of many small experts: k_ffn_down keeps every active expert's hidden vector in LDS and streams their rows as one task
-                       // stream (kernels.hip.h k_ffn_down SEG) where all images together stay under 96 KiB; 0: one pass per expert
-int g_skew = 14;       // k_ffn_up: percent more tasks for the first-dispatched workgroup of each CU than an even split gives it (0: even) (k_ffn_up, k_output at two workgroups per CU; kernels.hip.h task_range)
-int g_qkv_wgs = 0;     // workgroups per CU of k_qkv's grid where the tasks exceed it (0: the rule in launch_qkv; A/B switch)
+// "forms" (decode) and "pf_forms" (prompt ingestion): the launchers pick a kernel form per shape by rule; these two bit sets exist for the
+// tests that run EVERY shipping form on small fixtures and compare (0 = the rules).  No form here is an experiment: each is what some
+// BASELINE or public shape gets by rule.
+//   forms     1: plain forms -- input vector read from LDS at every step (not held in registers: other widths), k_ffn_up's rounds dealt
+//                evenly (no skew: other grids), one k_ffn_down pass per expert (not side by side: large experts)
+//             2: small-matrix forms always -- k_qkv tiles half as deep, k_attn_out / k_ffn_down one row per task (by rule: TinyLlama, DBRX)
+//   pf_forms  1: K-split GEMMs only (short prompts)          2: the big form for every dense FFN-up / classifier (long prompts)
+//             4: grouped (expert) GEMMs never in the big form   8: ... always           (by rule: from 64 packed rows per expert)
+//            16: lane-arithmetic prompt attention (head sizes other than 64 / 128)      32: no skinny chain for 3-4 token chunks
+int g_forms = 0, g_pf_forms = 0;
+constexpr int SKEW_PERCENT = 14; // k_ffn_up: more tasks for the first-dispatched workgroup of each CU than an even split gives it (skew_cut)
+inline int knob_small() { return (g_forms & 2) ? 1 : 0; } // rows_balance_one / launch_qkv: 0 = by the rule, 1 = always
+inline bool pf_wide_on() { return !(g_pf_forms & 1); }
+inline int pf_big_mode() { return (g_pf_forms & 1) ? 0 : ((g_pf_forms & 2) ? 2 : 1); }        // 0 never, 1 by the rule, 2 always
+inline int pf_moe_big_mode() { return (g_pf_forms & 4) ? 0 : ((g_pf_forms & 8) ? 2 : 1); }
 long g_fused_steps = 0; // decode steps enqueued with the attention inside k_qkv's launch (calm_hip_configure("fused_steps"): tests check the path they mean to test ran)
 int g_qkv_attn = 1;    // short-context attention inside k_qkv's launch (kernels.hip.h k_qkv_attn) where the shape allows (fused_ok); 0: k_qkv, then k_attn
-int g_xreg = 1;        // input vectors of 4096 columns at fp8 / gf4, 2048 at fp16: the lanes keep their slice of the activation image in registers (kernels.hip.h run_rows_impl XR); 0: LDS reads per step
 int g_pf_score_mb = 256; // MiB of logits scratch the scoring GEMM may use (prefill_logprobs_hip scores a chunk in blocks of that many rows; read when the scratch is allocated)
-int g_pf_skinny = 1;   // prompt chunks of 3 / 4 tokens through k_pf_skinny (one weight stream, four tokens behind it) instead of the GEMM forms
-int g_pf_attn_mfma = 1; // prompt attention on the matrix cores for head sizes 64 / 128 (0: the lane-arithmetic kernel)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
-int g_pf_wide = 1;     // prompt GEMMs: the wide (B shared through LDS) form where its grid fills the chip (0: K-split form only)
 int g_pf_chunk_moe = PF_NT_MOE; // ... of a mixture-of-experts model (1024, 2048 or 4096 = PF_NT_MOE; read at the same moment)
-int g_pf_moe_big = 1;  // the grouped GEMMs of a mixture of experts in the big form, every expert's rows padded to whole 128-row columns: 1 = from 64 packed
-                       // rows per expert on average (the rule in prefill_chunk), 0 = never (64-row columns, the wide / K-split forms), 2 = always (tests)
 int g_pf_chunk = PF_NT_DENSE; // tokens per prompt chunk of a dense model (read when a model's prompt buffers are allocated; PF_NT ... PF_NT_DENSE)
-int g_pf_rounds = 1;   // ... the wide form in 2 / 4 ranges of K where its last round of workgroups would be mostly empty (0: whole rows only; A/B switch)
-int g_pf_big = 1;      // ... and the big form (512 units x 128 tokens per workgroup) for the FFN-up / classifier of long chunks (0: never; 2: always, for tests)
 char g_devname[256] = "none";
 
 // CALM_HIP_PROF_JSON=<path>: algorithmic bytes per kernel, accumulated over every decode step of the process and written at
@@ -316,7 +311,7 @@ Ctx* ctx_of(struct Transformer* t) {
 // in flight; 4 waves per CU measured latency-bound: gf4 FFN-up ran at 2.6 TB/s on a "perfectly
 // balanced" b = 1 grid) -- so the waste is weighted by (1 + 1/(2b)).
 int pick_blocks(int ntasks, int wpb, int kernel_bpc = 0, int max_bpc = 0) {
-	int bpc = g_bpc > 0 ? g_bpc : (kernel_bpc > 0 ? kernel_bpc : 2);
+	int bpc = kernel_bpc > 0 ? kernel_bpc : 2; // resident 256-thread workgroups per CU a grid is sized for: 2 measured better than 3 and 4, except where KShape names another
 	if (max_bpc > 0 && bpc > max_bpc) {
 		bpc = max_bpc;
 	}
@@ -348,12 +343,28 @@ size_t lds_bytes(int n) {
 	return (size_t)xs_slots<DB>(n) * 16 + LDS_EXTRA;
 }
 
+// A kernel may use more than 48 KiB of dynamic LDS only once the function has been told so -- per device.  Every launcher does it at
+// its launch site through launch_lds (round 6; a list of instantiations kept by hand in prepare_hip used to, and a form missing from
+// it was a launch failure waiting for an unusual shape); what has been granted is remembered, so a launch costs one map lookup.
+std::map<std::pair<int, const void*>, size_t> g_lds_granted;
 template <class K>
 void allow_lds(K kernel, size_t bytes) {
-	if (bytes > 48 * 1024) {
-		CALM_REQUIRE(bytes <= 160 * 1024, "activation vector does not fit the 160 KiB LDS");
-		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+	if (bytes <= 48 * 1024) {
+		return;
 	}
+	CALM_REQUIRE(bytes <= 160 * 1024, "activation vector does not fit the 160 KiB LDS");
+	int dev = 0;
+	HIP_CHECK(hipGetDevice(&dev));
+	size_t& have = g_lds_granted[{dev, reinterpret_cast<const void*>(kernel)}];
+	if (have < bytes) {
+		HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+		have = bytes;
+	}
+}
+template <class K, class... Args>
+void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, Args... args) {
+	allow_lds(kernel, lds);
+	hipLaunchKernelGGL(kernel, grid, block, lds, g_stream, args...);
 }
 
 // tasks the first-dispatched half of a two-workgroups-per-CU grid takes (kernels.hip.h task_range): whole ROUNDS of the half grid
@@ -362,14 +373,14 @@ void allow_lds(K kernel, size_t bytes) {
 // + 0.8-1.5 %), Mixtral's 28 (- 0.3 us); DBRX's 42 rounds and the classifier measured slower with it, coarser rounds cannot be cut
 // finely enough (Llama-3 gf4: 7 rounds, already 4 + 3).  0: no skew
 inline int skew_cut(int ntasks, int grid, int waves_per_block) {
-	if (g_skew <= 0 || grid != 2 * g_ncu) {
+	if ((g_forms & 1) || grid != 2 * g_ncu) {
 		return 0;
 	}
 	const int stride = (grid / 2) * waves_per_block, rounds = (ntasks + stride - 1) / stride;
 	if (rounds < 12 || rounds > 32) {
 		return 0;
 	}
-	const int r_old = (int)(rounds * (100 + g_skew) / 200.0 + 0.5);
+	const int r_old = (int)(rounds * (100 + SKEW_PERCENT) / 200.0 + 0.5);
 	return r_old >= rounds ? 0 : r_old * stride;
 }
 
@@ -377,7 +388,7 @@ inline int skew_cut(int ntasks, int grid, int waves_per_block) {
 // fp8 (4 chunks) or gf4 (2), 2048 at fp16 (4): the BASELINE models' dim
 template <int DB>
 inline bool use_xreg(int n) {
-	return g_xreg && n == xreg_chunks<DB, true>() * 64 * (128 / DB);
+	return !(g_forms & 1) && n == xreg_chunks<DB, true>() * 64 * (128 / DB);
 }
 
 // ---------------------------------------------------------------- stage launchers ---------------
@@ -420,7 +431,7 @@ void launch_qkv(Ctx* c, int l) {
 		// pick_blocks settles on ONE workgroup per CU for the 3072 row pairs of the BASELINE shapes (1.5 rounds of two per CU); measured
 		// (profiles/r04_startup.txt): right for fp8 (7.61 us; two per CU 8.15, three 7.62), wrong for gf4, whose half-size matrix wants the
 		// eight waves per CU: 6.86 -> 6.37 us
-		const int wgs = g_qkv_wgs > 0 ? g_qkv_wgs : (DB == 4 ? 2 : 0);
+		const int wgs = DB == 4 ? 2 : 0;
 		if (wgs > 0 && (ntasks + WG_WAVES - 1) / WG_WAVES > g_ncu * wgs) {
 			grid = dim3(g_ncu * wgs);
 		}
@@ -432,27 +443,26 @@ void launch_qkv(Ctx* c, int l) {
 	constexpr int U = KShape<DB, KS_QKV>::U;
 	const size_t per_wave = (size_t)(c->q_dim + 2 * c->kv_dim) * c->dim * DB / 8 / ((size_t)g_ncu * 2 * WG_WAVES);
 	const int chunks = (c->dim / (128 / DB) + 63) / 64;
-	const bool half = g_qkv_half ? g_qkv_half == 1 : (per_wave < (size_t)KShape<DB, KS_QKV>::NR * U * 1024 || (U > 1 && chunks % U != 0 && chunks % (U / 2) == 0));
+	const bool half = knob_small() ? true : (per_wave < (size_t)KShape<DB, KS_QKV>::NR * U * 1024 || (U > 1 && chunks % U != 0 && chunks % (U / 2) == 0));
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			by_bool(half, [&](auto HALF) {
-				hipLaunchKernelGGL((k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(HALF)::value>), grid, block, lds, g_stream, a.x, a.norm_w, a.dim, a.q_dim,
+				launch_lds(k_qkv<DB, KVB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(HALF)::value>, grid, block, lds, a.x, a.norm_w, a.dim, a.q_dim,
 				                   a.kv_dim, a);
 			});
 		});
 	});
 }
 
-// Short-context attention rides in k_qkv's launch (kernels.hip.h k_qkv_attn) when: the knob is on (1: by this rule; 2: also for gf4
-// weights); the step's attention is unsplit and its cached rows fit one workgroup's registers (256 at head size 128, 512 at 64); heads
+// Short-context attention rides in k_qkv's launch (kernels.hip.h k_qkv_attn) when: the knob is on; the weights are fp8 or fp16; the step's attention is unsplit and its cached rows fit one workgroup's registers (256 at head size 128, 512 at 64); heads
 // of 64 or 128 (8 / 16 lanes per row; LPR 4 is not instantiated, larger heads would need two loads per granule poll); the input vector
 // takes the 4-registers-per-thread staging and whole-KiB rows (every BASELINE shape; the other forms stay with the two launches rather
 // than doubling the instantiations); the heads leave at least half of the CUs to the row engine (FUSE_LDS: one workgroup per CU).
-// gf4 weights stay with the two launches by default: their k_qkv wants eight waves per CU (launch_qkv), the fused launch's row engine
+// gf4 weights stay with the two launches (no instantiation): their k_qkv wants eight waves per CU (launch_qkv), the fused launch's row engine
 // has four on ncu - n_heads CUs, and the two cancel (Llama-3-8B gf4, 8 layers: 2408-2439 tok/s against 2428-2432; profiles/r06_qkv_attn.txt).
 template <int DB>
 bool fused_ok(const Ctx* c, int kv_len, int n_split) {
-	return (DB == 4 ? g_qkv_attn == 2 : g_qkv_attn != 0) && c->gran && n_split == 1 && (c->lpr == 8 || c->lpr == 16) && kv_len <= fuse_max_kv(c->lpr) && stage_v4(c->dim, WG_THREADS) &&
+	return DB != 4 && g_qkv_attn != 0 && c->gran && n_split == 1 && (c->lpr == 8 || c->lpr == 16) && kv_len <= fuse_max_kv(c->lpr) && stage_v4(c->dim, WG_THREADS) &&
 	       rows_full<DB>(c->dim) && c->n_layers <= 256 && c->head_dim <= 4 * 64 && 2 * c->n_heads <= g_ncu;
 }
 // Every workgroup of the fused launch asks for more than half a CU's LDS, so a CU holds ONE: the attention workgroups get CUs of their
@@ -495,13 +505,14 @@ void launch_qkv_attn(Ctx* c, int l) {
 	constexpr int U = KShape<DB, KS_QKV>::U;
 	const size_t per_wave = (size_t)(c->q_dim + 2 * c->kv_dim) * c->dim * DB / 8 / ((size_t)g_ncu * 2 * WG_WAVES);
 	const int chunks = (c->dim / (128 / DB) + 63) / 64;
-	const bool half = g_qkv_half ? g_qkv_half == 1 : (per_wave < (size_t)KShape<DB, KS_QKV>::NR * U * 1024 || (U > 1 && chunks % U != 0 && chunks % (U / 2) == 0));
-	by_bool(half, [&](auto HALF) {
-		by_bool(c->lpr == 16, [&](auto L16) {
-			hipLaunchKernelGGL((k_qkv_attn<DB, KVB, decltype(HALF)::value, decltype(L16)::value ? 16 : 8>), grid, block, lds, g_stream, a.x, a.norm_w, a.dim, a.q_dim, a.kv_dim,
-			                   c->n_heads, a, f);
+	const bool half = knob_small() ? true : (per_wave < (size_t)KShape<DB, KS_QKV>::NR * U * 1024 || (U > 1 && chunks % U != 0 && chunks % (U / 2) == 0));
+	if constexpr (DB != 4) {
+		by_bool(half, [&](auto HALF) {
+			by_bool(c->lpr == 16, [&](auto L16) {
+				launch_lds(k_qkv_attn<DB, KVB, decltype(HALF)::value, decltype(L16)::value ? 16 : 8>, grid, block, lds, a.x, a.norm_w, a.dim, a.q_dim, a.kv_dim, c->n_heads, a, f);
+			});
 		});
-	});
+	}
 }
 
 // split attention on the matrix cores over the transposed value cache (k_attn_vt): prepare_hip keeps one for head size 128 and windows of whole 64-position blocks
@@ -544,13 +555,8 @@ void launch_attn_lpr(Ctx* c, int l, int n_split) {
 	a.pf_kv0 = 0, a.pf_stride = 0, a.pf_nb = 0;
 	if (n_split == 1) {
 		// short context: one 16-wave workgroup per query head, everything in one round, no merge pass
-		if (g_attn_waves == 4) {
-			hipLaunchKernelGGL((k_attn<KVB, LPR, 4>), dim3(c->n_heads), dim3(256), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
-		} else if (g_attn_waves == 8) {
-			hipLaunchKernelGGL((k_attn<KVB, LPR, 8>), dim3(c->n_heads), dim3(512), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
-		} else {
-			hipLaunchKernelGGL((k_attn<KVB, LPR, 16>), dim3(c->n_heads), dim3(1024), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
-		}
+		// (8 or 4 waves per workgroup measured 4.5 / 5.0 us against 3.65: profiles/HISTORY.md section 5c)
+		hipLaunchKernelGGL((k_attn<KVB, LPR, 16>), dim3(c->n_heads), dim3(1024), 0, g_stream, a.ts, a.q, a.kc, a.vc, a.head_dim, a.kv_mul, a.seq_len, a);
 		return;
 	}
 	// long context: K/V rows loaded once per kv head for several query heads, kv range split, then merged
@@ -618,7 +624,7 @@ inline bool rows_balance_one(int rows, int nr, int waves, int knob) {
 // k_attn_out's grid and row grouping (k_ffn_up's MOE == 2 form folds one partial column per workgroup of it)
 template <int DB>
 int attn_out_grid(const Ctx* c, bool* one_out = nullptr) {
-	const bool one = rows_balance_one(c->dim, KShape<DB, KS_ATTN_OUT>::NR, g_ncu * 2 * WG_WAVES, g_out_one);
+	const bool one = rows_balance_one(c->dim, KShape<DB, KS_ATTN_OUT>::NR, g_ncu * 2 * WG_WAVES, knob_small());
 	if (one_out) {
 		*one_out = one;
 	}
@@ -646,12 +652,12 @@ void launch_attn_out(Ctx* c, int l) {
 				by_bool(gate, [&](auto GATE) {
 					if constexpr (decltype(V4)::value && decltype(FULL)::value) {
 						if (use_xreg<DB>(c->q_dim)) {
-							hipLaunchKernelGGL((k_attn_out<DB, 4, true, decltype(ONE)::value, decltype(GATE)::value, true>), grid, block, lds, g_stream, c->x, c->att, wo, c->dim, c->q_dim, mt,
+							launch_lds(k_attn_out<DB, 4, true, decltype(ONE)::value, decltype(GATE)::value, true>, grid, block, lds, c->x, c->att, wo, c->dim, c->q_dim, mt,
 							                   c->gate_part, c->gate_ep);
 							return;
 						}
 					}
-					hipLaunchKernelGGL((k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(ONE)::value, decltype(GATE)::value>), grid, block, lds, g_stream, c->x,
+					launch_lds(k_attn_out<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value, decltype(ONE)::value, decltype(GATE)::value>, grid, block, lds, c->x,
 					                   c->att, wo, c->dim, c->q_dim, mt, c->gate_part, c->gate_ep);
 				});
 			});
@@ -685,7 +691,7 @@ void launch_ffn_up(Ctx* c, int l) {
 		a.n_experts = c->n_experts | (attn_out_grid<DB>(c) << 8) | (c->gate_ep << 24);
 		a.gate_c = c->gate_mt + (size_t)l * ((size_t)c->dim + 1) * c->gate_ep + (size_t)c->dim * c->gate_ep;
 	}
-	auto go = [&](auto kern) { hipLaunchKernelGGL(kern, grid, block, lds, g_stream, a.x, a.norm_w, a.w1, a.w3, a.moegate, a.dim, a.hidden, a.n_experts, a.n_active, a); };
+	auto go = [&](auto kern) { launch_lds(kern, grid, block, lds, a.x, a.norm_w, a.w1, a.w3, a.moegate, a.dim, a.hidden, a.n_experts, a.n_active, a); };
 	by_bool(stage_v4(c->dim, WG_THREADS), [&](auto V4) {
 		by_bool(rows_full<DB>(c->dim), [&](auto FULL) {
 			constexpr int V = decltype(V4)::value ? 4 : 8;
@@ -711,15 +717,6 @@ void launch_ffn_up(Ctx* c, int l) {
 	});
 }
 
-// gf4 rows of exactly 7 KiB chunks (hidden 14336) CAN take a 2 x 7 tile shape (knob "down_u4" = 7): one exact step per task.  It
-// was the default until round 3 (15.4 us against 17.9 for four half-empty 4 x 2 steps); tiles of 2 rows x 2 KiB measure 9.7 us
-// against its 12.8 -- with 14-KiB tiles every wave asks for the whole matrix before the hidden vector it needs first
-// (kernels.hip.h KShape).  For fp8 / fp16 rows the 2 x 7 shape measured SLOWER than 2 x 4 (14.0 vs 13.0 us at fp8, 223 VGPRs).
-inline bool ffn_down_u7(int hidden, int dbits) {
-	int nl = hidden / (128 / dbits);
-	return dbits == 4 && nl % 64 == 0 && (nl / 64) % 7 == 0;
-}
-
 // columns of w2 one k_ffn_down launch covers: all of hidden_dim while its fp32 image (plus gf4's word sums) fits the LDS,
 // else the smallest number of equal whole-KiB column ranges that do (Qwen1.5-72B's 49152 -> 2 x 24576)
 template <int DB>
@@ -740,7 +737,7 @@ int ffn_down_cols(int hidden) {
 // eight 4-KiB vectors, not Mixtral's two of 57 KiB (measured slower there, profiles/r04_moe.txt) -- and hidden_dim is one column range
 template <int DB>
 bool ffn_down_segs(const Ctx* c, int kn) {
-	return g_down_seg && c->n_active > 1 && kn == c->hidden && (size_t)c->n_active * xs_slots<DB>(kn) * 16 <= 96 * 1024;
+	return !(g_forms & 1) && c->n_active > 1 && kn == c->hidden && (size_t)c->n_active * xs_slots<DB>(kn) * 16 <= 96 * 1024;
 }
 
 template <int DB>
@@ -750,18 +747,19 @@ void launch_ffn_down(Ctx* c, int l) {
 	const int cols = ffn_down_cols<DB>(c->hidden);
 	for (int k0 = 0; k0 < c->hidden; k0 += cols) {
 		const int kn = c->hidden - k0 < cols ? c->hidden - k0 : cols;
-		// tile depth: the format's shape, or 2 rows x 7 / 2 chunks (ffn_down_u7; g_down_u = 2: rows of 4 n + 2 chunks -- hidden 14336
-		// at fp8 = 14 -- walked in exact steps of 2 instead of 4 + 4 + 4 + a half-empty 4)
+		// tile depth: the format's shape, or 2 rows x 2 chunks for fp8 / fp16 rows of 4 n + 2 chunks -- hidden 14336 at fp8 = 14 -- walked
+		// in exact steps of 2 instead of 4 + 4 + 4 + a half-empty 4 (- 1 us, profiles/r03_startup_experiments.txt; gf4's 7-chunk rows as one
+		// 2 x 7 tile measured 12.8 us against 9.7 for the format's 2 x 2: removed in round 6)
 		const int chunks = kn / (64 * (128 / DB));
 		// ... or ONE row x 4 chunks when the matrix has fewer row pairs than a full grid has waves (half of them would get no task)
-		const bool few_rows = rows_balance_one(c->dim, 2, g_ncu * (BLOCK / 64), g_down_one);
-		const int uo = (ffn_down_u7(kn, DB) && g_down_u4 == 7) ? 7 : (few_rows ? 1 : ((g_down_u == 2 && DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0));
+		const bool few_rows = rows_balance_one(c->dim, 2, g_ncu * (BLOCK / 64), knob_small());
+		const int uo = few_rows ? 1 : ((DB != 4 && rows_full<DB>(kn) && chunks % 4 == 2) ? 2 : 0);
 		int ntasks = c->dim / (uo == 1 ? 1 : (uo ? 2 : KShape<DB, KS_FFN_DOWN>::NR));
 		dim3 grid(pick_blocks(ntasks, BLOCK / 64)), block(BLOCK);
 		const bool segs = ffn_down_segs<DB>(c, kn);
 		size_t lds = segs ? (size_t)c->n_active * xs_slots<DB>(kn) * 16 + LDS_EXTRA : lds_bytes<DB>(kn);
 		auto go = [&](auto kern) {
-			hipLaunchKernelGGL(kern, grid, block, lds, g_stream, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
+			launch_lds(kern, grid, block, lds, c->x, c->he, w2, c->moe_w + (size_t)l * CALM_MAX_EXPERTS, c->moe_e + (size_t)l * CALM_MAX_EXPERTS, c->dim,
 			                   c->hidden, c->n_active, k0, kn);
 		};
 		if (segs) {
@@ -788,9 +786,7 @@ void launch_ffn_down(Ctx* c, int l) {
 		}
 		by_bool(stage_v4(kn, BLOCK), [&](auto V4) {
 			constexpr int V = decltype(V4)::value ? 4 : 8;
-			if (uo == 7) {
-				go(k_ffn_down<DB, BLOCK, V, 7, true, false>);
-			} else if (uo == 1 && rows_full<DB>(kn)) {
+			if (uo == 1 && rows_full<DB>(kn)) {
 				go(k_ffn_down<DB, BLOCK, V, 1, true, false>);
 			} else if (uo == 1) {
 				go(k_ffn_down<DB, BLOCK, V, 1, false, false>);
@@ -817,12 +813,12 @@ void launch_output(Ctx* c) {
 				// (not the gf4 classifier: its 4 workgroups per CU no longer fit with 145 VGPRs -- 3 fit, the grid's last quarter ran as a
 				// second batch: 46.9 against 45.0 us without, profiles/r04_gf4.txt)
 				if (use_xreg<DB>(c->dim) && DB != 4) {
-					hipLaunchKernelGGL((k_output<DB, 4, true, true>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab,
+					launch_lds(k_output<DB, 4, true, true>, grid, block, lds, c->logits_d, c->x, c->t->weights.rms_final_weight, c->t->weights.wcls, c->dim, c->vocab,
 					                   p->norm_eps, (int)p->norm_ln, 0);
 					return;
 				}
 			}
-			hipLaunchKernelGGL((k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>), grid, block, lds, g_stream, c->logits_d, c->x, c->t->weights.rms_final_weight,
+			launch_lds(k_output<DB, decltype(V4)::value ? 4 : 8, decltype(FULL)::value>, grid, block, lds, c->logits_d, c->x, c->t->weights.rms_final_weight,
 			                   c->t->weights.wcls, c->dim, c->vocab, p->norm_eps, (int)p->norm_ln, 0);
 		});
 	});
@@ -1272,10 +1268,10 @@ void launch_pf_attn_mfma(Ctx* c, int l, int nb, int pos0) {
 
 template <int KVB>
 void launch_pf_attn(Ctx* c, int l, int nb, int pos0) {
-	if (g_pf_attn_mfma && c->head_dim == 128) {
+	if (!(g_pf_forms & 16) && c->head_dim == 128) {
 		return launch_pf_attn_mfma<KVB, 128>(c, l, nb, pos0);
 	}
-	if (g_pf_attn_mfma && c->head_dim == 64) {
+	if (!(g_pf_forms & 16) && c->head_dim == 64) {
 		return launch_pf_attn_mfma<KVB, 64>(c, l, nb, pos0);
 	}
 	switch (c->lpr) {
@@ -1311,7 +1307,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	// k_pf_route, gran 2) where the chunk packs enough rows for the larger tile to pay for the extra padding (on average 64 rows per
 	// expert): from an average of 64 packed rows per expert -- Mixtral-8x7B from 256 tokens (+ 6 %; + 17 % at 1536), DBRX-132B from 256
 	// (+ 18 %), both behind at half that (profiles/r05_prefill.txt); fp8 / gf4 weights.  Otherwise 64-row columns and the wide / K-split forms.
-	const int moe_gran = (c->n_experts > 0 && DB != 16 && g_pf_big && g_pf_moe_big && (g_pf_moe_big >= 2 || g_pf_big >= 2 || nb * c->n_active >= 64 * c->n_experts)) ? 2 : 1;
+	const int moe_gran = (c->n_experts > 0 && DB != 16 && pf_big_mode() && pf_moe_big_mode() && (pf_moe_big_mode() >= 2 || pf_big_mode() >= 2 || nb * c->n_active >= 64 * c->n_experts)) ? 2 : 1;
 	// a grid of r rounds of workgroups over the CUs: whole rounds, and a last one that costs 0.6 of a round when it fills at most half
 	// the slots (measured: profiles/r04_prefill.txt), a full one otherwise
 	auto rounds_cost = [](double r) {
@@ -1329,7 +1325,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 			constexpr int CC = 16 * Fmt<DB>::G; // columns per chunk
 			constexpr int T = 4;
 			const int fit = (int)((150 * 1024) / (T * 4)) / CC * CC; // columns whose image fits
-			if (g_pf_skinny && nb <= T && !a.col_expert && a.K % CC == 0 && a.M % 4 == 0 && (epi == PF_EPI_RESID || a.K <= fit)) {
+			if (!(g_pf_forms & 32) && nb <= T && !a.col_expert && a.K % CC == 0 && a.M % 4 == 0 && (epi == PF_EPI_RESID || a.K <= fit)) {
 				const int ranges = (a.K + fit - 1) / fit;
 				const int per = ((a.K / CC + ranges - 1) / ranges) * CC;
 				for (int k0 = 0; k0 < a.K; k0 += per) {
@@ -1374,8 +1370,6 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 						best = t, kr = k;
 					}
 				}
-			} else if (epi == PF_EPI_RESID && g_pf_big == 3) {
-				kr = 0; // (A/B switch: the big form without the residual GEMM's ranges)
 			} else if (epi == PF_EPI_RESID) {
 				kr = g_ncu / (nxb * ncb);
 				kr = kr > 4 ? 4 : kr;
@@ -1385,7 +1379,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 					kr = 0; // (the residual GEMM only in ranges: unsplit, its 4096 units are a quarter of the chip)
 				}
 			}
-			if (g_pf_big && kr >= 1 && (g_pf_big >= 2 || grouped || (long)nxb * ncb * kr * 8 >= (long)g_ncu * 5)) {
+			if (pf_big_mode() && kr >= 1 && (pf_big_mode() >= 2 || grouped || (long)nxb * ncb * kr * 8 >= (long)g_ncu * 5)) {
 				a.ncols = ncb, a.ksplit = kr, a.partial = c->pf_partial, a.tile_count = c->pf_tile_count;
 				auto kern = k_pf_gemm_big<DB, epi>;
 				allow_lds(kern, PfBigA<DB>::LDS_BYTES);
@@ -1410,7 +1404,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 					ks = k;
 				}
 			}
-		} else if (g_pf_rounds) {
+		} else {
 			// Enough tiles -- but the workgroups run in rounds of two per CU, and what is left for the last round runs alone: Mixtral's
 			// grouped FFN-down at 1024 tokens is 1.25 rounds (886 us, 271 TFLOP/s).  Ranges of K (one workgroup each, as above) make the
 			// rounds finer: 2 or 4 where the model below says that saves more than the fold costs (~3 % per range).  A last round that fills
@@ -1429,7 +1423,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 				}
 			}
 		}
-		if (g_pf_wide && ks >= 1) {
+		if (pf_wide_on() && ks >= 1) {
 			a.ncols = ncols;
 			a.ksplit = ks, a.partial = c->pf_partial, a.tile_count = c->pf_tile_count;
 			auto kern = k_pf_gemm_wide<DB, kvb, epi, 1>;
@@ -1543,45 +1537,6 @@ void dispatch_prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed = t
 	CALM_REQUIRE(false, "unsupported dbits/kvbits combination");
 }
 
-template <int DB>
-void set_lds_attrs(Ctx* c) {
-	{
-		// only the hidden-sized image of k_ffn_down can exceed the default dynamic-LDS limit; the dim-sized
-		// images of the other kernels are checked too (dims up to ~38K floats fit the 160 KiB LDS)
-		const size_t big = lds_bytes<DB>(ffn_down_cols<DB>(c->hidden));
-		auto all = [&](auto V) {
-			constexpr int v = decltype(V)::value;
-			allow_lds(k_ffn_down<DB, 512, v, 7, true, false>, big), allow_lds(k_ffn_down<DB, 512, v, 2, true, false>, big), allow_lds(k_ffn_down<DB, 512, v, 1, true, false>, big);
-			allow_lds(k_ffn_down<DB, 512, v, 1, false, false>, big), allow_lds(k_ffn_down<DB, 512, v, 0, true, false>, big), allow_lds(k_ffn_down<DB, 512, v, 0, false, false>, big);
-		};
-		all(std::integral_constant<int, 4>()), all(std::integral_constant<int, 8>());
-		if (c->n_active > 1) { // the side-by-side form (ffn_down_segs): at most 96 KiB + the scratch behind it
-			const size_t sb = 96 * 1024 + LDS_EXTRA;
-			auto seg_all = [&](auto UOc) {
-				constexpr int uo = decltype(UOc)::value;
-				allow_lds(k_ffn_down<DB, 512, 4, uo, true, true>, sb), allow_lds(k_ffn_down<DB, 512, 4, uo, false, true>, sb);
-			};
-			seg_all(std::integral_constant<int, 1>()), seg_all(std::integral_constant<int, 2>()), seg_all(std::integral_constant<int, 4>());
-			seg_all(std::integral_constant<int, 9>()), seg_all(std::integral_constant<int, 10>()), seg_all(std::integral_constant<int, 12>());
-		}
-		{
-			const size_t fd = FUSE_LDS;
-			allow_lds(k_qkv_attn<DB, 16, false, 16>, fd), allow_lds(k_qkv_attn<DB, 16, true, 16>, fd), allow_lds(k_qkv_attn<DB, 16, false, 8>, fd), allow_lds(k_qkv_attn<DB, 16, true, 8>, fd);
-			allow_lds(k_qkv_attn<DB, 8, false, 16>, fd), allow_lds(k_qkv_attn<DB, 8, true, 16>, fd), allow_lds(k_qkv_attn<DB, 8, false, 8>, fd), allow_lds(k_qkv_attn<DB, 8, true, 8>, fd);
-		}
-		size_t d = lds_bytes<DB>(c->dim > c->q_dim ? c->dim : c->q_dim);
-		if (d > 48 * 1024) {
-			allow_lds(k_qkv<DB, 16, 8, true, false>, d), allow_lds(k_qkv<DB, 16, 8, false, false>, d), allow_lds(k_qkv<DB, 8, 8, true, false>, d), allow_lds(k_qkv<DB, 8, 8, false, false>, d);
-			allow_lds(k_qkv<DB, 16, 8, true, true>, d), allow_lds(k_qkv<DB, 16, 8, false, true>, d), allow_lds(k_qkv<DB, 8, 8, true, true>, d), allow_lds(k_qkv<DB, 8, 8, false, true>, d);
-			allow_lds(k_attn_out<DB, 8, true, false, false>, d), allow_lds(k_attn_out<DB, 8, false, false, false>, d), allow_lds(k_attn_out<DB, 8, true, true, false>, d), allow_lds(k_attn_out<DB, 8, false, true, false>, d);
-			allow_lds(k_attn_out<DB, 8, true, false, true>, d), allow_lds(k_attn_out<DB, 8, false, false, true>, d), allow_lds(k_attn_out<DB, 8, true, true, true>, d), allow_lds(k_attn_out<DB, 8, false, true, true>, d);
-			allow_lds(k_ffn_up<DB, 8, true, 0>, d), allow_lds(k_ffn_up<DB, 8, false, 0>, d), allow_lds(k_ffn_up<DB, 8, true, 1>, d), allow_lds(k_ffn_up<DB, 8, false, 1>, d);
-			allow_lds(k_ffn_up<DB, 8, true, 2>, d), allow_lds(k_ffn_up<DB, 8, false, 2>, d);
-			allow_lds(k_output<DB, 8, true>, d), allow_lds(k_output<DB, 8, false>, d);
-		}
-	}
-}
-
 } // namespace
 
 // ================================================================ C ABI =======================
@@ -1606,28 +1561,18 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_use_graph;
 	} else if (!strcmp(key, "prof")) {
 		slot = &g_prof;
-	} else if (!strcmp(key, "bpc")) {
-		slot = &g_bpc;
 	} else if (!strcmp(key, "split_t")) {
 		slot = &g_split_t;
 	} else if (!strcmp(key, "split_min")) {
 		slot = &g_split_min;
-	} else if (!strcmp(key, "attn_waves")) {
-		slot = &g_attn_waves;
 	} else if (!strcmp(key, "attn_vt")) {
 		slot = &g_attn_vt;
-	} else if (!strcmp(key, "down_u")) {
-		slot = &g_down_u;
-	} else if (!strcmp(key, "down_u4")) {
-		slot = &g_down_u4;
-	} else if (!strcmp(key, "qkv_half")) {
-		slot = &g_qkv_half;
-	} else if (!strcmp(key, "down_one")) {
-		slot = &g_down_one;
-	} else if (!strcmp(key, "out_one")) {
-		slot = &g_out_one;
 	} else if (!strcmp(key, "moe_route")) {
 		slot = &g_moe_route;
+	} else if (!strcmp(key, "forms")) {
+		slot = &g_forms;
+	} else if (!strcmp(key, "pf_forms")) {
+		slot = &g_pf_forms;
 	} else if (!strcmp(key, "qkv_attn")) {
 		slot = &g_qkv_attn;
 
@@ -1641,32 +1586,12 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 			total += e;
 		}
 		return (int)total;
-	} else if (!strcmp(key, "xreg")) {
-		slot = &g_xreg;
-	} else if (!strcmp(key, "qkv_wgs")) {
-		slot = &g_qkv_wgs;
-	} else if (!strcmp(key, "skew")) {
-		slot = &g_skew;
-	} else if (!strcmp(key, "down_seg")) {
-		slot = &g_down_seg;
-	} else if (!strcmp(key, "pf_wide")) {
-		slot = &g_pf_wide;
-	} else if (!strcmp(key, "pf_big")) {
-		slot = &g_pf_big;
-	} else if (!strcmp(key, "pf_rounds")) {
-		slot = &g_pf_rounds;
 	} else if (!strcmp(key, "pf_chunk")) {
 		CALM_REQUIRE(value < 0 || (value >= PF_NT && value <= PF_NT_DENSE && value % 128 == 0), "calm_hip_configure(\"pf_chunk\"): 1024 ... 2048 in steps of 128");
 		slot = &g_pf_chunk;
 	} else if (!strcmp(key, "pf_chunk_moe")) {
 		CALM_REQUIRE(value < 0 || value == 1024 || value == 2048 || value == PF_NT_MOE, "calm_hip_configure(\"pf_chunk_moe\"): 1024, 2048 or 4096");
 		slot = &g_pf_chunk_moe;
-	} else if (!strcmp(key, "pf_moe_big")) {
-		slot = &g_pf_moe_big;
-	} else if (!strcmp(key, "pf_attn_mfma")) {
-		slot = &g_pf_attn_mfma;
-	} else if (!strcmp(key, "pf_skinny")) {
-		slot = &g_pf_skinny;
 	} else if (!strcmp(key, "pf_score_mb")) {
 		CALM_REQUIRE(value < 0 || value >= 1, "calm_hip_configure(\"pf_score_mb\"): at least 1 MiB");
 		slot = &g_pf_score_mb;
@@ -1778,7 +1703,6 @@ extern "C" void init_hip(void) {
 		}
 		use_dev(0);
 	}
-	g_bpc = env_int("CALM_HIP_BPC", g_bpc);
 	g_use_graph = env_int("CALM_HIP_GRAPH", 1);
 	g_prof = env_int("CALM_HIP_PROF", 0);
 	g_prof_json = getenv("CALM_HIP_PROF_JSON");
@@ -1789,19 +1713,13 @@ extern "C" void init_hip(void) {
 	}
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
-	g_attn_waves = env_int("CALM_HIP_ATTN_WAVES", g_attn_waves);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
 	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
 	g_qkv_attn = env_int("CALM_HIP_QKV_ATTN", g_qkv_attn);
-	g_pf_wide = env_int("CALM_HIP_PF_WIDE", g_pf_wide);
-	g_pf_big = env_int("CALM_HIP_PF_BIG", g_pf_big);
 	g_pf_chunk = env_int("CALM_HIP_PF_CHUNK", g_pf_chunk);
 	CALM_REQUIRE(g_pf_chunk >= PF_NT && g_pf_chunk <= PF_NT_DENSE && g_pf_chunk % 128 == 0, "CALM_HIP_PF_CHUNK: 1024 ... 2048 in steps of 128");
 	g_pf_chunk_moe = env_int("CALM_HIP_PF_CHUNK_MOE", g_pf_chunk_moe);
 	CALM_REQUIRE(g_pf_chunk_moe == 1024 || g_pf_chunk_moe == 2048 || g_pf_chunk_moe == PF_NT_MOE, "CALM_HIP_PF_CHUNK_MOE: 1024, 2048 or 4096");
-	g_pf_moe_big = env_int("CALM_HIP_PF_MOE_BIG", g_pf_moe_big);
-	g_pf_attn_mfma = env_int("CALM_HIP_PF_ATTN_MFMA", g_pf_attn_mfma);
-	g_pf_skinny = env_int("CALM_HIP_PF_SKINNY", g_pf_skinny);
 	g_pf_score_mb = env_int("CALM_HIP_PF_SCORE_MB", g_pf_score_mb);
 	CALM_REQUIRE(g_pf_score_mb >= 1, "CALM_HIP_PF_SCORE_MB: at least 1 MiB");
 	if (env_int("CALM_HIP_VERBOSE", 0)) {
@@ -1994,17 +1912,6 @@ void prepare_ctx(struct Transformer* t) {
 	// logits land in pinned host memory: the host sampler reads and overwrites them (src/sampler.c:55)
 	HIP_CHECK(hipHostMalloc((void**)&c->logits_h, (size_t)c->vocab * sizeof(float), hipHostMallocDefault));
 	memset(c->logits_h, 0, (size_t)c->vocab * sizeof(float));
-
-	switch (c->dbits) {
-	case 16:
-		set_lds_attrs<16>(c);
-		break;
-	case 8:
-		set_lds_attrs<8>(c);
-		break;
-	default:
-		set_lds_attrs<4>(c);
-	}
 
 	c->ba.ts = c->ts;
 	c->ba.x = c->x;

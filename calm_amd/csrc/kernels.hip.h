@@ -839,23 +839,11 @@ __device__ __forceinline__ void run_rows_segs(int ntasks, int first, int stride,
 	run_rows_impl<DB, NR, U, FULL, true, 0>(ntasks, first, stride, n, segs, xs4, dummy, rows_of, pre, stage, aux_of, epi);
 }
 
-// Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): WG_THREADS per
-// workgroup; STAGE_FIRST: a workgroup barrier between the staging loads and the first weight-tile loads, so that every wave's
-// staging loads sit AHEAD of every tile load in the CU's memory queue (with one 512-thread workgroup per CU that is the whole CU).
-#ifndef CALM_WG_THREADS
-#define CALM_WG_THREADS 256
-#endif
-#ifndef CALM_STAGING_FIRST
-#define CALM_STAGING_FIRST 0
-#endif
-constexpr int WG_THREADS = CALM_WG_THREADS, WG_WAVES = WG_THREADS / 64;
-constexpr bool STAGE_FIRST = CALM_STAGING_FIRST != 0;
+// Workgroup shape of the matvec kernels that stage a dim-sized vector (k_qkv, k_attn_out, k_ffn_up, k_output): 256 threads, two
+// workgroups per CU.  (One 512-thread workgroup per CU: - 4 %; a barrier, or a wait for the vector to have landed, between the
+// staging loads and the first tile loads: no change -- profiles/HISTORY.md section 5c.)
+constexpr int WG_THREADS = 256, WG_WAVES = WG_THREADS / 64;
 __device__ __forceinline__ void stage_first_barrier() {
-	if constexpr (CALM_STAGING_FIRST == 2) {
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // A/B: the vector has LANDED before the first tile is asked for
-	} else if constexpr (STAGE_FIRST) {
-		__syncthreads();
-	}
 }
 
 // Tile shape per kernel and weight format: NR rows per task x U 1-KiB chunks of each per step, two tiles in flight per wave.
@@ -872,7 +860,6 @@ __device__ __forceinline__ void stage_first_barrier() {
 //     48.9, 45.2, 44.2, 47.2.
 //     Round 4: with the activations in registers (XREG) no row shares an image read any more and 2 x 2 -- 14 rounds of tasks, so the skewed
 //     deal applies -- is k_ffn_up's best: 4x1 13.70, 2x1 14.15, 2x2 13.43 us (profiles/r04_gf4.txt).
-// (The CALM_* macros are for A/B builds.)
 // Task ranges of a wave when the grid is two workgroups per CU and the FIRST-dispatched one is given more tasks (`cut` > 0; knob
 // "skew"): a CU's older workgroup wins its memory queue and used to leave 2-3 us before the younger one, whose waves then ran the
 // kernel's tail alone at half the bytes in flight (profiles/r02_kernel_timeline.txt).  Blocks [0, G/2) deal tasks [0, cut) among
@@ -900,60 +887,6 @@ template <int DB, bool XREG>
 constexpr int xreg_chunks() {
 	return XREG ? (DB == 4 ? 2 : 4) : 0;
 }
-#ifndef CALM_F8_QKV
-#define CALM_F8_QKV 2, 4
-#endif
-#ifndef CALM_F8_ATTN_OUT
-#define CALM_F8_ATTN_OUT 2, 2
-#endif
-#ifndef CALM_F8_FFN_UP
-#define CALM_F8_FFN_UP 2, 2
-#endif
-#ifndef CALM_F8_FFN_DOWN
-#define CALM_F8_FFN_DOWN 2, 4
-#endif
-#ifndef CALM_F8_OUTPUT
-#define CALM_F8_OUTPUT 2, 2
-#endif
-#ifndef CALM_F16_QKV
-#define CALM_F16_QKV 2, 4
-#endif
-#ifndef CALM_F16_ATTN_OUT
-#define CALM_F16_ATTN_OUT 2, 2
-#endif
-#ifndef CALM_F16_FFN_UP
-#define CALM_F16_FFN_UP 2, 2
-#endif
-#ifndef CALM_F16_FFN_DOWN
-#define CALM_F16_FFN_DOWN 2, 4
-#endif
-#ifndef CALM_F16_OUTPUT
-#define CALM_F16_OUTPUT 2, 2
-#endif
-#ifndef CALM_GF4_QKV
-#define CALM_GF4_QKV 2, 2
-#endif
-#ifndef CALM_GF4_ATTN_OUT
-#define CALM_GF4_ATTN_OUT 2, 1
-#endif
-#ifndef CALM_GF4_FFN_UP
-#define CALM_GF4_FFN_UP 2, 2
-#endif
-#ifndef CALM_GF4_FFN_DOWN
-#define CALM_GF4_FFN_DOWN 2, 2
-#endif
-#ifndef CALM_GF4_OUTPUT
-#define CALM_GF4_OUTPUT 2, 2
-#endif
-#ifndef CALM_GF4_OUTPUT_BPC
-#define CALM_GF4_OUTPUT_BPC 4
-#endif
-#ifndef CALM_F8_OUTPUT_BPC
-#define CALM_F8_OUTPUT_BPC 0
-#endif
-#ifndef CALM_F16_OUTPUT_BPC
-#define CALM_F16_OUTPUT_BPC 0
-#endif
 template <int NR_, int U_>
 struct ShapeOf {
 	static constexpr int NR = NR_, U = U_;
@@ -962,12 +895,12 @@ template <int K, class Q, class A, class F, class D, class O>
 using ShapePick = std::conditional_t<K == KS_QKV, Q, std::conditional_t<K == KS_ATTN_OUT, A, std::conditional_t<K == KS_FFN_UP, F, std::conditional_t<K == KS_FFN_DOWN, D, O>>>>;
 template <int DB, int K>
 struct KShape {
-	using S = std::conditional_t<DB == 4, ShapePick<K, ShapeOf<CALM_GF4_QKV>, ShapeOf<CALM_GF4_ATTN_OUT>, ShapeOf<CALM_GF4_FFN_UP>, ShapeOf<CALM_GF4_FFN_DOWN>, ShapeOf<CALM_GF4_OUTPUT>>,
-	                             std::conditional_t<DB == 8, ShapePick<K, ShapeOf<CALM_F8_QKV>, ShapeOf<CALM_F8_ATTN_OUT>, ShapeOf<CALM_F8_FFN_UP>, ShapeOf<CALM_F8_FFN_DOWN>, ShapeOf<CALM_F8_OUTPUT>>,
-	                                                ShapePick<K, ShapeOf<CALM_F16_QKV>, ShapeOf<CALM_F16_ATTN_OUT>, ShapeOf<CALM_F16_FFN_UP>, ShapeOf<CALM_F16_FFN_DOWN>, ShapeOf<CALM_F16_OUTPUT>>>>;
+	//                                                            k_qkv          k_attn_out     k_ffn_up       k_ffn_down     k_output
+	using S = std::conditional_t<DB == 4, ShapePick<K, ShapeOf<2, 2>, ShapeOf<2, 1>, ShapeOf<2, 2>, ShapeOf<2, 2>, ShapeOf<2, 2>>,    // gf4
+	                             ShapePick<K, ShapeOf<2, 4>, ShapeOf<2, 2>, ShapeOf<2, 2>, ShapeOf<2, 4>, ShapeOf<2, 2>>>;   // fp8, fp16
 	static constexpr int NR = S::NR, U = S::U;
-	// resident 256-thread workgroups per CU the kernel's grid is sized for while the "bpc" knob is 0 (0 here: the common default, 2)
-	static constexpr int BPC = K != KS_OUTPUT ? 0 : (DB == 4 ? CALM_GF4_OUTPUT_BPC : (DB == 8 ? CALM_F8_OUTPUT_BPC : CALM_F16_OUTPUT_BPC));
+	// resident 256-thread workgroups per CU the kernel's grid is sized for (0: the common default, 2): the gf4 classifier takes 4
+	static constexpr int BPC = (K == KS_OUTPUT && DB == 4) ? 4 : 0;
 };
 
 __device__ __forceinline__ float clipf(float x, float v) {
@@ -2280,9 +2213,7 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 // ---- attention output projection + residual:  x += wo . att      (src/infer.c:408-415) ---------
 // ONE: one row per task (tiles of the same size: twice as deep) -- for row counts that leave a full grid's last round of row PAIRS
 // half empty (DBRX's 6144 rows = 3072 pairs over 2048 waves; the host decides: rows_balance)
-#ifndef CALM_ONE_U
-#define CALM_ONE_U 2
-#endif
+constexpr int CALM_ONE_U = 2;
 // GATE (mixture-of-experts models, knob "moe_route"): the router's logits for the FFN that follows are LINEAR in the residual this
 // kernel completes -- logit_e = rsqrt(mean(x^2) + eps) * sum_j moegate[e][j] g[j] x[j] (src/infer.c:183-207 then :422-424) -- so the
 // lane that writes x[j] also adds x[j] * (moegate[e][j] g[j]) for every expert e (lane e of the wave: one coalesced load of row j of

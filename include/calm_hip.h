@@ -160,39 +160,34 @@ double perf_stage_hip(struct Transformer* transformer, int stage, int iters, uin
 /* name of the HIP device in use (static storage) */
 const char* calm_hip_device_name(void);
 
-/* Run-time knobs (the CALM_HIP_* environment variables read by init_hip set the same switches before the first model):
+/* Run-time knobs -- twelve (the CALM_HIP_GRAPH / _PROF / _SPLIT_T / _SPLIT_MIN / _ATTN_VT / _MOE_ROUTE / _QKV_ATTN / _PF_CHUNK / _PF_CHUNK_MOE /
+ * _PF_SCORE_MB environment variables read by init_hip set the same switches before the first model):
  *   "graph"     1 = replay each step from a hipGraph (default), 0 = eager launches
  *   "prof"      1 = eager launches bracketed by per-stage events, reported by perf_hip (a model split over stages: also an event pair
  *               around every stage-to-stage copy)
- *   "bpc"       cap on resident 256-thread workgroups per CU when sizing grids (default 0: each kernel's own -- 2, the gf4 classifier 4)
  *   "split_t"   cached positions per attention KV split (default 128)
  *   "split_min" contexts up to this many positions are not split (default 384)
  *   "attn_vt"   1 = split attention on the matrix cores over the transposed value cache (default; head size 128), 0 = lane arithmetic.
- *               Read by prepare_hip: 0 at that point also saves the transposed cache's memory
- *   "attn_waves" waves per workgroup of the unsplit attention kernel: 16 (default), 8 or 4
+ *               Read by prepare_hip: 0 at that point also saves the transposed cache's memory (+ 50 % of the KV cache)
  *   "moe_route" 1 = a mixture-of-experts layer's routing is derived from partial sums the attention output projection leaves
- *               (default), 0 = every workgroup of the FFN kernel computes the gate from the vector first
- *   "down_seg"  1 = a mixture of many small experts keeps all active experts' hidden vectors in LDS and streams their down-projection
- *               rows as one task stream (default; where the vectors together stay under 96 KiB), 0 = one pass per expert
- *   "xreg"      1 = input vectors of exactly 4 KiB of weights per row (4096 columns at fp8 / gf4, 2048 at fp16) are held in registers
- *               after staging (default), 0 = read from LDS at every step
- *   "skew"      percent more of the FFN up-projection's tasks for the first-dispatched workgroup of each CU (default 14; 0 = even)
- *   "qkv_half" / "out_one" / "down_one" / "down_u" / "down_u4": tile-shape overrides of single kernels (0 = the launchers' rules by
- *               matrix size; calm_amd/csrc/infer_hip.hip) -- for A/B measurements and the tests that force every shape
- *   "pf_wide" / "pf_big" / "pf_attn_mfma" / "pf_skinny": forms of the prompt-ingestion kernels (1 = default forms; "pf_big" 2: the
- *       512-unit x 128-token GEMM form for every dense fp8 / gf4 FFN-up and classifier whatever its grid -- a test switch)
- *   "pf_rounds": 1 = a prompt GEMM whose last round of workgroups would be mostly empty runs in 2 / 4 ranges of K (0: never; A/B switch)
+ *               (default), 0 = every workgroup of the FFN kernel computes the gate from the vector first (also the form of models
+ *               with more than 64 experts or a parallel residual)
+ *   "qkv_attn"  1 = a step whose cached rows fit one workgroup's registers (256 at head size 128, 512 at 64; fp8 / fp16 weights) runs
+ *               its attention inside the QKV projection's launch (default), 0 = two launches
+ *   "forms", "pf_forms": bit sets that force kernel forms the launchers otherwise pick by shape (0 = the rules; the forms are listed at
+ *               their definition in calm_amd/csrc/infer_hip.hip) -- for the tests that run every shipping form on small fixtures
  *   "pf_chunk": tokens per prompt chunk of a dense model, 1024 ... 2048 in steps of 128 (default 2048; read when a model's prompt
  *       buffers are allocated, i.e. at its first prefill_hip call)
- *   "pf_chunk_moe": ... of a mixture-of-experts model: 1024, 2048 or 4096 (default 4096; read at the same moment)
- *   "pf_moe_big": the grouped GEMMs of a mixture-of-experts chunk in the 512-unit x 128-token form, every expert's rows padded to whole
- *       128-row columns: 1 = where a chunk packs at least 64 rows per expert on average (fp8 / gf4 weights), 0 = never, 2 = always (tests)
+ *   "pf_chunk_moe": ... of a mixture-of-experts model: 1024, 2048 or 4096 (default 4096; read at the same moment).  The experts'
+ *       gathered rows take chunk x active experts x (dim + hidden_dim) x 4 bytes of scratch: 0.8 GB for Mixtral-8x7B, 1.7 GB for
+ *       DBRX-132B at 4096, a quarter of that at 1024
  *   "pf_score_mb": MiB of device scratch for the logits of prefill_logprobs_hip (default 256; read when that scratch is allocated, at a
  *       model's first scoring call): a chunk is scored in blocks of as many tokens as fit (whole 128-token columns, at least 128)
- *   "stage"     multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip)
+ * Placement: "stage" -- multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip).
  * Queries (value ignored): "stages" (pipeline stages of this process), "stage_device" (value = stage -> its device), "pf_redone"
  * (prompt tokens prefill_hip sent back through the serial path), "handoffs" / "handoff_ns" (stage-to-stage copies timed under "prof"
- * and their average duration).
+ * and their average duration), "fused_steps" (decode steps that took the "qkv_attn" launch), "fuse_timeouts" (its bounded waits that
+ * expired: 0 unless a launch lost a producer; the affected head's output is NaN).
  * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.  Changing a knob that shapes the launches drops
  * the captured graphs of every prepared model (they are re-captured on next use). */
 int calm_hip_configure(const char* key, int value);

@@ -260,24 +260,21 @@ def test_alternative_tile_shapes_give_the_reference_logits(hiplib, case):
     if case not in GOLDEN_CASES:
         pytest.skip("no such golden case")
     model, z = load_golden(case)
-    knobs = {b"qkv_half": 1, b"out_one": 1, b"down_one": 1}
-    for k, v in knobs.items():
-        assert hiplib.calm_hip_configure(k, v) == 0  # 0 = "by the rule" is the default
+    assert hiplib.calm_hip_configure(b"forms", 2) == 0  # 0 = "by the rule" is the default; 2: the small-matrix forms always
     b = HipBackend(model)
     try:
         for pos, tok in enumerate(z["tokens"]):
             assert rel_err(b.forward(int(tok), pos, 0), z["logits"][pos]) < LOGIT_TOL, pos
     finally:
         b.close()
-        for k in knobs:
-            hiplib.calm_hip_configure(k, 0)
+        hiplib.calm_hip_configure(b"forms", 0)
 
 
 @pytest.mark.parametrize("name,dtype,layers", [("mistral-7b", "fp8", 2), ("llama-3-8b", "gf4", 1), ("tinyllama-1.1b", "fp16", 2), ("mixtral-8x7b", "fp8", 1)])
 def test_launch_forms_that_only_reorder_work_are_bit_identical(hiplib, name, dtype, layers):
-    """Round 4's forms that change WHO does a row or WHERE its activations are read from, not its arithmetic -- activations in registers
-    ("xreg"), the skewed deal of k_ffn_up's task rounds ("skew"), all experts' images side by side in k_ffn_down ("down_seg") -- must
-    leave every logit bit-identical to the plain forms (full-width shapes: the knobs only engage at dim 4096 / 2048 and full grids).
+    """Round 4's forms that change WHO does a row or WHERE its activations are read from, not its arithmetic -- activations in registers,
+    the skewed deal of k_ffn_up's task rounds, all experts' images side by side in k_ffn_down -- must leave every logit bit-identical
+    to the plain forms ("forms" 1; full-width shapes: the forms only engage at dim 4096 / 2048 and full grids).
     "moe_route" changes the router's summation order: same experts away from near-ties, logits within the common tolerance."""
     spec = cf.SPECS[name]
     tensors, md = cf.synth_model_big(spec, dtype, seed=17, n_layers=layers)
@@ -292,12 +289,11 @@ def test_launch_forms_that_only_reorder_work_are_bit_identical(hiplib, name, dty
             b.close()
 
     base = run()
-    for knob, off in ((b"xreg", 0), (b"skew", 0), (b"down_seg", 0)):
-        old = hiplib.calm_hip_configure(knob, off)
-        try:
-            assert np.array_equal(run(), base), knob
-        finally:
-            hiplib.calm_hip_configure(knob, old)
+    old = hiplib.calm_hip_configure(b"forms", 1)
+    try:
+        assert np.array_equal(run(), base)
+    finally:
+        hiplib.calm_hip_configure(b"forms", old)
     if spec.n_experts:
         old = hiplib.calm_hip_configure(b"moe_route", 0)
         try:
@@ -331,13 +327,12 @@ def test_attention_inside_the_qkv_launch_gives_the_reference_logits(hiplib, case
         hiplib.calm_hip_configure(b"qkv_attn", old)
 
 
-@pytest.mark.parametrize("name,dtype,layers,kvbits,knob", [("mistral-7b", "fp8", 2, 16, 1), ("mistral-7b", "fp8", 2, 8, 1), ("tinyllama-1.1b", "fp16", 3, 16, 1),
-                                                      ("llama-3-8b", "gf4", 1, 16, 2)])
-def test_attention_inside_the_qkv_launch_agrees_with_two_launches_at_full_width(hiplib, name, dtype, layers, kvbits, knob):
+@pytest.mark.parametrize("name,dtype,layers,kvbits", [("mistral-7b", "fp8", 2, 16), ("mistral-7b", "fp8", 2, 8), ("tinyllama-1.1b", "fp16", 3, 16), ("llama-3-8b", "gf4", 1, 16)])
+def test_attention_inside_the_qkv_launch_agrees_with_two_launches_at_full_width(hiplib, name, dtype, layers, kvbits):
     """the same decode, 300 positions from 0, with the knob on and off at the BASELINE widths: the fused launch serves positions up to
     its register capacity (256 cached rows at head size 128) and hands over to k_qkv + k_attn beyond it in the same sequence.  Logits
-    agree to summation order (fp16 cache) / to the e5m2 cache's code flips (FP8KV_TOL, tests/conftest.py); gf4 takes the fused launch
-    only when told to (knob 2: its k_qkv prefers the grid the fused launch cannot give it)."""
+    agree to summation order (fp16 cache) / to the e5m2 cache's code flips (FP8KV_TOL, tests/conftest.py); gf4 weights never take the
+    fused launch (their k_qkv prefers the grid it cannot give them: launch rule fused_ok) -- the knob must change nothing there."""
     spec = cf.SPECS[name]
     tensors, md = cf.synth_model_big(spec, dtype, seed=23, n_layers=layers)
     model = HostModel(tensors, md, context=512)
@@ -355,8 +350,8 @@ def test_attention_inside_the_qkv_launch_agrees_with_two_launches_at_full_width(
             hiplib.calm_hip_configure(b"qkv_attn", old)
 
     two, ran0 = run(0)
-    one, ran1 = run(knob)
-    assert ran0 == 0 and ran1 == (256 if spec.head_dim == 128 else n), (ran0, ran1)
+    one, ran1 = run(1)
+    assert ran0 == 0 and ran1 == (0 if dtype == "gf4" else (256 if spec.head_dim == 128 else n)), (ran0, ran1)
     assert np.isfinite(one).all() and hiplib.calm_hip_configure(b"fuse_timeouts", -1) == 0
     worst = max(rel_err(one[p], two[p]) for p in range(n))
     assert worst < (2e-5 if kvbits == 16 else FP8KV_TOL), worst
@@ -735,7 +730,7 @@ def test_prefill_equals_the_serial_prompt_loop(hiplib, case, kvbits):
 
 @pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_prefill_big_gemm_form_on_every_golden_shape(hiplib, case):
-    """calm_hip_configure("pf_big", 2): the FFN-up and the classifier of every dense fp8 / gf4 chunk through k_pf_gemm_big (512 units x
+    """calm_hip_configure("pf_forms", 2): the FFN-up and the classifier of every dense fp8 / gf4 chunk through k_pf_gemm_big (512 units x
     128 tokens per workgroup) whatever the grid -- ragged hidden sizes, partial 128-token columns, gelu, parallel residual -- against
     the reference's golden logits and against the same prompt with the form off; scored log-probabilities of both agree."""
     model, z = load_golden(case)
@@ -744,19 +739,19 @@ def test_prefill_big_gemm_form_on_every_golden_shape(hiplib, case):
     big = HipBackend(model)
     plain = HipBackend(model)
     try:
-        assert hiplib.calm_hip_configure(b"pf_big", 2) == 1
+        assert hiplib.calm_hip_configure(b"pf_forms", 2) == 0  # 2: the big form always
         try:
             big.prefill(toks[: T - 1], 0)
             lb = big.forward(toks[T - 1], T - 1, 0).copy()
             lpb = big.prefill_logprobs(toks, 0)
         finally:
-            hiplib.calm_hip_configure(b"pf_big", 0)
+            hiplib.calm_hip_configure(b"pf_forms", 1)  # 1: K-split GEMMs only
         try:
             plain.prefill(toks[: T - 1], 0)
             lp = plain.forward(toks[T - 1], T - 1, 0).copy()
             lpp = plain.prefill_logprobs(toks, 0)
         finally:
-            hiplib.calm_hip_configure(b"pf_big", 1)
+            hiplib.calm_hip_configure(b"pf_forms", 0)
         assert rel_err(lb, z["logits"][T - 1]) < LOGIT_TOL, rel_err(lb, z["logits"][T - 1])
         assert rel_err(lb, lp) < 2e-5, rel_err(lb, lp)
         assert np.isfinite(lpb).all() and np.abs(lpb - lpp).max() < 1e-4 * max(1.0, float(np.abs(lpp).max()))
@@ -935,21 +930,21 @@ def test_prefill_chunks_of_three_or_four_tokens_stream_the_weights_once(hiplib, 
         for pos, tok in enumerate(toks[:-1]):
             o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         lo = o.forward(toks[-1], len(toks) - 1, 0).copy()
-        assert hiplib.calm_hip_configure(b"pf_skinny", -1) == 1
+        assert hiplib.calm_hip_configure(b"pf_forms", -1) == 0
         pos = 0
         for n in sizes:
             b.prefill(toks[pos : pos + n], pos)
             pos += n
         lb = b.forward(toks[-1], pos, 0).copy()
         assert rel_err(lb, lo) < logit_tol(kvbits), rel_err(lb, lo)
-        hiplib.calm_hip_configure(b"pf_skinny", 0)
+        hiplib.calm_hip_configure(b"pf_forms", 32)  # no skinny chain: the GEMM forms
         try:
             pos = 0
             for n in sizes:
                 g.prefill(toks[pos : pos + n], pos)
                 pos += n
         finally:
-            hiplib.calm_hip_configure(b"pf_skinny", 1)
+            hiplib.calm_hip_configure(b"pf_forms", 0)
         lg = g.forward(toks[-1], pos, 0).copy()
         assert rel_err(lg, lo) < logit_tol(kvbits), rel_err(lg, lo)
         if kvbits == 16:
@@ -968,7 +963,7 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
     """k_pf_attn_mfma (head sizes 64 / 128): every grouping of query heads per kv head it is compiled for -- 1, 2, 4 heads per
     round, one or several rounds, several token tiles per workgroup -- with both cache formats: a 333-token prompt in four
     calls (201, 3, 33 and 96 tokens: partial tiles on both sides, a nearly empty query tile), then one decode step against the oracle;
-    and the same prompt through the lane-arithmetic kernel (calm_hip_configure("pf_attn_mfma", 0)): cache rows equal"""
+    and the same prompt through the lane-arithmetic kernel (calm_hip_configure("pf_forms", 16)): cache rows equal"""
     dim = 256
     # (head size 128 with a window of whole 64-position blocks: V is read from the transposed cache -- the other window length keeps the
     # LDS-transposing form of the same kernel under test)
@@ -985,19 +980,19 @@ def test_prefill_attention_on_the_matrix_cores(hiplib, head_dim, n_heads, n_kv_h
         for pos, tok in enumerate(toks[:-1]):
             o.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         lo = o.forward(toks[-1], 333, 0).copy()
-        assert hiplib.calm_hip_configure(b"pf_attn_mfma", -1) == 1
+        assert hiplib.calm_hip_configure(b"pf_forms", -1) == 0
         b.prefill(toks[:201], 0)
         b.prefill(toks[201:204], 201)  # a chunk of three tokens (the smallest that is batched: one or two go through the decode path) ...
         b.prefill(toks[204:237], 204)  # ... of one tile and one token ...
         b.prefill(toks[237:333], 237)
         lb = b.forward(toks[-1], 333, 0).copy()
         assert rel_err(lb, lo) < logit_tol(kvbits), rel_err(lb, lo)
-        hiplib.calm_hip_configure(b"pf_attn_mfma", 0)
+        hiplib.calm_hip_configure(b"pf_forms", 16)
         try:
             v.prefill(toks[:201], 0)
             v.prefill(toks[201:333], 201)
         finally:
-            hiplib.calm_hip_configure(b"pf_attn_mfma", 1)
+            hiplib.calm_hip_configure(b"pf_forms", 0)
         lv = v.forward(toks[-1], 333, 0).copy()
         assert rel_err(lv, lo) < logit_tol(kvbits), rel_err(lv, lo)  # (lo: the oracle with THIS cache format, fp8-KV mode included)
         if kvbits == 16:
@@ -1016,7 +1011,7 @@ def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
     of the long chunk runs in the wide form (k_pf_gemm_wide: B staged through LDS, no K split) -- the FFN-up and the classifier of the dense fp8 / gf4 models in
     the big form (k_pf_gemm_big: 512 units x 128 tokens per workgroup), as is the FFN-down with K cut into ranges -- a short chunk in the
     K-split form.  Against serial
-    ingestion on the same backend, against the K-split form alone (calm_hip_configure("pf_wide", 0) and ("pf_big", 0)), and the
+    ingestion on the same backend, against the K-split form alone (calm_hip_configure("pf_forms", 1)), and the
     scored log-probabilities of both against each other."""
     spec = cf.SPECS[name]
     tensors, md = cf.synth_model_big(spec, dtype, seed=10, n_layers=1)
@@ -1031,19 +1026,17 @@ def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
         for pos, tok in enumerate(toks[:n]):
             serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         ls = serial.forward(toks[n], n, 0).copy()
-        assert hiplib.calm_hip_configure(b"pf_wide", -1) == 1
+        assert hiplib.calm_hip_configure(b"pf_forms", -1) == 0
         wide.prefill(toks[:n], 0)
         lw = wide.forward(toks[n], n, 0).copy()
         lpw = wide.prefill_logprobs(toks[: n + 1], 0)
-        hiplib.calm_hip_configure(b"pf_wide", 0)
-        assert hiplib.calm_hip_configure(b"pf_big", 0) == 1
+        hiplib.calm_hip_configure(b"pf_forms", 1)
         try:
             ksplit.prefill(toks[:n], 0)
             lk = ksplit.forward(toks[n], n, 0).copy()
             lpk = ksplit.prefill_logprobs(toks[: n + 1], 0)
         finally:
-            hiplib.calm_hip_configure(b"pf_wide", 1)
-            hiplib.calm_hip_configure(b"pf_big", 1)
+            hiplib.calm_hip_configure(b"pf_forms", 0)
         assert rel_err(lw, ls) < 2e-4, rel_err(lw, ls)
         assert rel_err(lk, ls) < 2e-4, rel_err(lk, ls)
         assert np.isfinite(lpw).all() and np.abs(lpw - lpk).max() < 2e-3 * max(1.0, float(np.abs(lpk).max()))
@@ -1060,7 +1053,7 @@ def test_prefill_mixture_chunks_of_2048_tokens_and_128_row_expert_groups(hiplib,
     """Round 5: a mixture-of-experts chunk holds up to 4096 tokens (k_pf_route: four tokens per thread, packed in token order) and, for
     fp8 / gf4 weights, pads every expert's rows to whole 128-row columns so that the grouped GEMMs run in the big form (k_pf_gemm_big,
     FFN-down in ranges of K).  A 3000-token prompt as ONE chunk in that form, against the same prompt (a) in 64-row groups through the
-    wide / K-split forms ("pf_moe_big" 0), (b) in chunks of 1024 + 1024 + 952 ("pf_chunk_moe" 1024): fp32-rounding apart; the scored
+    wide / K-split forms ("pf_forms" 4), (b) in chunks of 1024 + 1024 + 952 ("pf_chunk_moe" 1024): fp32-rounding apart; the scored
     log-probabilities likewise; and the logits behind the prompt against the oracle.  (fp16 weights keep 64-row groups: same checks.)"""
     spec = cf.tiny_spec("pfmoe", max_seq_len=3072, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=400, n_layers=2,
                         n_experts=experts, n_experts_active=active)
@@ -1083,7 +1076,7 @@ def test_prefill_mixture_chunks_of_2048_tokens_and_128_row_expert_groups(hiplib,
                 hiplib.calm_hip_configure(k, v)
 
     l_big, lp_big = run({})
-    l_small, lp_small = run({b"pf_moe_big": 0})
+    l_small, lp_small = run({b"pf_forms": 4})
     l_two, lp_two = run({b"pf_chunk_moe": 1024})
     assert np.isfinite(l_big).all() and np.isfinite(lp_big).all()
     assert rel_err(l_big, l_small) < 2e-4, rel_err(l_big, l_small)

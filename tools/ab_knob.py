@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B of a launch-shaping knob of the library (calm_hip_configure(key, v); KNOB_VALUES=0,1 by default) on a layer-reduced BASELINE
 shape: per-stage timings, tok/s over 256 greedy tokens, identical tokens.
-    python tools/ab_knob.py <knob> [model] [dtype] [layers]      e.g.  bpc mistral-7b fp8 8"""
+    python tools/ab_knob.py <knob> [model] [dtype] [layers]      e.g.  qkv_attn mistral-7b fp8 8"""
 import os
 import sys
 import time

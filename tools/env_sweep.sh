@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 run() { # label, env assignments...
   local label="$1"; shift
   echo "== $label" >> $OUT/sweep.txt
-  ( env "$@" timeout 120 python tools/tune.py mistral-7b fp8 8 brief 2>&1 | grep -E "graph=|bpc=" ) >> $OUT/sweep.txt
+  ( env "$@" timeout 120 python tools/tune.py mistral-7b fp8 8 brief 2>&1 | grep -E "graph=|GB/s" ) >> $OUT/sweep.txt
 }
 : > $OUT/sweep.txt
 run "default" A=1

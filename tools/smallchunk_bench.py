@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Prompt ingestion in chunks of 3 .. 16 tokens (prefill_hip called with n tokens at a time) on a layer-reduced BASELINE shape:
-us per chunk and per layer with k_pf_skinny (chunks up to 8 tokens) and with the GEMM forms (knob pf_skinny = 0), against n serial
+us per chunk and per layer with k_pf_skinny (chunks up to 8 tokens) and with the GEMM forms (knob pf_forms = 32), against n serial
 decode steps.  usage: smallchunk_bench.py [model] [dtype] [layers]"""
 import os
 import sys
@@ -33,7 +33,7 @@ print(f"{name} {dtype} L={L}: one serial decode step {serial*1e6:7.1f} us = {ser
 for n in (3, 4, 5, 8, 12, 16):
     row = []
     for knob in (1, 0):
-        be.lib.calm_hip_configure(b"pf_skinny", knob)
+        be.lib.calm_hip_configure(b"pf_forms", 0 if knob else 32)
         be.prefill(toks[:n], 200)
         reps = 40
         t0 = time.perf_counter()
@@ -41,6 +41,6 @@ for n in (3, 4, 5, 8, 12, 16):
             be.prefill(toks[r : r + n], 200 + n * (r % 8))
         dt = (time.perf_counter() - t0) / reps
         row.append(f"{'skinny' if knob else 'GEMMs '}: {dt*1e6:8.1f} us per chunk = {dt/L*1e6:7.2f} us per layer")
-    be.lib.calm_hip_configure(b"pf_skinny", 1)
+    be.lib.calm_hip_configure(b"pf_forms", 0)
     print(f"chunk of {n:2d} tokens: " + " | ".join(row) + f" | {n} serial steps {n*serial/L*1e6:7.2f} us per layer", flush=True)
 be.close()

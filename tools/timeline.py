@@ -72,7 +72,7 @@ for i, st in enumerate(STAGES):
     buf = np.zeros((waves, 8), dtype=np.uint64)
     lib.calm_tl_read(buf.ctypes.data, waves)
     t = buf.astype(np.int64) * 10
-    if st == "qkv" and lib.calm_hip_configure(b"qkv_attn", -1) == 1:
+    if st == "qkv" and lib.calm_hip_configure(b"qkv_attn", -1) >= 1:
         # k_qkv_attn: the first n_heads workgroups are the attention role -- entry / q here / old positions folded in, past the barrier /
         # this token's k, v rows here / exit; the row engine's stamps follow below
         na = spec.n_heads * 4
@@ -87,6 +87,11 @@ for i, st in enumerate(STAGES):
                     w = (t[4 * h:4 * h + 4] - t0) / 1e3
                     print(f"   wg {h:2d}: q here " + " ".join(f"{x:5.2f}" for x in w[:, 1]) + " | folded " + " ".join(f"{x:5.2f}" for x in w[:, 5]) + f" | barrier {w[0, 2]:5.2f} | kv {w[0, 4]:5.2f} | exit {w[0, 3]:5.2f}")
         t[:na] = 0
+        wo = t[t[:, 7] > 0]
+        if len(wo):  # k_qkv_attn WO: the row engine's waves go on to the output projection
+            c = lambda k: (wo[:, k] - t0) / 1e3
+            f = lambda k: f"{np.percentile(c(k), 10):5.2f} / {float(np.median(c(k))):5.2f} / {c(k).max():5.2f}"
+            print(f"{'qkv:wo':9s} {'':9s} {len(wo):6d} | rows of wo asked for {f(4)} | every flag up {f(5)} | image built {f(6)} | exit {f(7)}   (p10 / p50 / max)")
     a = t[t[:, 3] > 0]
     t0 = a[:, 0].min()
     ex = (a[:, 3] - t0) / 1e3

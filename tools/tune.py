@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stage-time sweep on the GPU box: a Mistral-7B-shaped model cut to 8 layers (1.7 GB of layer weights,
-far beyond the 256 MiB Infinity Cache), per-stage event timings for a few grid caps."""
+far beyond the 256 MiB Infinity Cache), per-stage event timings."""
 import os
 import sys
 import time
@@ -17,7 +17,7 @@ L = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 brief = len(sys.argv) > 4
 spec = cf.SPECS.get(name) or cf.ARCH_SPECS[name]
 lib = load_lib()
-for kv_ in os.environ.get("KNOBS", "").split():  # e.g. KNOBS="down_u4=0 attn_waves=8"
+for kv_ in os.environ.get("KNOBS", "").split():  # e.g. KNOBS="forms=1 qkv_attn=0"
     key, val = kv_.split("=")
     assert lib.calm_hip_configure(key.encode(), int(val)) >= 0, key
 model = HostModel(cf.stub_tensors(spec, dtype, L), cf.dataclasses.replace(spec, n_layers=L).metadata(dtype))
@@ -25,14 +25,11 @@ be = HipBackend(model, stream=cf.synth_stream_big(spec, dtype, 1, L))
 for kv in ((256,) if brief else (128, 256)):
     generate(be, model, [17], kv)
     print(f"== {name} {dtype} L={L} kv_len={kv}")
-    for bpc in (tuple(int(b) for b in os.environ["BPCS"].split()) if os.environ.get("BPCS") else ((0,) if brief else (1, 2, 3, 4))):
-        lib.calm_hip_configure(b"bpc", bpc)
-        row = []
-        for i, st in enumerate(STAGES):
-            us, b = be.stage_us(i, 6 if i != 5 else 2)
-            row.append(f"{st} {us:6.2f}us {b/us/1e3:6.0f}GB/s")
-        print(f"bpc={bpc}: " + " | ".join(row), flush=True)
-    lib.calm_hip_configure(b"bpc", 0)
+    row = []
+    for i, st in enumerate(STAGES):
+        us, b = be.stage_us(i, 6 if i != 5 else 2)
+        row.append(f"{st} {us:6.2f}us {b/us/1e3:6.0f}GB/s")
+    print(" | ".join(row), flush=True)
 if not brief or os.environ.get("LONGCTX"):
     # long context: the last 32 positions of a 4096 window (the reference README's "last 32" column)
     generate(be, model, [17], 8, pos_offset=4000)
@@ -49,8 +46,6 @@ if not brief or os.environ.get("LONGCTX"):
         dt = time.perf_counter() - t0
         print(f"   split_t={st_:4d}: attn stage {us:6.2f}us {b/us/1e3:6.0f}GB/s; last-32 {32/dt:8.1f} tok/s")
         lib.calm_hip_configure(b"split_t", old)
-if os.environ.get("BPC"):
-    lib.calm_hip_configure(b"bpc", int(os.environ["BPC"]))
 for graph in ((1,) if brief else (1, 0)):
     lib.calm_hip_configure(b"graph", graph)
     generate(be, model, [17], 16)
