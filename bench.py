@@ -386,6 +386,9 @@ def main():
             if k.startswith("k_ffn_up<") and args.pipeline <= 1:
                 gbps = dom["bytes"] / v["avg_us"] / 1e3
                 rocprof = {"us_per_launch": round(v["avg_us"], 2), "achieved": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBPS, 4), "calls": v["calls"],
+                           # (the timed region above replays hipGraphs; rocprofv3 7.2 crashes on this library's long replays, so the trace is of
+                           # eager launches of the same kernels, grids and arguments -- a kernel's own duration does not depend on that)
+                           "launch_mode": (ks.get("_launch_mode") or "hipGraph replay").split(":")[0],
                            "source": f"profiles/{os.path.basename(ks_file)} (rocprofv3 --kernel-trace of the bench command, same kernel sources"
                                      + (f"; {ks['_launch_mode'].split(':')[0]}" if ks.get("_launch_mode") else "") + ")"}
         break

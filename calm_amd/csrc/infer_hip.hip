@@ -1183,7 +1183,10 @@ void pf_alloc(Ctx* c) {
 		return p;
 	};
 	// a mixture-of-experts chunk packs (token, expert) pairs into 64-row columns, one group per expert
+	// (no chunk is longer than the context window -- a chunk never wraps the rolling buffer -- so a short window bounds the scratch: the
+	// experts' gathered rows take chunk x active experts x (dim + hidden_dim) x 4 bytes, 1.7 GB for DBRX-132B at 4096 tokens)
 	c->pf_nt = c->n_experts > 0 ? g_pf_chunk_moe : g_pf_chunk;
+	c->pf_nt = std::min(c->pf_nt, std::max(PF_NT, (c->seq_len + 127) / 128 * 128));
 	const int NT = c->pf_nt;
 	// (worst case: every expert's group padded to a whole 128-row column pair -- k_pf_route gran 2 -- and the count even)
 	c->pf_max_cols = c->n_experts > 0 ? ((NT * c->n_active + 63) / 64 + 2 * c->n_experts + 1) / 2 * 2 : 0;
@@ -1464,7 +1467,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	a.clip = p->qkv_clip, a.gelu = p->act_gelu;
 	for (int l = 0; l < c->n_layers; ++l) {
 		// attention norm; q / k / v + bias + clip + RoPE + KV append   (src/infer.c:352-381)
-		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_att_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
+		hipLaunchKernelGGL(k_pf_norm, pf_norm_grid(nb, c->dim, g_ncu), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_att_weight[l], c->dim, p->norm_eps, (int)p->norm_ln, nb);
 		a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->q_dim + 2 * c->kv_dim;
 		a.w0 = w->wq[l], a.w1 = w->wk[l], a.w2 = w->wv[l], a.bqkv = w->bqkv[l];
 		a.out = c->pf_q;
@@ -1478,7 +1481,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		gemm(a, EpiResid(), cols);
 		// FFN   (src/infer.c:417-457); parallel-residual models reuse the attention norm's output
 		if (!p->norm_par) {
-			hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln);
+			hipLaunchKernelGGL(k_pf_norm, pf_norm_grid(nb, c->dim, g_ncu), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_ffn_weight[l], c->dim, p->norm_eps, (int)p->norm_ln, nb);
 		}
 		if (c->n_experts == 0) {
 			a.xin = (const float4*)c->pf_xn, a.K = c->dim, a.M = c->hidden, a.w0 = w->w1[l], a.w1 = w->w3[l], a.out = c->pf_h;
@@ -1508,7 +1511,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 	}
 	if (score) {
 		// final norm + classifier for every token of the chunk (src/infer.c:465-469), then log softmax of the target
-		hipLaunchKernelGGL(k_pf_norm, dim3(nb), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_final_weight, c->dim, p->norm_eps, (int)p->norm_ln);
+		hipLaunchKernelGGL(k_pf_norm, pf_norm_grid(nb, c->dim, g_ncu), block, 0, g_stream, (float4*)c->pf_xn, c->pf_x, w->rms_final_weight, c->dim, p->norm_eps, (int)p->norm_ln, nb);
 		// in blocks of pf_score_nt tokens (whole 128-token columns: a block of the fragment-major matrix starts at a 32-token group), so
 		// that the logits scratch stays bounded for 128k / 256k vocabularies
 		a.K = c->dim, a.M = c->vocab, a.w0 = w->wcls, a.out = c->pf_logits;

@@ -125,43 +125,81 @@ __global__ void k_pf_begin(const int* tokens, int pos0, float* X, const void* em
 	}
 }
 
-// out (fragment-major) = norm(X[b][:]) * normw, one workgroup per token   (src/infer.c:183-207)
-__global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, const float* normw, int n, float eps, int ln) {
-	__shared__ float red[16];
-	const int b = blockIdx.x;
-	const float4* x4 = (const float4*)(X + (size_t)b * n);
-	const float4* w4 = (const float4*)normw;
+// out (fragment-major) = norm(X[t][:]) * normw   (src/infer.c:183-207)
+// A workgroup takes EIGHT consecutive tokens (blockIdx.x) and one of gridDim.y column slices: a 128-byte line of the fragment-major
+// matrix is the same 8 columns of 8 consecutive tokens (pf_unit: the token is the lane), so one workgroup writes whole lines -- with
+// one token per workgroup (rounds 1-5) every line was put together in the L2 out of eight workgroups' 16-byte pieces: 34.5 us for
+// the 2048 x 4096 matrix, 67 MB moved at 1.9 TB/s.  Pass 1: every wave reduces two of the tokens' rows (whole rows, whatever the
+// slice: the column slices of a token group recompute it -- reads out of the L2); pass 2: thread = (token, block of 8 columns).
+// grid = (ceil(nb / 8), slices), 256 threads; n % 32 == 0
+__global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, const float* normw, int n, float eps, int ln, int nb) {
+	__shared__ float sm_mean[8], sm_scale[8];
+	const int t0 = blockIdx.x * 8, lane = lane_id(), wave = wave_id();
 	const int n4 = n >> 2;
-	float mean = 0.f;
-	if (ln) {
-		float s = 0.f;
-		for (int i = threadIdx.x; i < n4; i += 256) {
-			float4 t = x4[i];
-			s += (t.x + t.y) + (t.z + t.w);
+#pragma unroll
+	for (int h = 0; h < 2; ++h) {
+		const int tl = 2 * wave + h, t = min(t0 + tl, nb - 1);
+		const float4* x4 = (const float4*)(X + (size_t)t * n);
+		float mean = 0.f;
+		if (ln) {
+			float s = 0.f;
+			for (int i = lane; i < n4; i += 64) {
+				const float4 v = x4[i];
+				s += (v.x + v.y) + (v.z + v.w);
+			}
+			mean = wave_sum(s) / (float)n;
 		}
-		mean = block_sum<256>(s, red) / (float)n;
+		float ss0 = 0.f, ss1 = 0.f, ss2 = 0.f, ss3 = 0.f; // four loads in flight per lane
+		int i = lane;
+		for (; i + 192 < n4; i += 256) {
+			const float4 a = x4[i], b = x4[i + 64], c = x4[i + 128], d = x4[i + 192];
+			ss0 += ((a.x - mean) * (a.x - mean) + (a.y - mean) * (a.y - mean)) + ((a.z - mean) * (a.z - mean) + (a.w - mean) * (a.w - mean));
+			ss1 += ((b.x - mean) * (b.x - mean) + (b.y - mean) * (b.y - mean)) + ((b.z - mean) * (b.z - mean) + (b.w - mean) * (b.w - mean));
+			ss2 += ((c.x - mean) * (c.x - mean) + (c.y - mean) * (c.y - mean)) + ((c.z - mean) * (c.z - mean) + (c.w - mean) * (c.w - mean));
+			ss3 += ((d.x - mean) * (d.x - mean) + (d.y - mean) * (d.y - mean)) + ((d.z - mean) * (d.z - mean) + (d.w - mean) * (d.w - mean));
+		}
+		for (; i < n4; i += 64) {
+			const float4 a = x4[i];
+			ss0 += ((a.x - mean) * (a.x - mean) + (a.y - mean) * (a.y - mean)) + ((a.z - mean) * (a.z - mean) + (a.w - mean) * (a.w - mean));
+		}
+		const float var = wave_sum((ss0 + ss1) + (ss2 + ss3)) / (float)n;
+		if (lane == 0) {
+			sm_mean[tl] = mean;
+			sm_scale[tl] = 1.0f / sqrtf(var + eps);
+		}
 	}
-	float ss = 0.f;
-	for (int i = threadIdx.x; i < n4; i += 256) {
-		float4 t = x4[i];
-		float a = t.x - mean, c = t.y - mean, d = t.z - mean, e = t.w - mean;
-		ss += (a * a + c * c) + (d * d + e * e);
-	}
-	float var = block_sum<256>(ss, red) / (float)n;
-	float scale = 1.0f / sqrtf(var + eps);
-	const int nsteps = pf_steps(n);
-	for (int i = threadIdx.x; i < (n >> 3); i += 256) { // n is a multiple of 32
+	__syncthreads();
+	const int tl = threadIdx.x & 7, t = t0 + tl;
+	const float mean = sm_mean[tl], scale = sm_scale[tl];
+	const float4* x4 = (const float4*)(X + (size_t)min(t, nb - 1) * n);
+	const float4* w4 = (const float4*)normw;
+	const int nsteps = pf_steps(n), nkb = n >> 3;
+	const int per = (nkb + (int)gridDim.y - 1) / (int)gridDim.y;
+	const int kb1 = min(nkb, ((int)blockIdx.y + 1) * per);
+	for (int kb = (int)blockIdx.y * per + (int)(threadIdx.x >> 3); kb < kb1; kb += 32) {
 		float v[8];
 #pragma unroll
 		for (int h = 0; h < 2; ++h) {
-			const float4 t = x4[2 * i + h], g = w4[2 * i + h];
-			v[4 * h] = (t.x - mean) * scale * g.x;
-			v[4 * h + 1] = (t.y - mean) * scale * g.y;
-			v[4 * h + 2] = (t.z - mean) * scale * g.z;
-			v[4 * h + 3] = (t.w - mean) * scale * g.w;
+			const float4 a = x4[2 * kb + h], g = w4[2 * kb + h];
+			v[4 * h] = (a.x - mean) * scale * g.x;
+			v[4 * h + 1] = (a.y - mean) * scale * g.y;
+			v[4 * h + 2] = (a.z - mean) * scale * g.z;
+			v[4 * h + 3] = (a.w - mean) * scale * g.w;
 		}
-		pf_store8(out, b, 8 * i, nsteps, v);
+		if (t < nb) {
+			pf_store8(out, t, 8 * kb, nsteps, v);
+		}
 	}
+}
+// its grid: 8-token groups x as many column slices as bring the grid to two workgroups per CU (at most 8, at least 64 columns each)
+inline dim3 pf_norm_grid(int nb, int n, int ncu) {
+	const int groups = (nb + 7) / 8;
+	int slices = (2 * ncu + groups - 1) / groups;
+	slices = slices > 8 ? 8 : slices;
+	while (slices > 1 && (n >> 3) / slices < 8) {
+		--slices;
+	}
+	return dim3(groups, slices < 1 ? 1 : slices);
 }
 
 // Mixture-of-experts routing of a chunk (src/infer.c:277-305 per token): top-k by logit, first maximum wins
@@ -175,7 +213,7 @@ __global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, cons
 // token order (deterministic): a token's place in its expert's group is the number of earlier tokens routed to that expert -- a
 // ballot per expert within the wave plus the counts of the (pass, wave) pairs before it (a token routes to an expert at most once).
 constexpr int PF_ROUTE_TPT = 4;                 // tokens per thread of k_pf_route
-constexpr int PF_NT_MOE = PF_ROUTE_TPT * PF_NT; // the most a mixture-of-experts model's chunk is (knob "pf_chunk_moe"; default 2048)
+constexpr int PF_NT_MOE = PF_ROUTE_TPT * PF_NT; // the most a mixture-of-experts model's chunk is (knob "pf_chunk_moe", which it is the default of)
 __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, int n_experts, int n_active, int max_cols, int gran, int* rows, int* col_expert, int* slot,
                                                     float* wsel) {
 	constexpr int NW = PF_NT / 64, TPT = PF_ROUTE_TPT;
@@ -291,7 +329,7 @@ __global__ __launch_bounds__(PF_NT) void k_pf_route(const float* gate, int nb, i
 	}
 }
 
-// packed row r (fragment-major) = row rows[r] of src; padding rows keep whatever they held (finite).
+// packed row r (fragment-major) = row rows[r] of src; padding rows (rows[r] < 0) are zero-filled.
 // A wave writes whole 1 KiB blocks of the destination ([32-row group][step][MFMA][hi, lo][lane]: 64 consecutive units) and
 // fetches, per lane, the unit of its row's source token from the L2-resident source matrix.
 // grid = (row groups of 32, ceil(nsteps / 8)), 256 threads
@@ -302,13 +340,13 @@ __global__ __launch_bounds__(256) void k_pf_gather(float4* dst, const float4* sr
 	}
 	const int t = rows[32 * g + (lane & 31)], nsteps = pf_steps(n);
 	const int s0 = blockIdx.y * 8, s1 = min(s0 + 8, nsteps);
-	if (t < 0) {
-		return;
-	}
-	const float4* sp = src + (size_t)(t >> 5) * nsteps * 512 + (lane & 32) + (t & 31);
+	const int ts = t < 0 ? 0 : t; // a padding row is written as zeros: whatever a longer chunk left there went through the FFN-up's
+	                              // epilogue and could raise the range flag (a serial redo for nothing)
+	const float4* sp = src + (size_t)(ts >> 5) * nsteps * 512 + (lane & 32) + (ts & 31);
 	float4* dp = dst + (size_t)g * nsteps * 512 + lane;
 	for (int b = s0 * 8 + wave; b < s1 * 8; b += 4) { // block b: step b / 8, (MFMA, hi / lo) b % 8
-		dp[(size_t)b * 64] = sp[(size_t)b * 64];
+		const float4 v = sp[(size_t)b * 64];
+		dp[(size_t)b * 64] = t < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : v;
 	}
 }
 

@@ -1048,19 +1048,19 @@ def test_prefill_long_prompt_takes_the_wide_gemm_form(hiplib, name, dtype):
         ksplit.close()
 
 
-@pytest.mark.parametrize("dtype,experts,active", [("fp8", 6, 2), ("gf4", 4, 3), ("fp16", 5, 2)])
-def test_prefill_mixture_chunks_of_2048_tokens_and_128_row_expert_groups(hiplib, dtype, experts, active):
+@pytest.mark.parametrize("dtype,experts,active,n", [("fp8", 6, 2, 3000), ("gf4", 4, 3, 3000), ("fp16", 5, 2, 3000), ("fp8", 6, 2, 4300)])
+def test_prefill_mixture_chunks_of_4096_tokens_and_128_row_expert_groups(hiplib, dtype, experts, active, n):
     """Round 5: a mixture-of-experts chunk holds up to 4096 tokens (k_pf_route: four tokens per thread, packed in token order) and, for
     fp8 / gf4 weights, pads every expert's rows to whole 128-row columns so that the grouped GEMMs run in the big form (k_pf_gemm_big,
     FFN-down in ranges of K).  A 3000-token prompt as ONE chunk in that form, against the same prompt (a) in 64-row groups through the
     wide / K-split forms ("pf_forms" 4), (b) in chunks of 1024 + 1024 + 952 ("pf_chunk_moe" 1024): fp32-rounding apart; the scored
-    log-probabilities likewise; and the logits behind the prompt against the oracle.  (fp16 weights keep 64-row groups: same checks.)"""
-    spec = cf.tiny_spec("pfmoe", max_seq_len=3072, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=400, n_layers=2,
-                        n_experts=experts, n_experts_active=active)
+    log-probabilities likewise; and the logits behind the prompt against the oracle.  (fp16 weights keep 64-row groups: same checks.)
+    The 4300-token prompt is one FULL 4096-token chunk (k_pf_route's fourth pass, every scratch buffer at its bound) and a remainder."""
+    spec = cf.tiny_spec("pfmoe", max_seq_len=3072 if n < 3072 else 4352, dim=128, hidden_dim=352, n_heads=4, n_kv_heads=2, head_dim=32, vocab_size=400,
+                        n_layers=2, n_experts=experts, n_experts_active=active)
     tensors, md = cf.synth_model(spec, dtype, seed=41)
     model = HostModel(tensors, md)
     rng = np.random.default_rng(14)
-    n = 3000
     toks = [int(t) for t in rng.integers(0, 400, size=n + 1)]
 
     def run(knobs):

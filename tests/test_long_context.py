@@ -40,12 +40,16 @@ def test_fp8_kv_cache_matches_the_oracle(hiplib, case):
     o = oracle.OracleBackend(model, kvbits=8)
     b = HipBackend(model, kvbits=8)
     try:
-        worst = 0.0
+        errs = []
         for pos, tok in enumerate(toks):
             lo = o.forward(tok, pos, 0)
             lg = b.forward(tok, pos, 0)
-            worst = max(worst, rel_err(lg, lo))
+            errs.append(rel_err(lg, lo))
+        worst = max(errs)
         assert worst < FP8KV_TOL, worst
+        # ... which bounds the rare position where a cached code flipped; the TYPICAL position answers to the common tolerance (a
+        # systematic error of the e5m2 path at the 3e-3 level would pass the line above and fail this one)
+        assert float(np.median(errs)) < LOGIT_TOL, float(np.median(errs))
         c = model.config
         n = min(len(toks), c.seq_len)
         for layer in range(c.n_layers):
