@@ -2633,7 +2633,8 @@ __global__ __launch_bounds__(BLOCK) void k_ffn_down(float* x, const float* he, c
 	// the chip has waves (TinyLlama's 2048 rows: 7.9 -> 6.6 us)
 	// (Round 4: every task split along K between an older and a younger wave of the workgroup -- 8 + 6 of Mistral-7B's 14 chunks, the partial sums
 	// handed over through LDS: the older four waves of a workgroup leave 0.8-1.1 us before the younger four -- 12.18 -> 12.0 us, gf4 unchanged:
-	// profiles/r04_startup.txt; not kept.)
+	// profiles/r04_startup.txt; not kept.  Round 6: s_setprio 1 / 3 for the younger four, and for k_ffn_up's later-dispatched workgroups:
+	// 11.8 -> 11.8-12.0 us, k_ffn_up 19.3 -> 20.1, the token 0.9-1.5 % slower -- profiles/r06_gf4.txt.)
 	// (Round 4: ONE row x 11 chunks for DBRX's ragged 10.5-KiB rows -- one exact step instead of 4 + 4 + 3 and a clamped surplus load --
 	// measured 51 us against 49: profiles/r04_moe.txt.)
 	// SEG: UO = chunks per step (1 / 2 / 4: the largest that divides a segment's chunk count -- a segment is walked in whole steps)
