@@ -1399,7 +1399,9 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		int ks = 1; // 0: the K-split form
 		if ((long)nx * ncols * 8 < (long)g_ncu * 5) {
 			ks = 0;
-			if (nsteps >= 80 || epi == PF_EPI_FFN_UP || nx * ncols * 2 >= g_ncu) {
+			// (round 6: also from three token columns whatever the row length -- the QKV / wo GEMMs of 129-448 token prompts: Mistral-7B
+			// 256 tokens 20.2 -> 21.5 k tok/s, 384 tokens 20.1 -> 21.1; at 64 tokens the K-split form stays ahead by 6 %, at 128 they tie)
+			if (nsteps >= 80 || epi == PF_EPI_FFN_UP || nx * ncols * 2 >= g_ncu || ncols >= 3) {
 				int k = g_ncu / (nx * ncols);
 				k = k > 8 ? 8 : k;
 				k = k > nsteps / 16 ? nsteps / 16 : k;
@@ -1413,7 +1415,8 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 			// rounds finer: 2 or 4 where the model below says that saves more than the fold costs (~3 % per range).  A last round that fills
 			// at most half the slots leaves one workgroup per CU, which runs at ~0.6 of a full round's time, not 0.5 (hence nothing for the
 			// QKV GEMM's 1.5 rounds at 2048 tokens: measured 32.0 against 32.4 k tok/s with it split); a grid under one round gains nothing
-			// from ranges at all (TinyLlama's FFN-down: - 5 %).  profiles/r04_prefill.txt.
+			// from ranges at all (TinyLlama's FFN-down: - 5 %; round 6: the FFN-up of a 128-token prompt, 0.44 rounds, in two ranges: 88.7 -> 89.7 us --
+			// a workgroup's step costs the CU the same whoever shares it).  profiles/r04_prefill.txt, r06_prefill.txt.
 			const double r1 = (double)nx * ncols / (2.0 * g_ncu);
 			double best = rounds_cost(r1);
 			for (int k = 2; k <= 4 && r1 > 1.0; k *= 2) {
