@@ -232,6 +232,9 @@ def main():
         if args.dry_run:
             dist_.init_process_group("gloo")
         else:
+            from calm_amd.host import require_torch_first
+
+            require_torch_first("bench.py --gpus N")  # torch's bundled HIP runtime first, libcalm_hip.so's after
             torch.cuda.set_device(local_rank)
             dist_.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         dist = dist_

@@ -1348,7 +1348,7 @@ void prefill_chunk(Ctx* c, int nb, int pos0, bool score, bool embed) {
 		// The big form (prefill.hip.h k_pf_gemm_big: 512 units x 128 tokens per 8-wave workgroup, one per CU) for the GEMMs with enough
 		// units to fill the chip with such tiles -- the FFN-up and the classifier of a dense model from ~384 tokens: ahead of the wide
 		// form from 5/8 of the CUs covered (+6...20 %), behind below that (tools/experiments/exp_pfgemm_big.hip, profiles/r04_prefill.txt).
-		// fp8 / gf4 weights.  Knob "pf_big": 0 off, 2 whatever the grid (tests), 3 without the residual GEMM's form (A/B).
+		// fp8 / gf4 weights.  ("pf_forms" 1: never, 2: whatever the grid -- the tests' switches.)
 		// The residual GEMM with long rows and few units (the FFN-down: 8 x 8 such tiles at 1024 tokens) takes it with K cut into 2-4 ranges,
 		// one workgroup each, while a range keeps >= 48 steps (316 -> us at 1024 tokens).
 		if constexpr ((epi == PF_EPI_FFN_UP || epi == PF_EPI_STORE || epi == PF_EPI_RESID) && DB != 16) {

@@ -860,8 +860,8 @@ __device__ __forceinline__ void stage_first_barrier() {
 //     48.9, 45.2, 44.2, 47.2.
 //     Round 4: with the activations in registers (XREG) no row shares an image read any more and 2 x 2 -- 14 rounds of tasks, so the skewed
 //     deal applies -- is k_ffn_up's best: 4x1 13.70, 2x1 14.15, 2x2 13.43 us (profiles/r04_gf4.txt).
-// Task ranges of a wave when the grid is two workgroups per CU and the FIRST-dispatched one is given more tasks (`cut` > 0; knob
-// "skew"): a CU's older workgroup wins its memory queue and used to leave 2-3 us before the younger one, whose waves then ran the
+// Task ranges of a wave when the grid is two workgroups per CU and the FIRST-dispatched one is given more tasks (`cut` > 0:
+// SKEW_PERCENT in infer_hip.hip; "forms" 1: even deal): a CU's older workgroup wins its memory queue and used to leave 2-3 us before the younger one, whose waves then ran the
 // kernel's tail alone at half the bytes in flight (profiles/r02_kernel_timeline.txt).  Blocks [0, G/2) deal tasks [0, cut) among
 // their waves, blocks [G/2, G) tasks [cut, ntasks).  Placement-independent: another dispatch order only changes who finishes when.
 struct TaskRange {
@@ -880,7 +880,7 @@ __device__ __forceinline__ TaskRange task_range(int ntasks, int waves_per_block,
 }
 
 enum KernelId { KS_QKV, KS_ATTN_OUT, KS_FFN_UP, KS_FFN_DOWN, KS_OUTPUT };
-// XREG kernels (knob "xreg"): the launcher picks them where the input vector has exactly 4096 columns at fp8 (rows of 4 chunks) or at
+// XREG kernels ("forms" 1 turns them off): the launcher picks them where the input vector has exactly 4096 columns at fp8 (rows of 4 chunks) or at
 // gf4 (2 chunks), 2048 at fp16 (4 chunks) -- the BASELINE models' dim -- and every lane keeps its float4s of the image in registers
 // (run_rows_impl XR: 64-72 VGPRs at fp8 / gf4, 32 at fp16)
 template <int DB, bool XREG>

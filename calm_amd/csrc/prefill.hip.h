@@ -129,48 +129,82 @@ __global__ void k_pf_begin(const int* tokens, int pos0, float* X, const void* em
 // A workgroup takes EIGHT consecutive tokens (blockIdx.x) and one of gridDim.y column slices: a 128-byte line of the fragment-major
 // matrix is the same 8 columns of 8 consecutive tokens (pf_unit: the token is the lane), so one workgroup writes whole lines -- with
 // one token per workgroup (rounds 1-5) every line was put together in the L2 out of eight workgroups' 16-byte pieces: 34.5 us for
-// the 2048 x 4096 matrix, 67 MB moved at 1.9 TB/s.  Pass 1: every wave reduces two of the tokens' rows (whole rows, whatever the
-// slice: the column slices of a token group recompute it -- reads out of the L2); pass 2: thread = (token, block of 8 columns).
+// the 2048 x 4096 matrix, 67 MB moved at 1.9 TB/s.  Pass 1: the rows' sums of squares, all threads on all eight rows (whole rows,
+// whatever the slice: the column slices of a token group recompute them -- reads out of the L2); pass 2: thread = (token, block of 8 columns).
 // grid = (ceil(nb / 8), slices), 256 threads; n % 32 == 0
 __global__ __launch_bounds__(256) void k_pf_norm(void* out, const float* X, const float* normw, int n, float eps, int ln, int nb) {
-	__shared__ float sm_mean[8], sm_scale[8];
+	__shared__ float sm_part[2][8][4], sm_mean[8];
 	const int t0 = blockIdx.x * 8, lane = lane_id(), wave = wave_id();
 	const int n4 = n >> 2;
+	// pass 1: all 256 threads on each of the eight rows (eight loads in flight per thread), the waves' sums through LDS
+	const float4* rows[8];
 #pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		const int tl = 2 * wave + h, t = min(t0 + tl, nb - 1);
-		const float4* x4 = (const float4*)(X + (size_t)t * n);
-		float mean = 0.f;
-		if (ln) {
-			float s = 0.f;
-			for (int i = lane; i < n4; i += 64) {
-				const float4 v = x4[i];
-				s += (v.x + v.y) + (v.z + v.w);
+	for (int tl = 0; tl < 8; ++tl) {
+		rows[tl] = (const float4*)(X + (size_t)min(t0 + tl, nb - 1) * n);
+	}
+	float mean8[8];
+#pragma unroll
+	for (int tl = 0; tl < 8; ++tl) {
+		mean8[tl] = 0.f;
+	}
+	if (ln) {
+		float s8[8];
+#pragma unroll
+		for (int tl = 0; tl < 8; ++tl) {
+			s8[tl] = 0.f;
+		}
+		for (int i = threadIdx.x; i < n4; i += 256) {
+#pragma unroll
+			for (int tl = 0; tl < 8; ++tl) {
+				const float4 v = rows[tl][i];
+				s8[tl] += (v.x + v.y) + (v.z + v.w);
 			}
-			mean = wave_sum(s) / (float)n;
 		}
-		float ss0 = 0.f, ss1 = 0.f, ss2 = 0.f, ss3 = 0.f; // four loads in flight per lane
-		int i = lane;
-		for (; i + 192 < n4; i += 256) {
-			const float4 a = x4[i], b = x4[i + 64], c = x4[i + 128], d = x4[i + 192];
-			ss0 += ((a.x - mean) * (a.x - mean) + (a.y - mean) * (a.y - mean)) + ((a.z - mean) * (a.z - mean) + (a.w - mean) * (a.w - mean));
-			ss1 += ((b.x - mean) * (b.x - mean) + (b.y - mean) * (b.y - mean)) + ((b.z - mean) * (b.z - mean) + (b.w - mean) * (b.w - mean));
-			ss2 += ((c.x - mean) * (c.x - mean) + (c.y - mean) * (c.y - mean)) + ((c.z - mean) * (c.z - mean) + (c.w - mean) * (c.w - mean));
-			ss3 += ((d.x - mean) * (d.x - mean) + (d.y - mean) * (d.y - mean)) + ((d.z - mean) * (d.z - mean) + (d.w - mean) * (d.w - mean));
+#pragma unroll
+		for (int tl = 0; tl < 8; ++tl) {
+			const float s = wave_sum(s8[tl]);
+			if (lane == 0) {
+				sm_part[0][tl][wave] = s;
+			}
 		}
-		for (; i < n4; i += 64) {
-			const float4 a = x4[i];
-			ss0 += ((a.x - mean) * (a.x - mean) + (a.y - mean) * (a.y - mean)) + ((a.z - mean) * (a.z - mean) + (a.w - mean) * (a.w - mean));
+		__syncthreads();
+#pragma unroll
+		for (int tl = 0; tl < 8; ++tl) {
+			mean8[tl] = ((sm_part[0][tl][0] + sm_part[0][tl][1]) + (sm_part[0][tl][2] + sm_part[0][tl][3])) / (float)n;
 		}
-		const float var = wave_sum((ss0 + ss1) + (ss2 + ss3)) / (float)n;
-		if (lane == 0) {
-			sm_mean[tl] = mean;
-			sm_scale[tl] = 1.0f / sqrtf(var + eps);
+	}
+	{
+		float s8[8];
+#pragma unroll
+		for (int tl = 0; tl < 8; ++tl) {
+			s8[tl] = 0.f;
+		}
+		for (int i = threadIdx.x; i < n4; i += 256) {
+#pragma unroll
+			for (int tl = 0; tl < 8; ++tl) {
+				const float4 v = rows[tl][i];
+				const float a = v.x - mean8[tl], b = v.y - mean8[tl], c = v.z - mean8[tl], d = v.w - mean8[tl];
+				s8[tl] += (a * a + b * b) + (c * c + d * d);
+			}
+		}
+#pragma unroll
+		for (int tl = 0; tl < 8; ++tl) {
+			const float s = wave_sum(s8[tl]);
+			if (lane == 0) {
+				sm_part[1][tl][wave] = s;
+			}
+		}
+		if (threadIdx.x == 0) { // (every thread holds all eight means)
+#pragma unroll
+			for (int tl = 0; tl < 8; ++tl) {
+				sm_mean[tl] = mean8[tl];
+			}
 		}
 	}
 	__syncthreads();
 	const int tl = threadIdx.x & 7, t = t0 + tl;
-	const float mean = sm_mean[tl], scale = sm_scale[tl];
+	const float var = ((sm_part[1][tl][0] + sm_part[1][tl][1]) + (sm_part[1][tl][2] + sm_part[1][tl][3])) / (float)n;
+	const float mean = sm_mean[tl], scale = 1.0f / sqrtf(var + eps);
 	const float4* x4 = (const float4*)(X + (size_t)min(t, nb - 1) * n);
 	const float4* w4 = (const float4*)normw;
 	const int nsteps = pf_steps(n), nkb = n >> 3;

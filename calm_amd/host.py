@@ -76,6 +76,21 @@ class _Libs:
         return getattr(self._test, name)
 
 
+def lib_loaded() -> bool:
+    """has libcalm_hip.so (and with it the system HIP runtime) been brought up in this process?"""
+    return _LIB is not None
+
+
+def require_torch_first(what: str = "torch.distributed over RCCL") -> None:
+    """A process that uses BOTH PyTorch-ROCm (for RCCL) and this library must initialise torch's device first: torch ships its own copy
+    of the HIP runtime, and when /opt/rocm's copy (which libcalm_hip.so links) has claimed the device before it, torch finds none
+    (profiles/r05_gpu_tests.txt section 2; the working order is exercised by tools/experiments/dist_probe.py, profiles/r06_dist_probe.txt).
+    Fails with a message instead of a missing device."""
+    if lib_loaded():
+        raise RuntimeError(f"{what}: initialise torch (torch.cuda.set_device + init_process_group) BEFORE the first calm_amd.host.load_lib() / "
+                           "HipBackend in this process -- libcalm_hip.so is already loaded (INTEGRATION.md section D)")
+
+
 def load_lib() -> "_Libs":
     """dlopen libcalm_hip.so and declare the prototypes of include/calm_hip.h; the hooks of calm_hip_test.h resolve through the
     same object from libcalm_hip_test.so"""

@@ -121,8 +121,9 @@ def main():
     import torch.distributed as dist
 
     from . import calmfile as cf
-    from .host import HipBackend
+    from .host import HipBackend, require_torch_first
 
+    require_torch_first("calm_amd.pipeline")  # (torch's device comes up below, before the first HipBackend)
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="dbrx-132b")
     ap.add_argument("--dtype", default="fp8")

@@ -26,10 +26,10 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-CALM_HIP_PROF_JSON=$OUT/kernel_bytes.json timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- "$@" > $OUT/trace.log 2>&1
+CALM_HIP_PROF_JSON=$OUT/kernel_bytes.json timeout 420 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- "$@" > $OUT/trace.log 2>&1
 echo "kernel trace: exit $?"
 if [ $PMC = 1 ]; then
-  timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc -o fetch -- "$@" > $OUT/pmc.log 2>&1
+  timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc -o fetch -- "$@" > $OUT/pmc.log 2>&1
   echo "FETCH_SIZE pass: exit $?"
   python $ROOT/tools/prof_summary.py $OUT/trace $OUT/pmc --tag $TAG --workload "$WORKLOAD" --bytes $OUT/kernel_bytes.json
 else
