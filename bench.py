@@ -460,14 +460,14 @@ def main():
     if args.pipeline > 1:
         # where the stages really sit, and what one hand-off of the residual stream costs: a few more steps with the library's
         # profiling on (an event pair around every stage-to-stage copy; perf_hip prints the same)
-        stage_devices = [int(be.lib.calm_hip_configure(b"stage_device", s_)) for s_ in range(be.lib.calm_hip_configure(b"stages", -1))]
+        stage_devices = [int(be.lib.calm_hip_query(b"stage_device", s_)) for s_ in range(be.lib.calm_hip_query(b"stages", 0))]
         be.lib.calm_hip_configure(b"prof", 1)
         tok = first_token
         for pos in range(8):
             tok = int(np.argmax(be.forward(tok, pos, 0)))
         be.lib.calm_hip_configure(b"prof", 0)
-        handoffs = int(be.lib.calm_hip_configure(b"handoffs", -1))
-        handoff_us = round(be.lib.calm_hip_configure(b"handoff_ns", -1) / 1e3, 2) if handoffs else None
+        handoffs = int(be.lib.calm_hip_query(b"handoffs", 0))
+        handoff_us = round(be.lib.calm_hip_query(b"handoff_ns", 0) / 1e3, 2) if handoffs else None
 
     out = {
         "metric": f"decode tok/s (batch=1, {args.steps} tok)",

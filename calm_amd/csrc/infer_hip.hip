@@ -78,21 +78,21 @@ std::map<const void*, size_t> g_pending_uploads;
 // ... unless the host says where it belongs first: calm_hip_configure("stage", s) routes the following upload_hip / alloc_hip
 // calls to stage s's device at once (-1: back to deferring) -- for hosts that know tensor names, or fill tensors on the device
 int g_alloc_stage = -1;
-double g_hop_us = 0; // time inside the stage-to-stage copies of profiled steps, and their number (perf_hip; knobs "handoff_ns" / "handoffs")
+double g_hop_us = 0; // time inside the stage-to-stage copies of profiled steps, and their number (perf_hip; calm_hip_query "handoff_ns" / "handoffs")
 uint64_t g_hop_n = 0;
 int g_use_graph = 1; // CALM_HIP_GRAPH=0 -> eager launches
 int g_prof = 0;      // CALM_HIP_PROF=1 -> eager + per-stage events
 int g_split_t = 128;   // kv positions per attention split up to 32 splits (two rounds of the 4-wave GQA kernel); twice that beyond
 int g_split_min = 384; // contexts up to this many positions use the unsplit one-workgroup-per-head kernel
 int g_attn_vt = 1;     // split attention (contexts beyond split_min) on the matrix cores over the transposed value cache where the head size is 128 (k_attn_vt); 0: k_attn_gqa
-int g_moe_route = 1;   // mixture-of-experts models: the router's logits from partial sums k_attn_out's epilogue leaves (k_ffn_up MOE == 2); 0: every
-                       // workgroup of k_ffn_up computes the gate from the vector before it asks for its first weight byte
 // "forms" (decode) and "pf_forms" (prompt ingestion): the launchers pick a kernel form per shape by rule; these two bit sets exist for the
 // tests that run EVERY shipping form on small fixtures and compare (0 = the rules).  No form here is an experiment: each is what some
 // BASELINE or public shape gets by rule.
 //   forms     1: plain forms -- input vector read from LDS at every step (not held in registers: other widths), k_ffn_up's rounds dealt
 //                evenly (no skew: other grids), one k_ffn_down pass per expert (not side by side: large experts)
 //             2: small-matrix forms always -- k_qkv tiles half as deep, k_attn_out / k_ffn_down one row per task (by rule: TinyLlama, DBRX)
+//             8: a mixture-of-experts layer's gate computed by every workgroup of k_ffn_up from the vector (MOE == 1; by rule: more
+//                than 64 experts, a parallel residual) instead of derived from the partial sums k_attn_out's epilogue leaves (MOE == 2)
 //   pf_forms  1: K-split GEMMs only (short prompts)          2: the big form for every dense FFN-up / classifier (long prompts)
 //             4: grouped (expert) GEMMs never in the big form   8: ... always           (by rule: from 64 packed rows per expert)
 //            16: lane-arithmetic prompt attention (head sizes other than 64 / 128)      32: no skinny chain for 3-4 token chunks
@@ -102,7 +102,7 @@ inline int knob_small() { return (g_forms & 2) ? 1 : 0; } // rows_balance_one / 
 inline bool pf_wide_on() { return !(g_pf_forms & 1); }
 inline int pf_big_mode() { return (g_pf_forms & 1) ? 0 : ((g_pf_forms & 2) ? 2 : 1); }        // 0 never, 1 by the rule, 2 always
 inline int pf_moe_big_mode() { return (g_pf_forms & 4) ? 0 : ((g_pf_forms & 8) ? 2 : 1); }
-long g_fused_steps = 0; // decode steps enqueued with the attention inside k_qkv's launch (calm_hip_configure("fused_steps"): tests check the path they mean to test ran)
+long g_fused_steps = 0; // decode steps enqueued with the attention inside k_qkv's launch (calm_hip_query("fused_steps"): tests check the path they mean to test ran)
 int g_qkv_attn = 1;    // short-context attention inside k_qkv's launch (kernels.hip.h k_qkv_attn) where the shape allows (fused_ok); 0: k_qkv, then k_attn
 int g_pf_score_mb = 256; // MiB of logits scratch the scoring GEMM may use (prefill_logprobs_hip scores a chunk in blocks of that many rows; read when the scratch is allocated)
 long g_pf_redone = 0;   // prompt tokens sent back through the serial path because an activation left the binary16 range
@@ -239,7 +239,7 @@ struct Ctx {
 	float2 *rope_cs = nullptr, *rope_cs1 = nullptr;
 	TokState* ts = nullptr;
 	unsigned long long* gran = nullptr; // k_qkv_attn's hand-off granules: (q_dim + 2 kv_dim) x {value, tag}, one buffer for every layer
-	unsigned* fuse_err = nullptr;       // device word its bounded waits raise (the head's output is NaN then; calm_hip_configure("fuse_timeouts") reads it)
+	unsigned* fuse_err = nullptr;       // device word its bounded waits raise (the head's output is NaN then; calm_hip_query("fuse_timeouts") reads it)
 	unsigned fuse_salt = 0;             // perf_stage_hip only (FuseArgs::salt)
 	void *kc = nullptr, *vc = nullptr;
 	void* vt = nullptr; // the value cache once more, transposed: [layer][kv_head][head_dim][seq_len] (k_attn_vt); head size 128 only, behind vc in ONE allocation (prepare_ctx)
@@ -631,11 +631,11 @@ int attn_out_grid(const Ctx* c, bool* one_out = nullptr) {
 	return pick_blocks_wg(c->dim / (one ? 1 : KShape<DB, KS_ATTN_OUT>::NR), KShape<DB, KS_ATTN_OUT>::BPC);
 }
 
-// the router's logits travel from k_attn_out's epilogue to k_ffn_up (knob "moe_route"): a mixture-of-experts model whose FFN
+// the router's logits travel from k_attn_out's epilogue to k_ffn_up ("forms" 8 turns it off): a mixture-of-experts model whose FFN
 // normalises the residual k_attn_out completes (not a parallel-residual one, which feeds the FFN the attention norm's output)
 template <int DB>
 bool moe_route_ahead(const Ctx* c) {
-	return g_moe_route && c->gate_mt && attn_out_grid<DB>(c) <= GATE_COLS;
+	return !(g_forms & 8) && c->gate_mt && attn_out_grid<DB>(c) <= GATE_COLS;
 }
 
 template <int DB>
@@ -1573,8 +1573,6 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		slot = &g_split_min;
 	} else if (!strcmp(key, "attn_vt")) {
 		slot = &g_attn_vt;
-	} else if (!strcmp(key, "moe_route")) {
-		slot = &g_moe_route;
 	} else if (!strcmp(key, "forms")) {
 		slot = &g_forms;
 	} else if (!strcmp(key, "pf_forms")) {
@@ -1582,16 +1580,6 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 	} else if (!strcmp(key, "qkv_attn")) {
 		slot = &g_qkv_attn;
 
-	} else if (!strcmp(key, "fused_steps")) {
-		return (int)(g_fused_steps & 0x7fffffff);
-	} else if (!strcmp(key, "fuse_timeouts")) { // bounded waits of k_qkv_attn that expired, over every prepared model (0 unless a launch lost a producer)
-		unsigned total = 0;
-		for (auto& kv : g_ctx) {
-			unsigned e = 0;
-			dev_copy_sync(&e, kv.second->fuse_err, sizeof(e), hipMemcpyDeviceToHost);
-			total += e;
-		}
-		return (int)total;
 	} else if (!strcmp(key, "pf_chunk")) {
 		CALM_REQUIRE(value < 0 || (value >= PF_NT && value <= PF_NT_DENSE && value % 128 == 0), "calm_hip_configure(\"pf_chunk\"): 1024 ... 2048 in steps of 128");
 		slot = &g_pf_chunk;
@@ -1606,17 +1594,6 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		int old_stage = g_alloc_stage;
 		g_alloc_stage = value; // (-1 is a value here, not "query")
 		return old_stage;
-	} else if (!strcmp(key, "stages")) {
-		return (int)g_devs.size();
-	} else if (!strcmp(key, "stage_device")) { // the device stage `value` sits on
-		CALM_REQUIRE(value >= 0 && value < (int)g_devs.size(), "calm_hip_configure(\"stage_device\"): no such stage");
-		return g_devs[value].dev;
-	} else if (!strcmp(key, "handoffs")) { // hand-off copies timed so far (profiled steps of a model split over stages)
-		return (int)g_hop_n;
-	} else if (!strcmp(key, "handoff_ns")) { // ... and their average duration
-		return g_hop_n ? (int)(g_hop_us * 1e3 / (double)g_hop_n) : 0;
-	} else if (!strcmp(key, "pf_redone")) {
-		return (int)g_pf_redone; // prompt tokens prefill_hip sent back through the serial path (activations beyond binary16)
 	} else {
 		return -1;
 	}
@@ -1639,6 +1616,35 @@ extern "C" int calm_hip_configure(const char* key, int value) {
 		*slot = value;
 	}
 	return old;
+}
+
+// read-only state (kept apart from the knobs: nothing here changes a launch)
+extern "C" int calm_hip_query(const char* key, int value) {
+	init_hip();
+	HIP_CHECK(hipStreamSynchronize(g_stream));
+	if (!strcmp(key, "fused_steps")) {
+		return (int)(g_fused_steps & 0x7fffffff);
+	} else if (!strcmp(key, "fuse_timeouts")) { // bounded waits of k_qkv_attn that expired, over every prepared model (0 unless a launch lost a producer)
+		unsigned total = 0;
+		for (auto& kv : g_ctx) {
+			unsigned e = 0;
+			dev_copy_sync(&e, kv.second->fuse_err, sizeof(e), hipMemcpyDeviceToHost);
+			total += e;
+		}
+		return (int)total;
+	} else if (!strcmp(key, "stages")) {
+		return (int)g_devs.size();
+	} else if (!strcmp(key, "stage_device")) { // the device stage `value` sits on
+		CALM_REQUIRE(value >= 0 && value < (int)g_devs.size(), "calm_hip_query(\"stage_device\"): no such stage");
+		return g_devs[value].dev;
+	} else if (!strcmp(key, "handoffs")) { // hand-off copies timed so far (profiled steps of a model split over stages)
+		return (int)g_hop_n;
+	} else if (!strcmp(key, "handoff_ns")) { // ... and their average duration
+		return g_hop_n ? (int)(g_hop_us * 1e3 / (double)g_hop_n) : 0;
+	} else if (!strcmp(key, "pf_redone")) {
+		return (int)g_pf_redone; // prompt tokens prefill_hip sent back through the serial path (activations beyond binary16)
+	}
+	return -1;
 }
 
 extern "C" void init_hip(void) {
@@ -1720,7 +1726,6 @@ extern "C" void init_hip(void) {
 	g_split_t = env_int("CALM_HIP_SPLIT_T", g_split_t);
 	g_split_min = env_int("CALM_HIP_SPLIT_MIN", g_split_min);
 	g_attn_vt = env_int("CALM_HIP_ATTN_VT", g_attn_vt);
-	g_moe_route = env_int("CALM_HIP_MOE_ROUTE", g_moe_route);
 	g_qkv_attn = env_int("CALM_HIP_QKV_ATTN", g_qkv_attn);
 	g_pf_chunk = env_int("CALM_HIP_PF_CHUNK", g_pf_chunk);
 	CALM_REQUIRE(g_pf_chunk >= PF_NT && g_pf_chunk <= PF_NT_DENSE && g_pf_chunk % 128 == 0, "CALM_HIP_PF_CHUNK: 1024 ... 2048 in steps of 128");

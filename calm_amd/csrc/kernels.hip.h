@@ -2214,7 +2214,7 @@ __global__ __launch_bounds__(512) void k_attn_merge(const float* partial, float*
 // ONE: one row per task (tiles of the same size: twice as deep) -- for row counts that leave a full grid's last round of row PAIRS
 // half empty (DBRX's 6144 rows = 3072 pairs over 2048 waves; the host decides: rows_balance)
 constexpr int CALM_ONE_U = 2;
-// GATE (mixture-of-experts models, knob "moe_route"): the router's logits for the FFN that follows are LINEAR in the residual this
+// GATE (mixture-of-experts models; "forms" 8 turns it off): the router's logits for the FFN that follows are LINEAR in the residual this
 // kernel completes -- logit_e = rsqrt(mean(x^2) + eps) * sum_j moegate[e][j] g[j] x[j] (src/infer.c:183-207 then :422-424) -- so the
 // lane that writes x[j] also adds x[j] * (moegate[e][j] g[j]) for every expert e (lane e of the wave: one coalesced load of row j of
 // the [dim][EP] fp32 table `gate_mt` that prepare_hip derives from moegate and the FFN norm weight, k_gate_prep), x[j]^2 and x[j];

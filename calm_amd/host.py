@@ -28,7 +28,7 @@ TEST_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcal
 
 # include/calm_hip.h: the drop-in library
 EXPORTS = [
-    "init_hip", "upload_hip", "alloc_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "release_hip",
+    "init_hip", "upload_hip", "alloc_hip", "prepare_hip", "forward_hip", "perf_hip", "calm_hip_device_count", "calm_hip_device_name", "calm_hip_configure", "calm_hip_query", "release_hip",
     "free_hip", "download_hip", "decode_greedy_hip", "decode_sample_hip", "prefill_hip", "prefill_logprobs_hip", "forward_stage_hip", "copy_hip", "perf_stage_hip",
 ]
 # include/calm_hip_test.h: libcalm_hip_test.so, tests and tools only
@@ -112,6 +112,7 @@ def load_lib() -> "_Libs":
         "calm_hip_device_count": (C.c_int, []),
         "calm_hip_device_name": (C.c_char_p, []),
         "calm_hip_configure": (C.c_int, [C.c_char_p, C.c_int]),
+        "calm_hip_query": (C.c_int, [C.c_char_p, C.c_int]),
         "release_hip": (None, [T]),
         "free_hip": (None, [C.c_void_p]),
         "download_hip": (None, [C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -263,7 +264,7 @@ class HipBackend:
         # CALM_HIP_DEVICES=P > 1: the library splits the layers over P pipeline stages (include/calm_hip.h).  A host that knows
         # tensor names says where each tensor goes before it uploads or generates it; one that does not (run.c) lets upload_hip
         # defer to prepare_hip, for which the host arrays must stay alive until then.
-        self.stages = self.lib.calm_hip_configure(b"stages", -1)
+        self.stages = self.lib.calm_hip_query(b"stages", 0)
         self._keep_host = []
         L, P = model.config.n_layers, self.stages
 

@@ -109,7 +109,7 @@ float* decode_sample_hip(struct Transformer* transformer, int token, int pos, in
  * serial"), computed up to 2048 tokens at a time (mixture-of-experts models: 4096): weights are streamed once per chunk and the multiply-adds run on
  * the f16 matrix cores with the fp32 activations carried as hi + lo binary16 (every product exact, fp32 accumulation:
  * 3-7e-7 per GEMM), so the cache rows agree with the serial path to fp32 rounding.  A chunk in which an activation leaves the binary16 range (beyond +-65504, or NaN)
- * is redone token by token through the serial fp32 decode path inside the call (knob "pf_redone" counts such tokens).
+ * is redone token by token through the serial fp32 decode path inside the call (calm_hip_query("pf_redone") counts such tokens).
  * Returns after the work is complete (`tokens` is host memory and may be reused).
  * Mixture-of-experts models are routed per token on the device and each expert runs one GEMM over the rows
  * routed to it.  Positions at or beyond seq_len (rolling buffer, sink rotation between tokens) are processed
@@ -160,8 +160,8 @@ double perf_stage_hip(struct Transformer* transformer, int stage, int iters, uin
 /* name of the HIP device in use (static storage) */
 const char* calm_hip_device_name(void);
 
-/* Run-time knobs -- twelve (the CALM_HIP_GRAPH / _PROF / _SPLIT_T / _SPLIT_MIN / _ATTN_VT / _MOE_ROUTE / _QKV_ATTN / _PF_CHUNK / _PF_CHUNK_MOE /
- * _PF_SCORE_MB environment variables read by init_hip set the same switches before the first model):
+/* Run-time knobs -- twelve keys, "stage" included (the CALM_HIP_GRAPH / _PROF / _SPLIT_T / _SPLIT_MIN / _ATTN_VT / _QKV_ATTN / _PF_CHUNK /
+ * _PF_CHUNK_MOE / _PF_SCORE_MB environment variables read by init_hip set the same switches before the first model):
  *   "graph"     1 = replay each step from a hipGraph (default), 0 = eager launches
  *   "prof"      1 = eager launches bracketed by per-stage events, reported by perf_hip (a model split over stages: also an event pair
  *               around every stage-to-stage copy)
@@ -169,28 +169,28 @@ const char* calm_hip_device_name(void);
  *   "split_min" contexts up to this many positions are not split (default 384)
  *   "attn_vt"   1 = split attention on the matrix cores over the transposed value cache (default; head size 128), 0 = lane arithmetic.
  *               Read by prepare_hip: 0 at that point also saves the transposed cache's memory (+ 50 % of the KV cache)
- *   "moe_route" 1 = a mixture-of-experts layer's routing is derived from partial sums the attention output projection leaves
- *               (default), 0 = every workgroup of the FFN kernel computes the gate from the vector first (also the form of models
- *               with more than 64 experts or a parallel residual)
  *   "qkv_attn"  1 = a step whose cached rows fit one workgroup's registers (256 at head size 128, 512 at 64; fp8 / fp16 weights) runs
  *               its attention inside the QKV projection's launch (default), 0 = two launches
  *   "forms", "pf_forms": bit sets that force kernel forms the launchers otherwise pick by shape (0 = the rules; the forms are listed at
  *               their definition in calm_amd/csrc/infer_hip.hip) -- for the tests that run every shipping form on small fixtures
  *   "pf_chunk": tokens per prompt chunk of a dense model, 1024 ... 2048 in steps of 128 (default 2048; read when a model's prompt
- *       buffers are allocated, i.e. at its first prefill_hip call)
+ *       buffers are allocated, i.e. at its first prefill_hip call; never more than the context window rounded up to 128)
  *   "pf_chunk_moe": ... of a mixture-of-experts model: 1024, 2048 or 4096 (default 4096; read at the same moment).  The experts'
  *       gathered rows take chunk x active experts x (dim + hidden_dim) x 4 bytes of scratch: 0.8 GB for Mixtral-8x7B, 1.7 GB for
  *       DBRX-132B at 4096, a quarter of that at 1024
  *   "pf_score_mb": MiB of device scratch for the logits of prefill_logprobs_hip (default 256; read when that scratch is allocated, at a
  *       model's first scoring call): a chunk is scored in blocks of as many tokens as fit (whole 128-token columns, at least 128)
- * Placement: "stage" -- multi-device: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to prepare_hip).
- * Queries (value ignored): "stages" (pipeline stages of this process), "stage_device" (value = stage -> its device), "pf_redone"
- * (prompt tokens prefill_hip sent back through the serial path), "handoffs" / "handoff_ns" (stage-to-stage copies timed under "prof"
- * and their average duration), "fused_steps" (decode steps that took the "qkv_attn" launch), "fuse_timeouts" (its bounded waits that
- * expired: 0 unless a launch lost a producer; the affected head's output is NaN).
+ *   "stage"     multi-device placement: route the following upload_hip / alloc_hip calls to that stage's device (-1: defer to
+ *               prepare_hip; -1 is a value here, not a query)
  * value < 0 only queries.  Returns the previous value, or -1 for an unknown key.  Changing a knob that shapes the launches drops
  * the captured graphs of every prepared model (they are re-captured on next use). */
 int calm_hip_configure(const char* key, int value);
+
+/* Read-only state (nothing here changes a launch): "stages" (pipeline stages of this process), "stage_device" (value = stage -> its
+ * device), "pf_redone" (prompt tokens prefill_hip sent back through the serial path), "handoffs" / "handoff_ns" (stage-to-stage copies
+ * timed under "prof" and their average duration), "fused_steps" (decode steps that took the "qkv_attn" launch), "fuse_timeouts" (its
+ * bounded waits that expired: 0 unless a launch lost a producer; the affected head's output is NaN).  -1 for an unknown key. */
+int calm_hip_query(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -84,7 +84,7 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11, outliers=Fal
         # then the decode step at position m against the reference's logits there; and the scored log-probabilities of the stream
         m = n_tokens - 1
         prompt = [first_token] + ref_tokens[: m - 1]
-        redone0 = hip.lib.calm_hip_configure(b"pf_redone", -1)
+        redone0 = hip.lib.calm_hip_query(b"pf_redone", 0)
         hip.prefill(prompt, 0)
         pf_err = rel_err(hip.forward(ref_tokens[m - 1], m, 0), ref_logits[m])
         lp = hip.prefill_logprobs(prompt + [ref_tokens[m - 1]], 0)
@@ -94,7 +94,7 @@ def full_depth_check(name, dtype, n_tokens, seed=3, first_token=11, outliers=Fal
             want.append((lr[ref_tokens[pos]] - lr.max()) - np.log(np.exp(lr - lr.max()).sum()))
         lp_err = float(np.abs(lp[:m] - np.array(want)).max())
         out = {"worst": worst, "diverged": diverged, "ref_tokens": ref_tokens, "hip_tokens": hip_tokens, "prefill": pf_err, "logprob": lp_err,
-               "pf_redone": hip.lib.calm_hip_configure(b"pf_redone", -1) - redone0, "logit_max": float(max(np.abs(l).max() for l in ref_logits))}
+               "pf_redone": hip.lib.calm_hip_query(b"pf_redone", 0) - redone0, "logit_max": float(max(np.abs(l).max() for l in ref_logits))}
         if outliers:  # position 0 against exact arithmetic: who is further from it, the reference or the HIP backend?
             from oracle.f64_step import position0_logits_f64
 

@@ -230,11 +230,11 @@ def test_golden_logits_teacher_forced(hiplib, case, graph):
 def test_expert_counts_that_are_not_powers_of_two_route_like_the_reference(hiplib, case, route):
     """6 experts top-2 (RMSNorm) and 12 experts top-3 (LayerNorm): k_attn_out<GATE> pads its expert rows to a power of two and files the
     norm statistics behind them; k_ffn_up<MOE = 2> must read them THERE (round 4 read rows n_experts, n_experts + 1: the padded experts'
-    zeros, so the picks were right and the mixture weights silently wrong).  Both routing forms -- "moe_route" 1: ahead, from the
-    partial sums; 0: the gate inside k_ffn_up -- against the reference's logits, and the routed experts of the last step against the
+    zeros, so the picks were right and the mixture weights silently wrong).  Both routing forms -- ahead, from the
+    partial sums (the rule); "forms" 8: the gate inside k_ffn_up -- against the reference's logits, and the routed experts of the last step against the
     oracle's (src/infer.c:277-305)."""
     model, z = load_golden(case)
-    old = hiplib.calm_hip_configure(b"moe_route", route)
+    old = hiplib.calm_hip_configure(b"forms", 0 if route else 8)
     b = HipBackend(model)
     cpu = oracle.OracleBackend(model)
     try:
@@ -250,7 +250,7 @@ def test_expert_counts_that_are_not_powers_of_two_route_like_the_reference(hipli
                 assert abs(float(np.sum(w[:k])) - 1.0) < 1e-5
     finally:
         b.close()
-        hiplib.calm_hip_configure(b"moe_route", old)
+        hiplib.calm_hip_configure(b"forms", old)
 
 
 @pytest.mark.parametrize("case", ["tiny_fp8", "moe_fp8", "sink_fp16", "bias_tied_gf4", "moe_gf4", "dbrx_like_fp8"])
@@ -275,7 +275,7 @@ def test_launch_forms_that_only_reorder_work_are_bit_identical(hiplib, name, dty
     """Round 4's forms that change WHO does a row or WHERE its activations are read from, not its arithmetic -- activations in registers,
     the skewed deal of k_ffn_up's task rounds, all experts' images side by side in k_ffn_down -- must leave every logit bit-identical
     to the plain forms ("forms" 1; full-width shapes: the forms only engage at dim 4096 / 2048 and full grids).
-    "moe_route" changes the router's summation order: same experts away from near-ties, logits within the common tolerance."""
+    "forms" 8 (the gate computed inside k_ffn_up) changes the router's summation order: same experts away from near-ties, logits within the common tolerance."""
     spec = cf.SPECS[name]
     tensors, md = cf.synth_model_big(spec, dtype, seed=17, n_layers=layers)
     model = HostModel(tensors, md, context=64)
@@ -295,11 +295,11 @@ def test_launch_forms_that_only_reorder_work_are_bit_identical(hiplib, name, dty
     finally:
         hiplib.calm_hip_configure(b"forms", old)
     if spec.n_experts:
-        old = hiplib.calm_hip_configure(b"moe_route", 0)
+        old = hiplib.calm_hip_configure(b"forms", 8)
         try:
             assert rel_err(run(), base) < LOGIT_TOL
         finally:
-            hiplib.calm_hip_configure(b"moe_route", old)
+            hiplib.calm_hip_configure(b"forms", old)
 
 
 @pytest.mark.parametrize("knob", [1, 0])
@@ -311,14 +311,14 @@ def test_attention_inside_the_qkv_launch_gives_the_reference_logits(hiplib, case
     the tag's layer field, the rolling 16-row buffer a masked slot in the middle of the cached range and the re-rotated sink keys."""
     model, z = load_golden(case)
     old = hiplib.calm_hip_configure(b"qkv_attn", knob)
-    before = hiplib.calm_hip_configure(b"fused_steps", -1)
+    before = hiplib.calm_hip_query(b"fused_steps", 0)
     b = HipBackend(model)
     try:
         for pos, tok in enumerate(z["tokens"]):
             assert rel_err(b.forward(int(tok), pos, 0), z["logits"][pos]) < LOGIT_TOL, pos
-        ran = hiplib.calm_hip_configure(b"fused_steps", -1) - before
+        ran = hiplib.calm_hip_query(b"fused_steps", 0) - before
         assert ran == (len(z["tokens"]) if knob else 0), "the step did not take the launch form this test is about"
-        assert hiplib.calm_hip_configure(b"fuse_timeouts", -1) == 0
+        assert hiplib.calm_hip_query(b"fuse_timeouts", 0) == 0
         k = b.read_kv(0, 0).astype(np.float32)
         kg = z["k_last"].view(np.float16).astype(np.float32)
         assert np.abs(k - kg).max() <= 2e-3 * max(np.abs(kg).max(), 1.0)
@@ -340,11 +340,11 @@ def test_attention_inside_the_qkv_launch_agrees_with_two_launches_at_full_width(
 
     def run(v):
         old = hiplib.calm_hip_configure(b"qkv_attn", v)
-        before = hiplib.calm_hip_configure(b"fused_steps", -1)
+        before = hiplib.calm_hip_query(b"fused_steps", 0)
         b = HipBackend(model, kvbits=kvbits)
         try:
             out = np.stack([b.forward((7 * pos + 3) % spec.vocab_size, pos, 0).copy() for pos in range(n)])
-            return out, hiplib.calm_hip_configure(b"fused_steps", -1) - before
+            return out, hiplib.calm_hip_query(b"fused_steps", 0) - before
         finally:
             b.close()
             hiplib.calm_hip_configure(b"qkv_attn", old)
@@ -352,7 +352,7 @@ def test_attention_inside_the_qkv_launch_agrees_with_two_launches_at_full_width(
     two, ran0 = run(0)
     one, ran1 = run(1)
     assert ran0 == 0 and ran1 == (0 if dtype == "gf4" else (256 if spec.head_dim == 128 else n)), (ran0, ran1)
-    assert np.isfinite(one).all() and hiplib.calm_hip_configure(b"fuse_timeouts", -1) == 0
+    assert np.isfinite(one).all() and hiplib.calm_hip_query(b"fuse_timeouts", 0) == 0
     worst = max(rel_err(one[p], two[p]) for p in range(n))
     assert worst < (2e-5 if kvbits == 16 else FP8KV_TOL), worst
 
@@ -782,16 +782,16 @@ def test_prefill_falls_back_to_the_serial_path_when_an_activation_leaves_binary1
         lo = o.forward(toks[-1], 40, 0).copy()
         assert biggest > 65504.0, "the fixture no longer leaves the binary16 range"
         ls = serial.forward(toks[-1], 40, 0).copy()
-        before = hiplib.calm_hip_configure(b"pf_redone", -1)
+        before = hiplib.calm_hip_query(b"pf_redone", 0)
         batched.prefill(toks[:-1], 0)
-        assert hiplib.calm_hip_configure(b"pf_redone", -1) == before + 40, "the chunk was not sent back through the serial path"
+        assert hiplib.calm_hip_query(b"pf_redone", 0) == before + 40, "the chunk was not sent back through the serial path"
         lb = batched.forward(toks[-1], 40, 0).copy()
         assert np.array_equal(lb, ls)
         assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)
         lp = batched.prefill_logprobs(toks, 0)  # scoring takes the same way out
         assert np.isfinite(lp).all()
         # ... and a model of the usual scale does not take it
-        before = hiplib.calm_hip_configure(b"pf_redone", -1)
+        before = hiplib.calm_hip_query(b"pf_redone", 0)
     finally:
         o.close()
         serial.close()
@@ -800,7 +800,7 @@ def test_prefill_falls_back_to_the_serial_path_when_an_activation_leaves_binary1
     b2 = HipBackend(model2)
     try:
         b2.prefill([int(t) for t in z["tokens"]][:-1], 0)
-        assert hiplib.calm_hip_configure(b"pf_redone", -1) == before
+        assert hiplib.calm_hip_query(b"pf_redone", 0) == before
     finally:
         b2.close()
 
@@ -835,9 +835,9 @@ def test_prefill_redoes_only_from_the_first_chunk_that_left_binary16(hiplib):
             serial.forward(tok, pos, abi.FF_UPDATE_KV_ONLY)
         lo = o.forward(toks[-1], 1100, 0).copy()
         ls = serial.forward(toks[-1], 1100, 0).copy()
-        before = hiplib.calm_hip_configure(b"pf_redone", -1)
+        before = hiplib.calm_hip_query(b"pf_redone", 0)
         batched.prefill(toks[:-1], 0)
-        assert hiplib.calm_hip_configure(b"pf_redone", -1) == before + (1100 - 1024), "tokens redone: the second chunk's, no more, no fewer"
+        assert hiplib.calm_hip_query(b"pf_redone", 0) == before + (1100 - 1024), "tokens redone: the second chunk's, no more, no fewer"
         lb = batched.forward(toks[-1], 1100, 0).copy()
         assert rel_err(lb, ls) < 2e-5, rel_err(lb, ls)  # (first-chunk rows from the batched path: fp32-rounding apart from the serial ones)
         assert rel_err(lb, lo) < LOGIT_TOL, rel_err(lb, lo)

@@ -37,7 +37,7 @@ WORKER = textwrap.dedent(
         out.append(b.forward(tok, pos, 0).copy())
     np.save(os.environ["CALM_OUT"], np.stack(out))
     sys.stdout.write(json.dumps({"stages": b.stages, "devices": b.lib.calm_hip_device_count(),
-                                 "stage_devices": [b.lib.calm_hip_configure(b"stage_device", s) for s in range(b.stages)]}) + "\\n")
+                                 "stage_devices": [b.lib.calm_hip_query(b"stage_device", s) for s in range(b.stages)]}) + "\\n")
     b.close()
     """
 )

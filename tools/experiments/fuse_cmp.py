@@ -18,4 +18,4 @@ for v in (0, 1):
 for pos in range(N):
     a, b = outs[0][pos], outs[1][pos]
     print(pos, float(np.abs(a - b).max() / np.abs(a).max()), bool(np.isfinite(b).all()))
-print("timeouts", lib.calm_hip_configure(b"fuse_timeouts", -1))
+print("timeouts", lib.calm_hip_query(b"fuse_timeouts", 0))
