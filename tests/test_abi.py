@@ -176,3 +176,14 @@ def test_no_kernel_of_the_product_touches_scratch_memory(tmp_path):
     assert len(names) == len(sizes) and len(names) > 100  # every template instantiation is a kernel
     bad = {n: s for n, s in zip(names, sizes) if s}
     assert not bad, f"kernels using scratch memory: {bad}"
+
+
+def test_torch_must_come_before_the_library(hiplib):
+    """a process that uses RCCL through torch AND this library initialises torch first (torch ships its own HIP runtime; INTEGRATION.md
+    section D): once libcalm_hip.so is loaded the guard of bench.py --gpus N / calm_amd.pipeline refuses with a message"""
+    from calm_amd import host
+
+    assert host.lib_loaded()
+    with pytest.raises(RuntimeError, match="BEFORE"):
+        host.require_torch_first("test")
+

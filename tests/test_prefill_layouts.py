@@ -38,6 +38,37 @@ def test_fragment_major_matrix_is_a_bijection_in_lane_order(n, tokens):
             assert (t, k, h) == (32 * g + (lane & 31), 64 * s + 32 * (lane >> 5) + 8 * m, hl)
 
 
+def pf_norm_grid(nb, n, ncu):
+    """k_pf_norm's grid (prefill.hip.h: pf_norm_grid): 8-token groups x column slices"""
+    groups = (nb + 7) // 8
+    slices = min(8, (2 * ncu + groups - 1) // groups)
+    while slices > 1 and (n >> 3) // slices < 8:
+        slices -= 1
+    return groups, max(1, slices)
+
+
+@pytest.mark.parametrize("n,nb", [(4096, 2048), (4096, 128), (2048, 3), (6144, 777), (64, 9), (288, 40)])
+def test_norm_kernel_writes_whole_lines_and_covers_every_unit_once(n, nb):
+    """k_pf_norm (round 6): a workgroup = 8 consecutive tokens x one column slice, a thread = (token t0 + tid % 8, blocks of 8 columns
+    tid / 8, + 32, ...).  What it relies on: the eight tokens' units of the same 8 columns are ONE aligned 128-byte line (so a
+    workgroup writes whole lines), and groups x slices x threads cover every (token < nb, column block) exactly once."""
+    nsteps = (n + 63) // 64
+    for t0, k in itertools.product(range(0, 64, 8), range(0, min(n, 256), 8)):
+        units = [pf_unit(t0 + j, k, nsteps) for j in range(8)]
+        assert units == list(range(units[0], units[0] + 8)) and units[0] % 8 == 0  # 8 x 16 bytes, line-aligned
+    groups, slices = pf_norm_grid(nb, n, 256)
+    nkb = n >> 3
+    per = (nkb + slices - 1) // slices
+    seen = set()
+    for g, y, tid in itertools.product(range(groups), range(slices), range(256)):
+        t = 8 * g + (tid & 7)
+        for kb in range(y * per + (tid >> 3), min(nkb, (y + 1) * per), 32):
+            if t < nb:
+                assert (t, kb) not in seen
+                seen.add((t, kb))
+    assert len(seen) == nb * nkb
+
+
 def mfma_key(u, hh, e):
     """key (within a 32-key tile) that lane-half hh's element e of P operand u stands for: P comes out of S^T's accumulator, whose
     register i of lane-half hh is row (i & 3) + 8 (i >> 2) + 4 hh; operand u is registers 8u .. 8u + 7"""
